@@ -1,0 +1,321 @@
+"""Known-answer tests for the CPU restatement (oracle), hand-derived from the cited
+reference lines (SURVEY.md §8c "KATs") plus the two structural pins the reference
+tree itself holds (tests/golden/reference_pins.json).  CPU only."""
+import json
+import os
+
+import numpy as np
+
+from tests import synth
+from tests.oracle_lib import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = json.load(open(os.path.join(HERE, "golden", "reference_pins.json")))
+
+F_PAIRED, F_PROPER, F_UNMAP, F_MUNMAP, F_REV, F_MREV, F_FIRST, F_LAST = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
+MATE_MAIN = 0x1000
+
+
+def h8(s):
+    v = 0
+    for c in s:
+        v = v * 4 + "ACGT".index(c)
+    return v
+
+
+def run(cols, refs=None, **kw):
+    o = Oracle(n_refs=max(1, len(refs) if refs else 1), **kw)
+    if refs:
+        for i, r in enumerate(refs):
+            o.reference(i, r)
+    rc = o.process(cols)
+    return rc, o.finalize()[0] if rc == 0 else None
+
+
+def test_8mer_kat_plain():
+    # OverallNumbers.hpp:137-168; seq ACGTACGTAC -> windows ACGTACGT, CGTACGTA, GTACGTAC
+    cols = synth.single_read("ACGTACGTAC", [30] * 10, [(10, "M")], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    assert rc == 0
+    nz = np.nonzero(c["eightmer"])[0].tolist()
+    assert nz == sorted([6939, 27756, 45489])
+    assert h8("ACGTACGT") == 6939 and h8("CGTACGTA") == 27756 and h8("GTACGTAC") == 45489
+    assert all(c["eightmer"][i] == 1 for i in nz)
+
+
+def test_8mer_kat_N_skips_window():
+    cols = synth.single_read("ACGTNCGTACGTACGT", [30] * 16, [(16, "M")], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    nz = {int(i): int(c["eightmer"][i]) for i in np.nonzero(c["eightmer"])[0]}
+    assert nz == {27756: 1, 45489: 1, 50886: 1, 6939: 1}
+
+
+def test_8mer_orientation_pin_adapter():
+    # bamqc_summary.py adapter_8_mers: every 8-mer of this 56-mer (reverse complement of the
+    # TruSeq universal adapter) is in the hard-coded index list => index is big-endian base 4.
+    adapter = "ATCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGCCGTATCATT"
+    cols = synth.single_read(adapter, [30] * len(adapter), [(len(adapter), "M")], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    nz = set(np.nonzero(c["eightmer"])[0].tolist())
+    assert len(nz) == 49
+    assert nz <= set(PINS["adapter_8mer_indices"])
+
+
+def test_8mer_reverse_strand_counts_revcomp():
+    # bamqualcheck.cpp:345-350: count8mers sees the reverse-complemented sequence
+    cols = synth.single_read("AAAAAAAACC", [30] * 10, [(10, "M")], F_PAIRED | F_FIRST | F_REV | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    nz = set(np.nonzero(c["eightmer"])[0].tolist())
+    assert nz == {h8("GGTTTTTT"), h8("GTTTTTTT"), h8("TTTTTTTT")}
+
+
+def _cov_read(pos, L=150, flag=F_PAIRED | F_FIRST | MATE_MAIN, cigar=None):
+    return synth.single_read("A" * L, [30] * L, cigar or [(L, "M")], flag, pos=pos, rid=0, mapq=0, as_=0)
+
+
+def test_coverage_kat_windows():
+    # OverallNumbers.hpp:79-135: reads at 100, 1100 (pos==1000: no slide), 1101 (slides)
+    cols = synth.concat([_cov_read(100), _cov_read(1100), _cov_read(1101)])
+    rc, c = run(cols)
+    assert rc == 0
+    assert int(c["poscov"][0]) == 2699 and int(c["poscov"][1]) == 152 and int(c["poscov"][2]) == 149
+    assert int(c["poscov"].sum()) == 3000
+
+
+def test_coverage_no_reads_gives_2000_zero_positions():
+    cols = synth.single_read("A" * 20, [30] * 20, [], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    assert int(c["poscov"][0]) == 2000 and int(c["poscov"].sum()) == 2000
+
+
+def test_coverage_leading_softclip_shifts_and_eqx_ignored():
+    # :112-134: S advances c without counting; '=' / 'X' contribute nothing
+    cols = synth.concat([_cov_read(0, cigar=[(10, "S"), (140, "M")]), _cov_read(0, cigar=[(150, "=")])])
+    rc, c = run(cols)
+    assert int(c["poscov"][1]) == 140 and int(c["poscov"][0]) == 2000 - 140
+
+
+def test_coverage_reset_on_chromosome_change_and_gap():
+    a = _cov_read(0)
+    b = _cov_read(5000)  # gap > 2000 -> flush both windows, new anchor
+    cc = _cov_read(10)
+    cc["rid"][:] = 1     # chromosome change -> reset
+    cols = synth.concat([a, b, cc])
+    o = Oracle(n_refs=2)
+    assert o.process(cols) == 0
+    c = o.finalize()[0]
+    assert int(c["poscov"].sum()) == 6000 and int(c["poscov"][1]) == 450
+
+
+def test_coverage_exact_2000_offset_dropped():
+    # read at shift+2000 neither slides nor resets (:91,:104) and all its increments fall at
+    # window offset >= 2000 -> DEFINED: dropped
+    cols = synth.concat([_cov_read(0), _cov_read(2000)])
+    rc, c = run(cols)
+    assert int(c["poscov"][1]) == 150 and int(c["poscov"].sum()) == 2000
+
+
+def test_triplet_kat_and_index_pin():
+    # TripletCounting.hpp:195-236; reference ACGTACGT..., read = reference[0:10]
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    cols = synth.single_read("ACGTACGTAC", [40] * 10, [(10, "M")], F_PAIRED | F_PROPER | F_FIRST | MATE_MAIN,
+                             pos=0, mapq=60, as_=100)
+    rc, c = run(cols, refs=[ref])
+    assert rc == 0
+    t = c["triplet"].reshape(64, 4, 4)  # ctx, group (fwd1st, fwd2nd, rev1st, rev2nd), base
+    expect = {("ACG", "C"): 2, ("CGT", "G"): 2, ("GTA", "T"): 2, ("TAC", "A"): 2}
+    for (ctx, base), n in expect.items():
+        idx = PINS["triplet_seq"].index(ctx)  # reference's own index->context mapping
+        assert idx == 16 * "ACGT".index(ctx[0]) + 4 * "ACGT".index(ctx[1]) + "ACGT".index(ctx[2])
+        assert int(t[idx, 0, "ACGT".index(base)]) == n
+    assert int(t.sum()) == 8
+    assert [PINS["triplet_seq"].index(x) for x in ("ACG", "CGT", "GTA", "TAC")] == [6, 27, 44, 49]
+
+
+def test_triplet_filters():
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    base = dict(pos=0, mapq=60, as_=100)
+    ok = F_PAIRED | F_PROPER | F_FIRST
+    cases = [
+        (ok, [(10, "M")], base, 8),
+        (ok | F_REV, [(10, "M")], base, 8),                      # strand is a don't-care
+        (ok & ~F_PROPER, [(10, "M")], base, 0),                  # proper pair required
+        (ok | F_MUNMAP, [(10, "M")], base, 0),
+        (ok, [(10, "M")], dict(pos=0, mapq=59, as_=100), 0),     # mapQ >= 60
+        (ok, [(10, "M")], dict(pos=0, mapq=60, as_=49), 0),      # AS >= 50
+        (ok, [(2, "S"), (8, "M")], base, 0),                     # no clipping allowed
+        (ok | 0x400, [(10, "M")], base, 0),                      # duplicate: caller guard
+        (ok | 0x200, [(10, "M")], base, 0),                      # QC fail: caller guard
+    ]
+    for flag, cig, kw, n in cases:
+        cols = synth.single_read("ACGTACGTAC", [40] * 10, cig, flag, **kw)
+        rc, c = run(cols, refs=[ref])
+        assert rc == 0 and int(c["triplet"].sum()) == n, (hex(flag), cig, kw)
+
+
+def test_triplet_as_missing_or_negative_is_fatal():
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    ok = F_PAIRED | F_PROPER | F_FIRST
+    for as_ in (synth.BQC_AS_ABSENT, -5):
+        cols = synth.single_read("ACGTACGTAC", [40] * 10, [(10, "M")], ok, pos=0, mapq=60, as_=as_)
+        rc, _ = run(cols, refs=[ref])
+        assert rc == 4  # BQC_ERR_AS_TAG
+    # ... but only for reads that passed flags + mapQ
+    cols = synth.single_read("ACGTACGTAC", [40] * 10, [(10, "M")], ok, pos=0, mapq=10, as_=synth.BQC_AS_ABSENT)
+    rc, _ = run(cols, refs=[ref])
+    assert rc == 0
+
+
+def test_triplet_low_quality_and_mismatching_flank():
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    ok = F_PAIRED | F_PROPER | F_FIRST
+    q = [40] * 10
+    q[3] = 19  # Phred 19 < 20 -> position 3 skipped
+    cols = synth.single_read("ACGTACGTAC", q, [(10, "M")], ok, pos=0, mapq=60, as_=100)
+    rc, c = run(cols, refs=[ref])
+    assert int(c["triplet"].sum()) == 7
+    # a mismatch at read position 4 removes positions 3 and 5 (flank mismatch) but position 4
+    # itself is counted with the read's base
+    cols = synth.single_read("ACGTCCGTAC", [40] * 10, [(10, "M")], ok, pos=0, mapq=60, as_=100)
+    rc, c = run(cols, refs=[ref])
+    t = c["triplet"].reshape(64, 4, 4)
+    assert int(t.sum()) == 6
+    assert int(t[PINS["triplet_seq"].index("TAC"), 0, 1]) == 1  # context TAC, read base C
+
+
+def test_triplet_deletion_and_insertion_walk():
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    ok = F_PAIRED | F_PROPER | F_FIRST
+    # 4M4D6M on ACGT-periodic reference: deleting a whole period keeps the read identical
+    cols = synth.single_read("ACGTACGTAC", [40] * 10, [(4, "M"), (4, "D"), (6, "M")], ok, pos=0, mapq=60, as_=100, nm=4)
+    rc, c = run(cols, refs=[ref])
+    assert int(c["triplet"].sum()) == 8
+    # 4M2I4M: inserted bases (positions 4,5) are skipped, flanks use raw neighbours
+    cols = synth.single_read("ACGTTTACGT", [40] * 10, [(4, "M"), (2, "I"), (4, "M")], ok, pos=0, mapq=60, as_=100, nm=2)
+    rc, c = run(cols, refs=[ref])
+    # evaluated read positions 1,2,3 (chromPos 1,2,3) and 6,7,8 (chromPos 4,5,6):
+    #   3: right neighbour seq[4]=T != ref[4]=A -> skipped
+    #   6: left neighbour is the INSERTED base seq[5]=T, compared against ref[3]=T -> counted (quirk kept)
+    t = c["triplet"].reshape(64, 4, 4)
+    assert int(t.sum()) == 2 + 3
+    assert int(t[PINS["triplet_seq"].index("TAC"), 0, 0]) == 1
+
+
+def test_softclip_kat():
+    L = 150
+    for cig, exp5, exp3 in (([(5, "S"), (140, "M"), (5, "S")], range(0, 5), []),
+                            ([(145, "M"), (5, "S")], [], range(145, 150)),
+                            ([(5, "H"), (5, "S"), (140, "M")], [], [])):
+        lq = sum(n for n, c in cig if c in "MIS=X")
+        cols = synth.single_read("A" * lq, [30] * lq, cig, F_PAIRED | F_FIRST | MATE_MAIN, pos=100, mapq=30)
+        rc, c = run(cols)
+        assert np.nonzero(c["r1.sc5"])[0].tolist() == list(exp5)
+        assert np.nonzero(c["r1.sc3"])[0].tolist() == list(exp3)
+
+
+def test_softclip_reverse_strand_uses_reversed_cigar():
+    # bamqualcheck.cpp:349: cigar reversed for RC reads -> BAM-order trailing clip is the 5' clip
+    cols = synth.single_read("A" * 150, [30] * 150, [(145, "M"), (5, "S")], F_PAIRED | F_FIRST | F_REV | MATE_MAIN, pos=100)
+    rc, c = run(cols)
+    assert np.nonzero(c["r1.sc5"])[0].tolist() == [0, 1, 2, 3, 4] and c["r1.sc3"].sum() == 0
+
+
+def test_avgqual_kat():
+    # QualityCheck.hpp:161-165: L=150, sum=4530 -> mean 30.2 -> bin 30, array length >= 32
+    q = [30] * 150
+    for i in range(30):
+        q[i] = 31
+    assert sum(q) == 4530
+    cols = synth.single_read("A" * 150, q, [], F_PAIRED | F_LAST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    assert len(c["r2.averageQual"]) == 32 and int(c["r2.averageQual"][30]) == 1
+    assert int(c["r2.qualcount"][0]) == 31 and int(c["r2.qualcount"][149]) == 30
+
+
+def test_avgqual_rounding_half_away_from_zero():
+    # mean exactly 30.5 -> round() gives 31; ceil 31 -> length 32
+    q = [30] * 4 + [31] * 4
+    cols = synth.single_read("ACGTACGT", q, [], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    assert int(c["r1.averageQual"][31]) == 1 and len(c["r1.averageQual"]) == 32
+
+
+def test_flag_cascade_kat():
+    # flag 0x400|0x41 mapped on a main chromosome
+    ref = np.zeros(1000, np.uint8)
+    cols = synth.single_read("A" * 50, [30] * 50, [(50, "M")], 0x400 | 0x41 | MATE_MAIN, pos=10, mapq=60, nm=0, as_=50)
+    rc, c = run(cols, refs=[ref])
+    s = dict(zip(__import__("bamqc_amd._abi", fromlist=["x"]).SCALAR_NAMES, c["scalars"].tolist()))
+    assert s["duplicates"] == 1 and s["readcount"] == 1 and s["totalbps"] == 50
+    assert int(c["triplet"].sum()) == 0
+    assert int(c["r1.mapQ"][60]) == 1 and int(c["r1.delhist"][0]) == 1 and int(c["r1.mismatch"][0]) == 1
+    assert int(c["r1.insertSize"][300]) == 1
+    assert int(c["poscov"][0]) == 2000           # no coverage for duplicates
+    assert s["first_and_or_second_mapped"] == 0
+    assert int(c["eightmer"][0]) == 43            # 8-mers are counted regardless
+
+
+def test_supplementary_and_secondary_are_skipped():
+    a = synth.single_read("A" * 20, [30] * 20, [(20, "M")], 0x800 | 0x41, pos=10)
+    b = synth.single_read("A" * 20, [30] * 20, [(20, "M")], 0x100 | 0x41, pos=10)
+    d = synth.single_read("A" * 20, [30] * 20, [(20, "M")], 0x900 | 0x41, pos=10)  # both: supplementary wins
+    rc, c = run(synth.concat([a, b, d]))
+    assert c["scalars"].tolist()[:5] == [2, 0, 0, 1, 0]
+    assert c["eightmer"].sum() == 0
+
+
+def test_no_mate_flag_is_fatal():
+    cols = synth.single_read("A" * 20, [30] * 20, [(20, "M")], 0x1, pos=10)
+    rc, _ = run(cols)
+    assert rc == 3
+
+
+def test_scalar_counters_pairs():
+    recs = [
+        synth.single_read("A" * 20, [30] * 20, [], F_PAIRED | F_FIRST | F_UNMAP | F_MUNMAP, rid=-1, pos=-1),
+        synth.single_read("A" * 20, [30] * 20, [], F_PAIRED | F_LAST | F_UNMAP | F_MUNMAP, rid=-1, pos=-1),
+        synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_PROPER | F_FIRST | F_MREV | MATE_MAIN, pos=5, mapq=30),
+        synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_PROPER | F_LAST | F_REV | MATE_MAIN, pos=200, mapq=30),
+        synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_PROPER | F_FIRST | MATE_MAIN, pos=300, mapq=30),  # FF
+    ]
+    rc, c = run(synth.concat(recs))
+    from bamqc_amd._abi import SCALAR_NAMES
+    s = dict(zip(SCALAR_NAMES, c["scalars"].tolist()))
+    assert s["readcount"] == 5 and s["bothunmapped"] == 1 and s["firstunmapped"] == 1 and s["secondunmapped"] == 1
+    assert s["properpair_count"] == 2 and s["FF_RR_orientation"] == 1
+    assert s["first_and_or_second_mapped"] == 2 and s["auto_properpair_count"] == 2
+
+
+def test_insert_size_overflow_bin_and_mate_chrom():
+    a = synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_FIRST | MATE_MAIN, pos=5, tlen=-5000)
+    b = synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_FIRST, pos=5, tlen=100)  # mate not on main chrom
+    rc, c = run(synth.concat([a, b]), isize=1000)
+    assert len(c["r1.insertSize"]) == 1001 and int(c["r1.insertSize"][1000]) == 1 and int(c["r1.insertSize"].sum()) == 1
+
+
+def test_mismatch_uses_nm_minus_indels_and_missing_nm():
+    a = synth.single_read("A" * 20, [30] * 20, [(10, "M"), (2, "I"), (8, "M")], F_PAIRED | F_FIRST, pos=5, nm=5)
+    b = synth.single_read("A" * 20, [30] * 20, [(20, "M")], F_PAIRED | F_FIRST, pos=5, nm=-1)
+    rc, c = run(synth.concat([a, b]))
+    assert c["r1.mismatch"].tolist() == [0, 0, 0, 1] and c["r1.inshist"].tolist() == [1, 0, 1]
+    # NM < D+I: fatal range error (DEFINED; the reference would try to allocate ~16 GB)
+    bad = synth.single_read("A" * 20, [30] * 20, [(10, "M"), (2, "I"), (8, "M")], F_PAIRED | F_FIRST, pos=5, nm=1)
+    rc, _ = run(bad)
+    assert rc == 6
+
+
+def test_base_counts_dna5_and_literal_N_GC():
+    # QualityCheck.hpp:122-166: non-ACGT -> bin 4, but cntN counts literal 'N' only
+    cols = synth.single_read("ACGTNRYC", [10] * 8, [], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(cols)
+    assert c["r1.dnacount4"].tolist() == [0, 0, 0, 0, 1, 1, 1, 0]
+    assert c["r1.Ncount"].tolist() == [0, 1, 0, 0, 0, 0, 0, 0, 0]
+    assert int(c["r1.GCcount"][3]) == 1
+
+
+def test_lengths_follow_longest_read():
+    a = synth.single_read("A" * 30, [30] * 30, [], F_PAIRED | F_FIRST | F_UNMAP, rid=-1, pos=-1)
+    b = synth.single_read("A" * 50, [30] * 50, [], F_PAIRED | F_LAST | F_UNMAP, rid=-1, pos=-1)
+    rc, c = run(synth.concat([a, b]))
+    assert c["r1.n_cycles"] == 30 and c["r2.n_cycles"] == 50
+    assert len(c["r1.Ncount"]) == 31 and len(c["r2.readLength"]) == 51 and len(c["r1.mapQ"]) == 0
