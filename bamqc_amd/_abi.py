@@ -1,8 +1,8 @@
 """ctypes mirror of include/bamqc.h (the C ABI of the aggregation path).
 
 Only structure layouts and small marshalling helpers live here; the library
-itself is loaded in `bamqc_amd._lib`.  The oracle (test infrastructure) uses the
-same structures, so tests marshal one batch and hand it to both sides.
+itself is loaded in `bamqc_amd._lib`.  The test suite's CPU checker accepts the same
+structures, so tests marshal one batch and hand it to both sides.
 """
 import ctypes as C
 
@@ -79,6 +79,12 @@ class LaneCounts(C.Structure):
 
 class Counts(C.Structure):
     _fields_ = [("n_lanes", C.c_uint32), ("lanes", C.POINTER(LaneCounts))]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_read_index", C.c_uint64), ("n_reads", C.c_uint32),
+                ("read_len", C.c_uint32), ("n_refs", C.c_uint32), ("ref_len", u32p), ("n_lanes", C.c_uint32),
+                ("isize", C.c_int32), ("long_reads", C.c_int32)]
 
 
 class HeaderInfo(C.Structure):

@@ -1,0 +1,750 @@
+// bqc_api.cpp — host side of libbamqc_gpu.so: context, host pre-pass, device batches, launches,
+// finalisation.  Implements include/bamqc.h.  There is NO CPU fallback in this library: without a
+// working HIP device bqc_create fails with BQC_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bamqc.h"
+#include "device_types.h"
+#include "sketch.h"
+
+extern "C" {
+void bqc_launch_reads(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
+void bqc_launch_bases(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, int variant, hipStream_t);
+void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, const uint32_t* parity, hipStream_t);
+void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
+void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
+void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
+hipError_t bqc_kernels_init();
+}
+
+static thread_local char g_create_err[512];
+
+struct LaneCov { // host side of OverallNumbers' window state machine (OverallNumbers.hpp:84-110)
+    bool first = true;
+    int32_t id = 0;
+    int32_t shift = 0;
+    uint64_t win = 0;        // absolute index (flush order) of the window currently held in v1
+    uint64_t batch_base = 0; // absolute window index that is batch-relative window 0 (= carry windows 0,1)
+};
+
+struct bqc_dbatch {
+    void* dmem = nullptr;
+    size_t dbytes = 0;
+    DevBatch d{};
+    uint8_t* d_lane_mask = nullptr; // [n_lanes] lanes that own coverage tiles in this batch
+    uint64_t algo_bytes = 0;
+    std::vector<uint64_t> add_idx, add_val; // host-computed additions (zero-depth windows)
+    uint64_t* d_add_idx = nullptr;
+    uint64_t* d_add_val = nullptr;
+};
+
+struct bqc_ctx {
+    bqc_options opt{};
+    std::vector<uint8_t> main_chrom;
+    std::vector<int32_t> fasta_index;
+    StateLayout sl{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n_cu = 256;
+    uint64_t* d_state = nullptr;
+    uint32_t* d_err = nullptr;
+    uint32_t* d_carry = nullptr;  // [lane][2][2000]
+    uint32_t* d_parity = nullptr; // [lane]
+    uint8_t* d_started = nullptr; // [lane]
+    // references
+    std::vector<uint8_t*> d_ref;
+    std::vector<uint64_t> ref_len;
+    uint8_t** d_ref_ptrs = nullptr;
+    uint64_t* d_ref_len = nullptr;
+    uint8_t* d_main = nullptr;
+    // coverage / genome host state
+    std::vector<LaneCov> cov;
+    int32_t fasta_cursor = -1;
+    bool flushed = false;
+    bool poisoned = false;
+    // sketch (N1)
+    SketchDevice* sketch = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<const char*> tnames;
+    std::vector<float> tms;
+    int n_timed = 0;
+    // finalize output
+    std::vector<uint64_t> h_state;
+    std::vector<std::vector<uint64_t>> arrays;
+    std::vector<bqc_lane_counts> lanes;
+    std::vector<std::vector<bqc_sketch_counts>> sk_out;
+    bqc_counts counts{};
+    int bases_variant = 0; // 0 fused, 1 split (BQC_BASES_SPLIT=1)
+    std::string err;
+};
+
+static int fail(bqc_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else snprintf(g_create_err, sizeof g_create_err, "%s", buf);
+    return code;
+}
+#define HIPCHK(c, call)                                                                                     \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail(c, BQC_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int bqc_abi_version(void) { return BQC_ABI_VERSION; }
+extern "C" const char* bqc_last_error(const bqc_ctx* c) { return c ? c->err.c_str() : g_create_err; }
+
+static int upload_ref_tables(bqc_ctx* c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->d_ref_ptrs, c->d_ref.data(), sizeof(uint8_t*) * c->d_ref.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ref_len, c->ref_len.data(), sizeof(uint64_t) * c->ref_len.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
+{
+    if (!opt || !out) return fail(nullptr, BQC_ERR_ARG, "bqc_create: null argument");
+    if (opt->struct_size != sizeof(bqc_options)) return fail(nullptr, BQC_ERR_ARG, "bqc_create: struct_size mismatch");
+    if (opt->n_lanes == 0 || opt->n_lanes > 256) return fail(nullptr, BQC_ERR_ARG, "bqc_create: n_lanes must be 1..256");
+    if (opt->isize < 0) return fail(nullptr, BQC_ERR_ARG, "bqc_create: negative insert size");
+    if (opt->max_read_len == 0 || opt->hist_cap == 0) return fail(nullptr, BQC_ERR_ARG, "bqc_create: zero capacity");
+    if (opt->n_refs && !opt->main_chrom) return fail(nullptr, BQC_ERR_ARG, "bqc_create: main_chrom missing");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, BQC_ERR_DEVICE, "bqc_create: no HIP device available (this library has no CPU fallback)");
+    if (opt->device < 0 || opt->device >= ndev) return fail(nullptr, BQC_ERR_DEVICE, "bqc_create: device %d out of range", opt->device);
+    bqc_ctx* c = new bqc_ctx();
+    c->opt = *opt;
+    c->device = opt->device;
+    uint32_t nr = opt->n_refs ? opt->n_refs : 1;
+    c->main_chrom.assign(nr, 0);
+    if (opt->n_refs) memcpy(c->main_chrom.data(), opt->main_chrom, opt->n_refs);
+    if (opt->fasta_index) c->fasta_index.assign(opt->fasta_index, opt->fasta_index + opt->n_refs);
+    c->opt.main_chrom = c->main_chrom.data();
+    c->opt.fasta_index = c->fasta_index.empty() ? nullptr : c->fasta_index.data();
+    c->sl = make_state_layout(opt->n_lanes, opt->max_read_len, opt->hist_cap, (uint32_t)opt->isize + 1);
+    c->cov.assign(opt->n_lanes, LaneCov());
+    c->d_ref.assign(nr, nullptr);
+    c->ref_len.assign(nr, 0);
+    const char* v = getenv("BQC_BASES_SPLIT");
+    c->bases_variant = (v && v[0] == '1') ? 1 : 0;
+#define CCHK(call)                                                                                            \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            fail(nullptr, BQC_ERR_DEVICE, "bqc_create: %s failed: %s", #call, hipGetErrorString(e_));         \
+            bqc_destroy(c);                                                                                   \
+            return BQC_ERR_DEVICE;                                                                            \
+        }                                                                                                     \
+    } while (0)
+    CCHK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    CCHK(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
+    CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CCHK(bqc_kernels_init());
+    CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
+    CCHK(hipMalloc(&c->d_err, 64));
+    CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
+    CCHK(hipMalloc(&c->d_parity, (size_t)opt->n_lanes * 4));
+    CCHK(hipMalloc(&c->d_started, opt->n_lanes));
+    CCHK(hipMalloc(&c->d_ref_ptrs, sizeof(uint8_t*) * nr));
+    CCHK(hipMalloc(&c->d_ref_len, sizeof(uint64_t) * nr));
+    CCHK(hipMalloc(&c->d_main, nr));
+    CCHK(hipMemcpy(c->d_main, c->main_chrom.data(), nr, hipMemcpyHostToDevice));
+    CCHK(hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
+    CCHK(hipMemsetAsync(c->d_err, 0, 64, c->stream));
+    CCHK(hipMemsetAsync(c->d_carry, 0, (size_t)opt->n_lanes * 2 * 2000 * 4, c->stream));
+    CCHK(hipMemsetAsync(c->d_parity, 0, (size_t)opt->n_lanes * 4, c->stream));
+    CCHK(hipMemsetAsync(c->d_started, 0, opt->n_lanes, c->stream));
+    CCHK(hipStreamSynchronize(c->stream));
+    if (upload_ref_tables(c)) { snprintf(g_create_err, sizeof g_create_err, "%s", c->err.c_str()); bqc_destroy(c); return BQC_ERR_DEVICE; }
+    if (opt->sketch.n_k && opt->sketch.n_q) {
+        std::string e;
+        c->sketch = sketch_create(opt->sketch, opt->n_lanes, c->stream, e);
+        if (!c->sketch) { fail(nullptr, BQC_ERR_ARG, "bqc_create: sketch: %s", e.c_str()); bqc_destroy(c); return BQC_ERR_ARG; }
+    }
+    for (int i = 0; i < 16; ++i) {
+        hipEvent_t e;
+        CCHK(hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void bqc_destroy(bqc_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto p : c->d_ref) if (p) (void)hipFree(p);
+    if (c->sketch) sketch_destroy(c->sketch);
+    (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
+    (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, uint64_t len)
+{
+    if (!c || rid < 0 || (uint32_t)rid >= c->opt.n_refs || (!dna5 && len)) return fail(c, BQC_ERR_ARG, "bqc_set_reference: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_ref[rid]) { HIPCHK(c, hipFree(c->d_ref[rid])); c->d_ref[rid] = nullptr; }
+    uint8_t* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, len ? len : 1));
+    HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
+    c->d_ref[rid] = p;
+    c->ref_len[rid] = len;
+    return upload_ref_tables(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host pre-pass
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Prep {
+    std::vector<uint16_t> flag, cov_off;
+    std::vector<uint32_t> cov_win, seq_off, qual_off, cigar_off, perm, cov_list;
+    std::vector<Chunk> chunks;
+    std::vector<CovTile> tiles;
+    std::vector<uint8_t> lane_mask;
+    std::vector<uint64_t> add_idx, add_val;
+    uint64_t seq_bytes = 0, qual_bytes = 0, cigar_words = 0;
+    bool identity = true;
+};
+}
+
+// checkFlagsAndQuality (TripletCounting.hpp:136-168): 1 eligible, 0 not, -1 fatal
+static int triplet_eligible(uint32_t flag, uint32_t mapq, int32_t as, const uint32_t* cg, uint32_t ncig)
+{
+    if (!(flag & 0x1) || !(flag & 0x2) || (flag & 0x4) || (flag & 0x8) || (flag & 0x100)) return 0;
+    if (mapq < 60) return 0;
+    if (as == BQC_AS_ABSENT || as < 0) return -1;
+    if (as < 50) return 0;
+    uint32_t clipped = 0;
+    for (uint32_t k = 0; k < ncig; ++k) {
+        uint32_t op = cg[k] & 15u;
+        if (op == 4u || op == 5u) clipped += cg[k] >> 4;
+    }
+    return clipped > 0 ? 0 : 1;
+}
+
+static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
+{
+    const uint32_t n = b->n_reads;
+    const uint32_t nl = c->opt.n_lanes;
+    P.flag.resize(n); P.cov_off.assign(n, 0); P.cov_win.assign(n, 0);
+    P.seq_off.resize(n); P.qual_off.resize(n); P.cigar_off.resize(n);
+    P.lane_mask.assign(nl, 0);
+    uint64_t so = 0, qo = 0, co = 0;
+    std::vector<std::vector<uint32_t>> lane_list(nl), lane_win(nl);
+    std::vector<uint8_t> started_before(nl);
+    for (uint32_t l = 0; l < nl; ++l) {
+        started_before[l] = !c->cov[l].first;
+        c->cov[l].batch_base = c->cov[l].win;
+    }
+    bool multi_lane = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t L = b->l_seq[i], nc = b->n_cigar[i], lane = b->lane[i];
+        if (L > c->opt.max_read_len)
+            return fail(c, BQC_ERR_RANGE, "read %u is %u bases long; max_read_len is %u", i, L, c->opt.max_read_len);
+        if (lane >= nl) return fail(c, BQC_ERR_ARG, "read %u: lane %u out of range", i, lane);
+        if (so > 0xFFFFFFFFull || qo > 0xFFFFFFFFull || co > 0xFFFFFFFFull)
+            return fail(c, BQC_ERR_ARG, "batch too large: payload offsets exceed 32 bits (split the batch)");
+        if (lane != b->lane[0]) multi_lane = true;
+        P.seq_off[i] = (uint32_t)so; P.qual_off[i] = (uint32_t)qo; P.cigar_off[i] = (uint32_t)co;
+        uint32_t flag = b->flag[i] & (0x0FFFu | BQC_FLAG_MATE_MAIN | BQC_FLAG_NO_QUAL);
+        if (L > 0 && b->qual[qo] == 0xFF) flag |= BQC_FLAG_NO_QUAL;
+        const uint32_t* cg = b->cigar + co;
+        so += (L + 1) / 2; qo += L; co += nc;
+        if (!(flag & 0x900)) { // primary record: bamqualcheck.cpp:318-327
+            const bool dup = flag & 0x400, qcf = flag & 0x200;
+            if (!dup && !qcf) { // tripletCounting, :338-342
+                int e = triplet_eligible(flag, b->mapq[i], b->as[i], cg, nc);
+                if (e < 0) return fail(c, BQC_ERR_AS_TAG, "ERROR: read %u has no usable AS tag.", i);
+                if (e > 0) { // Genome: forward-only FASTA scan (TripletCounting.hpp:254-259)
+                    const int32_t rid = b->rid[i];
+                    int32_t target = -1;
+                    if (rid >= 0 && (uint32_t)rid < c->opt.n_refs) target = c->fasta_index.empty() ? rid : c->fasta_index[rid];
+                    if (target < 0 || target < c->fasta_cursor || !c->d_ref[rid])
+                        return fail(c, BQC_ERR_FASTA, "ERROR: Could not read fasta record for reference id %d (read %u)", rid, i);
+                    c->fasta_cursor = target;
+                    flag |= BQC_FLAG_TRIPLET;
+                }
+            }
+            if (!(flag & 0xC0)) return fail(c, BQC_ERR_NO_MATE_FLAG, "ERROR: No first or second flag in read %u", i);
+            const int32_t rid = b->rid[i];
+            const bool in_main = rid >= 0 && (uint32_t)rid < c->opt.n_refs && c->main_chrom[rid];
+            if (in_main && !(flag & 0x4) && !dup) { // all.coverage(record), :430-433
+                LaneCov& s = c->cov[lane];
+                const uint32_t beginpos = (uint32_t)b->pos[i];
+                if (s.first) { s.first = false; s.id = rid; s.shift = (int32_t)beginpos; }
+                if (s.id != rid || (uint32_t)(beginpos - (uint32_t)s.shift) > 2u * BQC_VSIZE) { // reset: two windows flushed
+                    s.id = rid; s.win += 2; s.shift = (int32_t)beginpos;
+                }
+                uint32_t pos = beginpos - (uint32_t)s.shift;
+                if (pos > BQC_VSIZE && pos < 2u * BQC_VSIZE) { // slide: one window flushed
+                    s.win += 1; s.shift += BQC_VSIZE; pos = beginpos - (uint32_t)s.shift;
+                }
+                const uint64_t rel = s.win - s.batch_base;
+                if (rel > 0xFFFFFFF0ull) return fail(c, BQC_ERR_ARG, "batch spans too many coverage windows (split the batch)");
+                P.cov_win[i] = (uint32_t)rel;
+                P.cov_off[i] = (uint16_t)pos; // 0..2000
+                flag |= BQC_FLAG_COV;
+                lane_list[lane].push_back(i);
+                lane_win[lane].push_back((uint32_t)rel);
+            }
+        }
+        P.flag[i] = (uint16_t)flag;
+    }
+    P.seq_bytes = so; P.qual_bytes = qo; P.cigar_words = co;
+    // extras must reference valid reads
+    for (uint32_t e = 0; e < b->n_nm_extra; ++e)
+        if (b->nm_extra_read[e] >= n) return fail(c, BQC_ERR_ARG, "nm_extra_read out of range");
+
+    // ---- lane grouping (stable) and chunk table
+    P.identity = !multi_lane;
+    if (multi_lane) {
+        std::vector<uint32_t> cnt(nl + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) cnt[b->lane[i] + 1]++;
+        for (uint32_t l = 0; l < nl; ++l) cnt[l + 1] += cnt[l];
+        P.perm.resize(n);
+        for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
+    }
+    {
+        uint32_t start = 0, count = 0, bases = 0, cl = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t r = P.identity ? k : P.perm[k];
+            const uint32_t L = b->l_seq[r], lane = b->lane[r];
+            const bool huge = L > BQC_CHUNK_BASES;
+            if (count && (lane != cl || count == BQC_CHUNK_READS || bases + L > BQC_CHUNK_BASES || huge)) {
+                P.chunks.push_back(Chunk{start, count, cl, 0});
+                count = 0; bases = 0;
+            }
+            if (!count) { start = k; cl = lane; }
+            if (huge) { P.chunks.push_back(Chunk{k, 1, lane, 1}); continue; }
+            ++count; bases += L;
+        }
+        if (count) P.chunks.push_back(Chunk{start, count, cl, 0});
+    }
+    // ---- coverage tiles
+    for (uint32_t l = 0; l < nl; ++l) {
+        const auto& list = lane_list[l];
+        const auto& win = lane_win[l];
+        if (list.empty()) continue;
+        P.lane_mask[l] = 1;
+        const uint32_t W1 = win.back(); // windows < W1 are complete after this batch
+        const uint32_t base_off = (uint32_t)P.cov_list.size();
+        P.cov_list.insert(P.cov_list.end(), list.begin(), list.end());
+        std::vector<uint32_t> need; // tile ids, ascending
+        auto push_tile = [&](uint32_t w) {
+            uint32_t t = w / BQC_COV_TILE_WINDOWS;
+            if (need.empty() || need.back() < t) need.push_back(t);
+        };
+        size_t k = 0;
+        uint32_t specials[4] = {0, 1, W1, W1 + 1};
+        // merge the (sorted) read windows with the special windows
+        std::vector<uint32_t> ws;
+        ws.reserve(win.size() * 2 + 4);
+        for (k = 0; k < win.size(); ++k) { ws.push_back(win[k]); ws.push_back(win[k] + 1); }
+        if (started_before[l]) { ws.push_back(specials[0]); ws.push_back(specials[1]); }
+        ws.push_back(specials[2]); ws.push_back(specials[3]);
+        std::sort(ws.begin(), ws.end());
+        for (uint32_t w : ws) push_tile(w);
+        uint64_t covered_final = 0;
+        for (uint32_t t : need) {
+            const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
+            const uint32_t lo_key = wlo == 0 ? 0 : wlo - 1;
+            const uint32_t b0 = (uint32_t)(std::lower_bound(win.begin(), win.end(), lo_key) - win.begin());
+            const uint32_t b1 = (uint32_t)(std::lower_bound(win.begin(), win.end(), wlo + BQC_COV_TILE_WINDOWS) - win.begin());
+            CovTile ct{};
+            ct.lane = l; ct.win_lo = wlo; ct.list_begin = base_off + b0; ct.list_end = base_off + b1; ct.win_final = W1;
+            P.tiles.push_back(ct);
+            const uint64_t hi = std::min<uint64_t>((uint64_t)wlo + BQC_COV_TILE_WINDOWS, W1);
+            if (hi > wlo) covered_final += hi - wlo;
+        }
+        if (W1 > covered_final) { // complete windows nobody touched: depth 0 everywhere
+            P.add_idx.push_back(c->sl.lane_base(l) + c->sl.o_poscov + 0);
+            P.add_val.push_back((uint64_t)(W1 - covered_final) * BQC_VSIZE);
+        }
+        // the next batch numbers its windows from this batch's last live window
+        c->cov[l].batch_base = c->cov[l].win;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// upload / process
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+}
+
+extern "C" void bqc_dbatch_free(bqc_ctx* c, bqc_dbatch* db)
+{
+    if (!db) return;
+    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    (void)hipFree(db->dmem);
+    delete db;
+}
+extern "C" uint64_t bqc_dbatch_bytes(const bqc_dbatch* db) { return db ? db->algo_bytes : 0; }
+
+extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
+{
+    if (!c || !b || !out) return fail(c, BQC_ERR_ARG, "bqc_upload: null argument");
+    if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_upload after bqc_flush/bqc_finalize (call bqc_reset first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    Prep P;
+    int rc = prepass(c, b, P);
+    if (rc) { c->poisoned = true; return rc; }
+    const uint32_t n = b->n_reads;
+    bqc_dbatch* db = new bqc_dbatch();
+    Carver cv;
+    const size_t o_flag = cv.take(2ull * n), o_mapq = cv.take(n), o_lane = cv.take(n), o_rid = cv.take(4ull * n), o_pos = cv.take(4ull * n),
+                 o_tlen = cv.take(4ull * n), o_nm = cv.take(4ull * n), o_as = cv.take(4ull * n), o_lseq = cv.take(4ull * n),
+                 o_ncig = cv.take(2ull * n), o_coff = cv.take(2ull * n), o_cwin = cv.take(4ull * n), o_soff = cv.take(4ull * n),
+                 o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 16), o_qual = cv.take(P.qual_bytes + 16),
+                 o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * n),
+                 o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
+                 o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
+                 o_mask = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
+    db->dbytes = cv.off + 256;
+    hipError_t he = hipMalloc(&db->dmem, db->dbytes);
+    if (he != hipSuccess) { delete db; c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", db->dbytes, hipGetErrorString(he)); }
+    char* base = (char*)db->dmem;
+#define UP(off, src, bytes)                                                                                     \
+    do {                                                                                                        \
+        if ((bytes) > 0) {                                                                                      \
+            hipError_t e_ = hipMemcpyAsync(base + (off), (src), (bytes), hipMemcpyHostToDevice, c->stream);     \
+            if (e_ != hipSuccess) { bqc_dbatch_free(c, db); c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e_)); } \
+        }                                                                                                       \
+    } while (0)
+    UP(o_flag, P.flag.data(), 2ull * n); UP(o_mapq, b->mapq, n); UP(o_lane, b->lane, n); UP(o_rid, b->rid, 4ull * n);
+    UP(o_pos, b->pos, 4ull * n); UP(o_tlen, b->tlen, 4ull * n); UP(o_nm, b->nm, 4ull * n); UP(o_as, b->as, 4ull * n);
+    UP(o_lseq, b->l_seq, 4ull * n); UP(o_ncig, b->n_cigar, 2ull * n); UP(o_coff, P.cov_off.data(), 2ull * n);
+    UP(o_cwin, P.cov_win.data(), 4ull * n); UP(o_soff, P.seq_off.data(), 4ull * n); UP(o_qoff, P.qual_off.data(), 4ull * n);
+    UP(o_cgoff, P.cigar_off.data(), 4ull * n); UP(o_seq, b->seq, P.seq_bytes); UP(o_qual, b->qual, P.qual_bytes);
+    UP(o_cig, b->cigar, 4 * P.cigar_words);
+    if (!P.identity) UP(o_perm, P.perm.data(), 4ull * n);
+    UP(o_chunks, P.chunks.data(), sizeof(Chunk) * P.chunks.size());
+    UP(o_xr, b->nm_extra_read, 4ull * b->n_nm_extra); UP(o_xv, b->nm_extra_val, 4ull * b->n_nm_extra);
+    UP(o_clist, P.cov_list.data(), 4ull * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
+    UP(o_mask, P.lane_mask.data(), c->opt.n_lanes);
+    UP(o_aidx, P.add_idx.data(), 8ull * P.add_idx.size()); UP(o_aval, P.add_val.data(), 8ull * P.add_val.size());
+    he = hipStreamSynchronize(c->stream); // buffers may be reused by the caller on return
+    if (he != hipSuccess) { bqc_dbatch_free(c, db); c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "upload sync failed: %s", hipGetErrorString(he)); }
+    DevBatch& d = db->d;
+    d.n_reads = n;
+    d.flag = (const uint16_t*)(base + o_flag); d.mapq = (const uint8_t*)(base + o_mapq); d.lane = (const uint8_t*)(base + o_lane);
+    d.rid = (const int32_t*)(base + o_rid); d.pos = (const int32_t*)(base + o_pos); d.tlen = (const int32_t*)(base + o_tlen);
+    d.nm = (const int32_t*)(base + o_nm); d.as_ = (const int32_t*)(base + o_as); d.l_seq = (const uint32_t*)(base + o_lseq);
+    d.n_cigar = (const uint16_t*)(base + o_ncig); d.cov_off = (const uint16_t*)(base + o_coff); d.cov_win = (const uint32_t*)(base + o_cwin);
+    d.seq_off = (const uint32_t*)(base + o_soff); d.qual_off = (const uint32_t*)(base + o_qoff); d.cigar_off = (const uint32_t*)(base + o_cgoff);
+    d.seq = (const uint8_t*)(base + o_seq); d.qual = (const uint8_t*)(base + o_qual); d.cigar = (const uint32_t*)(base + o_cig);
+    d.perm = P.identity ? nullptr : (const uint32_t*)(base + o_perm);
+    d.chunks = (const Chunk*)(base + o_chunks); d.n_chunks = (uint32_t)P.chunks.size();
+    d.nm_extra_read = (const uint32_t*)(base + o_xr); d.nm_extra_val = (const int32_t*)(base + o_xv); d.n_nm_extra = b->n_nm_extra;
+    d.cov_list = (const uint32_t*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
+    db->d_lane_mask = (uint8_t*)(base + o_mask);
+    db->d_add_idx = (uint64_t*)(base + o_aidx); db->d_add_val = (uint64_t*)(base + o_aval);
+    db->add_idx = P.add_idx; db->add_val = P.add_val;
+    db->algo_bytes = 48ull * n + P.seq_bytes + P.qual_bytes + 4 * P.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
+    // lanes that saw their first coverage read in this batch are "started" from now on
+    std::vector<uint8_t> st(c->opt.n_lanes);
+    for (uint32_t l = 0; l < c->opt.n_lanes; ++l) st[l] = !c->cov[l].first;
+    HIPCHK(c, hipMemcpyAsync(c->d_started, st.data(), st.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = db;
+    return 0;
+}
+
+static int check_device_error(bqc_ctx* c)
+{
+    uint32_t e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!e) return 0;
+    c->poisoned = true;
+    if (e & BQC_DEVERR_MATE) return fail(c, BQC_ERR_NO_MATE_FLAG, "ERROR: No first or second flag in read");
+    if (e & BQC_DEVERR_RANGE) return fail(c, BQC_ERR_RANGE, "mismatch/deletion/insertion count exceeds hist_cap (or NM < D+I)");
+    return fail(c, BQC_ERR_RANGE, "base quality above 222 cannot be represented by the reference (q+33 wraps)");
+}
+
+static void tick(bqc_ctx* c, const char* name)
+{
+    if (!c->timing || c->n_timed + 1 >= (int)c->ev.size()) return;
+    (void)hipEventRecord(c->ev[c->n_timed + 1], c->stream);
+    c->tnames.push_back(name);
+    c->n_timed++;
+}
+
+extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
+{
+    if (!c || !db) return fail(c, BQC_ERR_ARG, "bqc_process: null argument");
+    if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_process after bqc_flush (call bqc_reset first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevRefs refs{(const uint8_t* const*)c->d_ref_ptrs, c->d_ref_len, c->d_main, c->opt.n_refs};
+    if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
+    bqc_launch_reads(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
+    tick(c, "k_reads");
+    if (c->bases_variant == 0) {
+        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);
+        tick(c, "k_bases");
+    } else {
+        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 1, c->stream);
+        tick(c, "k_bases<cyc>");
+        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 2, c->stream);
+        tick(c, "k_bases<8mer>");
+        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
+        tick(c, "k_bases<trip>");
+    }
+    if (db->d.n_cov_tiles) {
+        bqc_launch_cov(db->d, c->sl, c->d_state, c->d_carry, c->d_parity, c->stream);
+        bqc_launch_cov_flip(c->d_parity, db->d_lane_mask, c->opt.n_lanes, c->stream);
+    }
+    bqc_launch_add_words(c->d_state, db->d_add_idx, db->d_add_val, (uint32_t)db->add_idx.size(), c->stream);
+    tick(c, "k_cov");
+    if (c->sketch) { sketch_process(c->sketch, db->d, c->stream); tick(c, "k_sketch"); }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int bqc_submit(bqc_ctx* c, const bqc_batch* b)
+{
+    bqc_dbatch* db = nullptr;
+    int rc = bqc_upload(c, b, &db);
+    if (rc) return rc;
+    rc = bqc_process(c, db);
+    if (!rc) rc = check_device_error(c); // also drains the stream so the batch can be freed
+    bqc_dbatch_free(c, db);
+    return rc;
+}
+
+extern "C" int bqc_sync(bqc_ctx* c)
+{
+    if (!c) return BQC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_device_error(c);
+}
+
+extern "C" int bqc_reset(bqc_ctx* c)
+{
+    if (!c) return BQC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_carry, 0, (size_t)c->opt.n_lanes * 2 * 2000 * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_parity, 0, (size_t)c->opt.n_lanes * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_started, 0, c->opt.n_lanes, c->stream));
+    if (c->sketch) sketch_reset(c->sketch, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cov.assign(c->opt.n_lanes, LaneCov());
+    c->fasta_cursor = -1;
+    c->flushed = false;
+    c->poisoned = false;
+    return 0;
+}
+
+extern "C" int bqc_set_timing(bqc_ctx* c, int enable)
+{
+    if (!c) return BQC_ERR_ARG;
+    c->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int bqc_last_timing(bqc_ctx* c, uint32_t* n, const char* const** names, const float** ms)
+{
+    if (!c || !n || !names || !ms) return BQC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tms.assign(c->n_timed, 0.f);
+    for (int i = 0; i < c->n_timed; ++i) (void)hipEventElapsedTime(&c->tms[i], c->ev[i], c->ev[i + 1]);
+    *n = (uint32_t)c->n_timed;
+    *names = c->tnames.data();
+    *ms = c->tms.data();
+    return 0;
+}
+
+extern "C" int bqc_flush(bqc_ctx* c)
+{
+    if (!c) return BQC_ERR_ARG;
+    if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->flushed) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    bqc_launch_cov_final(c->sl, c->d_state, c->d_carry, c->d_parity, c->d_started, c->stream);
+    HIPCHK(c, hipGetLastError());
+    int rc = check_device_error(c);
+    if (rc) return rc;
+    c->flushed = true;
+    return 0;
+}
+
+extern "C" uint64_t bqc_state_words(const bqc_ctx* c) { return c ? c->sl.words + (c->sketch ? sketch_state_words(c->sketch) : 0) : 0; }
+
+extern "C" int bqc_state_export(bqc_ctx* c, void* dst)
+{
+    if (!c || !dst) return BQC_ERR_ARG;
+    int rc = bqc_flush(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_state, c->sl.words * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->sketch) sketch_state_export(c->sketch, (uint64_t*)dst + c->sl.words, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int bqc_state_import(bqc_ctx* c, const void* src)
+{
+    if (!c || !src) return BQC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_state, src, c->sl.words * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->sketch) sketch_state_import(c->sketch, (const uint64_t*)src + c->sl.words, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->flushed = true; // an imported vector is already flushed
+    return 0;
+}
+extern "C" int bqc_state_export_host(bqc_ctx* c, uint64_t* dst)
+{
+    if (!c || !dst) return BQC_ERR_ARG;
+    int rc = bqc_flush(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, c->d_state, c->sl.words * 8, hipMemcpyDeviceToHost));
+    if (c->sketch) {
+        uint64_t* tmp = nullptr;
+        const uint64_t w = sketch_state_words(c->sketch);
+        HIPCHK(c, hipMalloc(&tmp, w * 8));
+        sketch_state_export(c->sketch, tmp, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(dst + c->sl.words, tmp, w * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipFree(tmp));
+    }
+    return 0;
+}
+extern "C" int bqc_state_import_host(bqc_ctx* c, const uint64_t* src)
+{
+    if (!c || !src) return BQC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->d_state, src, c->sl.words * 8, hipMemcpyHostToDevice));
+    if (c->sketch) {
+        uint64_t* tmp = nullptr;
+        const uint64_t w = sketch_state_words(c->sketch);
+        HIPCHK(c, hipMalloc(&tmp, w * 8));
+        HIPCHK(c, hipMemcpy(tmp, src + c->sl.words, w * 8, hipMemcpyHostToDevice));
+        sketch_state_import(c->sketch, tmp, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(tmp));
+    }
+    c->flushed = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize
+// ---------------------------------------------------------------------------------------------------
+static uint32_t last_nonzero_len(const uint64_t* p, uint32_t n)
+{
+    while (n > 0 && p[n - 1] == 0) --n;
+    return n;
+}
+
+extern "C" int bqc_finalize(bqc_ctx* c, const bqc_counts** out)
+{
+    if (!c || !out) return BQC_ERR_ARG;
+    int rc = bqc_flush(c);
+    if (rc) return rc;
+    const StateLayout& sl = c->sl;
+    c->h_state.resize(sl.words);
+    HIPCHK(c, hipMemcpy(c->h_state.data(), c->d_state, sl.words * 8, hipMemcpyDeviceToHost));
+    c->arrays.clear();
+    c->lanes.assign(sl.n_lanes, bqc_lane_counts{});
+    c->sk_out.assign(sl.n_lanes, {});
+    auto keep = [&](std::vector<uint64_t>&& v) -> const uint64_t* {
+        c->arrays.push_back(std::move(v));
+        return c->arrays.back().data();
+    };
+    auto u32copy = [&](const uint64_t* p, uint32_t n) { // reference type `unsigned`: value mod 2^32
+        std::vector<uint64_t> v(n ? n : 1);
+        for (uint32_t i = 0; i < n; ++i) v[i] = p[i] & 0xFFFFFFFFull;
+        return v;
+    };
+    c->arrays.reserve(sl.n_lanes * 64);
+    for (uint32_t l = 0; l < sl.n_lanes; ++l) {
+        const uint64_t* S = c->h_state.data() + sl.lane_base(l);
+        bqc_lane_counts& L = c->lanes[l];
+        for (int i = 0; i < BQC_N_SCALARS; ++i)
+            L.scalars[i] = i == BQC_S_TOTALBPS ? S[sl.o_scalars + i] : (S[sl.o_scalars + i] & 0xFFFFFFFFull);
+        for (int i = 0; i <= BQC_COVSIZE; ++i) L.poscov[i] = S[sl.o_poscov + i];
+        if (S[sl.o_covstart] == 0) L.poscov[0] += 2 * BQC_VSIZE; // lane never saw coverage(): final flush of two empty windows
+        for (int i = 0; i <= BQC_COVSIZE; ++i) L.poscov[i] &= 0xFFFFFFFFull;
+        L.eightmer = S + sl.o_eightmer;
+        L.triplet = S + sl.o_triplet;
+        for (uint32_t m = 0; m < 2; ++m) {
+            const uint64_t* Mq = S + sl.o_mate[m];
+            bqc_mate_counts& mc = L.mate[m];
+            const uint32_t n_rl = last_nonzero_len(Mq + sl.m_readlen, sl.lcap + 1); // maxL + 1, or 0 when no read
+            const uint32_t ncyc = n_rl ? n_rl - 1 : 0;
+            mc.n_cycles = ncyc;
+            for (int j = 0; j < 5; ++j) mc.dnacount[j] = Mq + sl.m_dnacount + (uint64_t)j * sl.lcap;
+            mc.qualcount = Mq + sl.m_qualcount;
+            mc.qualcount_readnr = Mq[sl.m_readnr] & 0xFFFFFFFFull;
+            { // sc5[j] = #reads whose leading clip exceeds j (suffix sum of the clip-length histogram)
+                std::vector<uint64_t> v(ncyc ? ncyc : 1, 0);
+                uint64_t run = 0;
+                for (uint32_t j = sl.lcap + 1; j-- > 0;) {
+                    if (j < ncyc) v[j] = run & 0xFFFFFFFFull; // run = sum_{n > j} H[n]
+                    run += Mq[sl.m_sc5hist + j];
+                }
+                // v[j] = sum_{n > j} H[n]
+                mc.sc5 = keep(std::move(v));
+            }
+            { // sc3 = prefix sum of the difference array
+                std::vector<uint64_t> v(ncyc ? ncyc : 1, 0);
+                uint64_t run = 0;
+                for (uint32_t j = 0; j < ncyc; ++j) { run += Mq[sl.m_sc3diff + j]; v[j] = run & 0xFFFFFFFFull; }
+                mc.sc3 = keep(std::move(v));
+            }
+            mc.n_Ncount = n_rl; mc.Ncount = keep(u32copy(Mq + sl.m_ncount, n_rl));
+            mc.n_GCcount = n_rl; mc.GCcount = Mq + sl.m_gccount;
+            mc.n_averageQual = last_nonzero_len(Mq + sl.m_avgceil, 256);
+            mc.averageQual = keep(u32copy(Mq + sl.m_avgqual, mc.n_averageQual));
+            mc.n_insertSize = sl.icap; mc.insertSize = keep(u32copy(Mq + sl.m_insert, sl.icap));
+            mc.n_mapQ = last_nonzero_len(Mq + sl.m_mapq, 256); mc.mapQ = keep(u32copy(Mq + sl.m_mapq, mc.n_mapQ));
+            mc.n_readLength = n_rl; mc.readLength = keep(u32copy(Mq + sl.m_readlen, n_rl));
+            mc.n_mismatch = last_nonzero_len(Mq + sl.m_mismatch, sl.hcap); mc.mismatch = keep(u32copy(Mq + sl.m_mismatch, mc.n_mismatch));
+            mc.n_delhist = last_nonzero_len(Mq + sl.m_delhist, sl.hcap); mc.delhist = keep(u32copy(Mq + sl.m_delhist, mc.n_delhist));
+            mc.n_inshist = last_nonzero_len(Mq + sl.m_inshist, sl.hcap); mc.inshist = keep(u32copy(Mq + sl.m_inshist, mc.n_inshist));
+        }
+        if (c->sketch) {
+            std::string e;
+            if (!sketch_finalize(c->sketch, l, c->sk_out[l], c->stream, e)) return fail(c, BQC_ERR_DEVICE, "sketch finalize: %s", e.c_str());
+            L.n_sketch = (uint32_t)c->sk_out[l].size();
+            L.sketch = c->sk_out[l].data();
+        }
+    }
+    c->counts.n_lanes = sl.n_lanes;
+    c->counts.lanes = c->lanes.data();
+    *out = &c->counts;
+    return 0;
+}

@@ -1,0 +1,74 @@
+// device_types.h — structures shared by the host side of the library and the HIP kernels.
+#pragma once
+#include <stdint.h>
+#include "state_layout.h"
+
+// host annotations in the device flag column (see include/bamqc.h for 0x1000 / 0x8000)
+#define BQC_FLAG_TRIPLET 0x2000u // read passed checkFlagsAndQuality (TripletCounting.hpp:136-168)
+#define BQC_FLAG_COV     0x4000u // read enters OverallNumbers::coverage (bamqualcheck.cpp:430-433)
+
+#define BQC_TILE_STRIDE 56       // positions owned per wave tile (64 loaded: 8 look-ahead for 8-mers)
+#define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
+#define BQC_CHUNK_READS 128      // max reads per chunk
+#define BQC_CHUNK_BASES 24576    // max bases per chunk (bounds the u16 8-mer counters, see k_bases)
+#define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
+#define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
+
+// device error word bits
+#define BQC_DEVERR_QUAL  1u      // Phred byte > 222 (q+33 wraps in the reference's char arithmetic)
+#define BQC_DEVERR_RANGE 2u      // mismatch / deletion / insertion count >= hist_cap
+#define BQC_DEVERR_MATE  4u      // neither first nor last flag
+
+struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
+    uint32_t first, count, lane, huge; // huge: single read longer than BQC_CHUNK_BASES
+};
+
+struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
+    uint32_t lane;
+    uint32_t win_lo;      // first window (batch-relative index)
+    uint32_t list_begin;  // candidate reads: cov_list[list_begin, list_end)
+    uint32_t list_end;
+    uint32_t win_final;   // windows < win_final are complete -> histogram; win_final, win_final+1 -> carry out
+    uint32_t pad0, pad1, pad2;
+};
+
+struct DevBatch {
+    uint32_t n_reads;
+    // fixed columns, 48 B / read
+    const uint16_t* flag;
+    const uint8_t* mapq;
+    const uint8_t* lane;
+    const int32_t* rid;
+    const int32_t* pos;
+    const int32_t* tlen;
+    const int32_t* nm;
+    const int32_t* as_;
+    const uint32_t* l_seq;
+    const uint16_t* n_cigar;
+    const uint16_t* cov_off;  // pos - anchor of the read's first live window (0..2000)
+    const uint32_t* cov_win;  // batch-relative index of the read's first live window
+    const uint32_t* seq_off;
+    const uint32_t* qual_off;
+    const uint32_t* cigar_off;
+    // variable-length payload
+    const uint8_t* seq;    // 4-bit packed
+    const uint8_t* qual;   // raw Phred
+    const uint32_t* cigar; // len<<4|op
+    // work decomposition (host pre-pass)
+    const uint32_t* perm;  // reads grouped by lane (stable); nullptr = identity
+    const Chunk* chunks;
+    uint32_t n_chunks;
+    const uint32_t* nm_extra_read;
+    const int32_t* nm_extra_val;
+    uint32_t n_nm_extra;
+    const uint32_t* cov_list;
+    const CovTile* cov_tiles;
+    uint32_t n_cov_tiles;
+};
+
+struct DevRefs {
+    const uint8_t* const* ref; // [n_refs] Dna5 codes, nullptr if not loaded
+    const uint64_t* len;
+    const uint8_t* main_chrom; // [n_refs]
+    uint32_t n_refs;
+};

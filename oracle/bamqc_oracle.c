@@ -13,7 +13,7 @@
  * (8-mer index orientation and triplet context index, both via
  * bamqc_summary.py:347,369-380) and (b) hand-derived known-answer tests from the
  * cited source lines (tests/test_oracle_kats.py).  The k-mer sketch part
- * (oracle/sketch_oracle.cpp) IS pinned against the reference's own
+ * (oracle/sketch_oracle.c) IS pinned against the reference's own
  * kmerstream sources compiled into oracle/_ref.
  *
  * Structure: record-at-a-time, single thread, same pass structure as the
@@ -85,7 +85,7 @@ typedef struct {
     overall all;
     qcheck r1, r2;
     tripletcounts triplet[64];
-    void* sketch; /* N1, see sketch_oracle.cpp */
+    void* sketch; /* N1, see sketch_oracle.c */
 } counts_t;
 
 struct orc_ctx {
@@ -312,14 +312,13 @@ static int cigar_count(qcheck* q, const rec* r, uint32_t hist_cap) /* QualityChe
        is treated as "no operations". */
     if (cigarlength > 0) {
         if (r->cop[0] == 'S') {
-            /* DEFINED: writes beyond the per-cycle arrays (clip longer than the longest
-               read seen, only possible for inconsistent records) are dropped. */
-            for (uint32_t j = 0; j < r->ccnt[0]; ++j)
-                if (j < q->sc5.n) INC32(q->sc5.d[j]);
+            /* DEFINED: a clip longer than the read itself (inconsistent record; the reference
+               writes past the per-cycle arrays) only marks the read's own cycles. */
+            for (uint32_t j = 0; j < r->ccnt[0] && j < r->L; ++j) INC32(q->sc5.d[j]);
         } else if (r->cop[cigarlength - 1] == 'S') {
             uint32_t n = r->ccnt[cigarlength - 1];
-            for (uint32_t j = r->L - n; j < r->L; ++j) /* unsigned wrap if n > L: loop is empty or huge */
-                if (j < q->sc3.n) INC32(q->sc3.d[j]);
+            for (uint32_t j = r->L - n; j < r->L; ++j) /* unsigned: n > L wraps and the loop is empty */
+                INC32(q->sc3.d[j]);
         }
     }
     for (int i = 0; i < cigarlength; ++i) {
