@@ -24,6 +24,7 @@ void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* ca
 void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
+void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
 hipError_t bqc_kernels_init();
 }
 
@@ -46,6 +47,11 @@ struct bqc_dbatch {
     std::vector<uint64_t> add_idx, add_val; // host-computed additions (zero-depth windows)
     uint64_t* d_add_idx = nullptr;
     uint64_t* d_add_val = nullptr;
+    // host stream state after this batch (restored by bqc_process after a bqc_reset, see there)
+    uint8_t* d_started_after = nullptr;
+    std::vector<LaneCov> cov_after;
+    int32_t fasta_cursor_after = -1;
+    uint64_t seq = 0;
 };
 
 struct bqc_ctx {
@@ -72,6 +78,8 @@ struct bqc_ctx {
     int32_t fasta_cursor = -1;
     bool flushed = false;
     bool poisoned = false;
+    uint64_t upload_counter = 0; // number of batches pre-passed so far
+    uint64_t state_seq = 0;      // sequence number of the batch the host stream state (cov, fasta_cursor) reflects
     // sketch (N1)
     SketchDevice* sketch = nullptr;
     // timing
@@ -430,7 +438,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * n),
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
                  o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
-                 o_mask = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
+                 o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
     hipError_t he = hipMalloc(&db->dmem, db->dbytes);
     if (he != hipSuccess) { delete db; c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", db->dbytes, hipGetErrorString(he)); }
@@ -453,6 +461,9 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     UP(o_xr, b->nm_extra_read, 4ull * b->n_nm_extra); UP(o_xv, b->nm_extra_val, 4ull * b->n_nm_extra);
     UP(o_clist, P.cov_list.data(), 4ull * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
     UP(o_mask, P.lane_mask.data(), c->opt.n_lanes);
+    std::vector<uint8_t> st(c->opt.n_lanes);
+    for (uint32_t l = 0; l < c->opt.n_lanes; ++l) st[l] = !c->cov[l].first; // lanes that have seen a coverage read so far
+    UP(o_started, st.data(), c->opt.n_lanes);
     UP(o_aidx, P.add_idx.data(), 8ull * P.add_idx.size()); UP(o_aval, P.add_val.data(), 8ull * P.add_val.size());
     he = hipStreamSynchronize(c->stream); // buffers may be reused by the caller on return
     if (he != hipSuccess) { bqc_dbatch_free(c, db); c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "upload sync failed: %s", hipGetErrorString(he)); }
@@ -472,11 +483,11 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     db->d_add_idx = (uint64_t*)(base + o_aidx); db->d_add_val = (uint64_t*)(base + o_aval);
     db->add_idx = P.add_idx; db->add_val = P.add_val;
     db->algo_bytes = 48ull * n + P.seq_bytes + P.qual_bytes + 4 * P.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
-    // lanes that saw their first coverage read in this batch are "started" from now on
-    std::vector<uint8_t> st(c->opt.n_lanes);
-    for (uint32_t l = 0; l < c->opt.n_lanes; ++l) st[l] = !c->cov[l].first;
-    HIPCHK(c, hipMemcpyAsync(c->d_started, st.data(), st.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    db->d_started_after = (uint8_t*)(base + o_started);
+    db->cov_after = c->cov;
+    db->fasta_cursor_after = c->fasta_cursor;
+    db->seq = ++c->upload_counter;
+    c->state_seq = db->seq;
     *out = db;
     return 0;
 }
@@ -508,6 +519,12 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_process after bqc_flush (call bqc_reset first)");
     HIPCHK(c, hipSetDevice(c->device));
     DevRefs refs{(const uint8_t* const*)c->d_ref_ptrs, c->d_ref_len, c->d_main, c->opt.n_refs};
+    if (db->seq > c->state_seq) { // re-processing after bqc_reset: this batch (uploaded on a fresh context) defines the stream state again
+        c->cov = db->cov_after;
+        c->fasta_cursor = db->fasta_cursor_after;
+        c->state_seq = db->seq;
+    }
+    bqc_launch_or_bytes(c->d_started, db->d_started_after, c->opt.n_lanes, c->stream);
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
     bqc_launch_reads(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
     tick(c, "k_reads");
@@ -565,6 +582,7 @@ extern "C" int bqc_reset(bqc_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cov.assign(c->opt.n_lanes, LaneCov());
     c->fasta_cursor = -1;
+    c->state_seq = 0;
     c->flushed = false;
     c->poisoned = false;
     return 0;

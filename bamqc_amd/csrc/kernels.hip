@@ -58,10 +58,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #define LUT5_RC  0x4444444044414234ull
 __device__ __forceinline__ uint32_t lut5(uint64_t lut, uint32_t nib) { return (uint32_t)(lut >> (nib * 4)) & 7u; }
 
-__device__ __forceinline__ uint32_t revcomp16(uint32_t h) // reverse complement of 8 packed 2-bit bases
+__device__ __forceinline__ uint32_t reverse8x2(uint32_t h) // reverse the order of 8 packed 2-bit bases
 {
-    uint32_t x = (~h) & 0xFFFFu;
-    x = __brev(x) >> 16;                                  // reverses bit order: base order reversed, bits in pair swapped
+    const uint32_t x = __brev(h) >> 16;                   // reverses bit order: base order reversed, bits in pair swapped
     return ((x & 0xAAAAu) >> 1) | ((x & 0x5555u) << 1);   // swap the two bits of every base back
 }
 
@@ -335,14 +334,15 @@ __global__ __launch_bounds__(1024) void k_bases(DevBatch b, StateLayout sl, uint
                     nGC += (uint32_t)__popcll((unsigned long long)__ballot(own && (nib == 2u || nib == 4u))); // 'C' / 'G'
                 }
                 if (DO_8MER) { // count8mers, OverallNumbers.hpp:137-168; window starts at i (BAM orientation)
-                    const uint32_t c2 = lut5(LUT5_FWD, nib) & 3u;                // char -> Dna: non-ACGT -> A
+                    // char -> Dna AFTER the reverse complement: complemented code, non-ACGT -> A either way
+                    const uint32_t c2 = lut5(lut_seq, nib) & 3u;
                     const uint32_t v = in ? (c2 | (isN ? 0x10000u : 0u)) : 0x10000u; // past the end blocks the window
                     const uint32_t p2 = (v << 2) | (uint32_t)__shfl_down((int)v, 1);
                     const uint32_t p4 = (p2 << 4) | (uint32_t)__shfl_down((int)p2, 2);
                     const uint32_t p8 = (p4 << 8) | (uint32_t)__shfl_down((int)p4, 4);
                     if (own && (p8 >> 16) == 0) {
                         uint32_t h = p8 & 0xFFFFu;
-                        if (rc) h = revcomp16(h); // the window's 8-mer as it appears in the reverse-complemented read
+                        if (rc) h = reverse8x2(h); // bases are already complemented: the 8-mer as read off the RC'd sequence
                         if (!ch.huge) {
                             const uint32_t old = atomicAdd(&lds[L_T8 + (h >> 1)], (h & 1u) ? 0x10000u : 1u);
                             t8max = max(t8max, max(old >> 16, old & 0xFFFFu));
@@ -529,6 +529,12 @@ __global__ void k_cov_flip(uint32_t* __restrict__ parity, const uint8_t* __restr
     if (l < n_lanes && lane_mask[l]) parity[l] ^= 1u;
 }
 
+__global__ void k_or_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && src[i]) dst[i] = 1;
+}
+
 __global__ void k_add_words(uint64_t* __restrict__ state, const uint64_t* __restrict__ idx, const uint64_t* __restrict__ val, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -596,4 +602,9 @@ extern "C" void bqc_launch_cov_final(const StateLayout& sl, uint64_t* state, con
 extern "C" void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t s)
 {
     if (n) hipLaunchKernelGGL(k_add_words, dim3((n + 255) / 256), dim3(256), 0, s, state, idx, val, n);
+}
+
+extern "C" void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_or_bytes, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
 }
