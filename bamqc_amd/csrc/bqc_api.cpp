@@ -18,7 +18,7 @@
 #include "sketch.h"
 
 extern "C" {
-void bqc_launch_reads(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
+void bqc_launch_reads(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t n_cu, hipStream_t);
 void bqc_launch_bases(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, int variant, hipStream_t);
 void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, const uint32_t* parity, hipStream_t);
 void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
@@ -526,7 +526,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     }
     bqc_launch_or_bytes(c->d_started, db->d_started_after, c->opt.n_lanes, c->stream);
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
-    bqc_launch_reads(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
+    bqc_launch_reads(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
     tick(c, "k_reads");
     if (c->bases_variant == 0) {
         bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);

@@ -1,0 +1,148 @@
+// k_cov.hip — coverage depth histogram (OverallNumbers.hpp:59-135) and small utility kernels.
+#include "kernels_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// k_cov — coverage depth histogram
+// ---------------------------------------------------------------------------------------------------
+// Virtual coordinates: the host runs the order-dependent anchor recurrence (OverallNumbers.hpp:84-110)
+// and numbers every 1000-position window in flush order; a read contributes to
+// [win*1000 + off + c, ...) truncated at (win+2)*1000.  Depth is then order-free.
+__global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_t* __restrict__ state,
+                                                uint32_t* __restrict__ carry /* [lane][2][2000] */, const uint32_t* __restrict__ parity)
+{
+    __shared__ int32_t diff[BQC_COV_TILE + 8];
+    __shared__ uint32_t hist[BQC_COVSIZE + 1];
+    __shared__ uint32_t wsum[4];
+    const CovTile t = b.cov_tiles[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < BQC_COV_TILE + 8; i += blockDim.x) diff[i] = 0;
+    for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE, hi = lo + BQC_COV_TILE;
+    for (uint32_t e = t.list_begin + threadIdx.x; e < t.list_end; e += blockDim.x) {
+        const uint32_t r = b.cov_list[e];
+        const uint32_t flag = b.flag[r];
+        const bool rc = flag & 0x10;
+        const int64_t base = (int64_t)b.cov_win[r] * BQC_VSIZE;
+        const int64_t limit = base + 2 * BQC_VSIZE; // DEFINED: increments at window offset >= 2000 are dropped
+        const int64_t p0 = base + b.cov_off[r];
+        const uint32_t ncig = b.n_cigar[r];
+        const uint32_t* cg = b.cigar + b.cigar_off[r];
+        uint32_t c = 0; // `int c` in the reference; wraps identically
+        for (uint32_t k = 0; k < ncig; ++k) { // seq-oriented CIGAR: reversed for RC reads (bamqualcheck.cpp:349)
+            const uint32_t w = cg[rc ? ncig - 1 - k : k], op = w & 15u, n = w >> 4;
+            if (op == 4u) c += n;                    // 'S'
+            if (op == 0u || op == 2u) {              // 'M' or 'D'
+                int64_t a = p0 + c, z = a + n;
+                if (z > limit) z = limit;
+                if (a < lo) a = lo;
+                if (z > hi) z = hi;
+                if (a < z) {
+                    atomicAdd(&diff[a - lo], 1);
+                    atomicAdd(&diff[z - lo], -1);
+                }
+                c += n;
+            }
+        }
+    }
+    __syncthreads();
+    // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16)
+    const uint32_t per = (BQC_COV_TILE + 255) / 256;
+    const uint32_t s0 = threadIdx.x * per;
+    int32_t loc = 0;
+    for (uint32_t j = 0; j < per; ++j) if (s0 + j < BQC_COV_TILE) loc += diff[s0 + j];
+    // inclusive wave scan of thread totals
+    int32_t inc = loc;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int32_t v = __shfl_up(inc, o);
+        if (lane_id() >= o) inc += v;
+    }
+    if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
+    __syncthreads();
+    int32_t off = inc - loc;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
+    const uint32_t par = parity[t.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
+    const uint32_t* cin = carry + ((uint64_t)t.lane * 2 + par) * 2000;
+    uint32_t* cout = carry + ((uint64_t)t.lane * 2 + (par ^ 1u)) * 2000;
+    int32_t run = off;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t p = s0 + j;
+        if (p >= BQC_COV_TILE) break;
+        run += diff[p];
+        const int64_t vp = lo + p;
+        uint32_t depth = (uint32_t)run;
+        if (vp < 2 * BQC_VSIZE) depth += cin[vp]; // partial windows carried over from the previous batch
+        const uint32_t win = t.win_lo + p / BQC_VSIZE;
+        if (win < t.win_final) atomicAdd(&hist[depth > BQC_COVSIZE ? BQC_COVSIZE : depth], 1u); // update_coverage :66-77
+        else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
+        if (hist[i]) gadd(state + sl.lane_base(t.lane) + sl.o_poscov + i, hist[i]);
+}
+
+// end of stream: histogram the two live windows of every started lane (bamqualcheck.cpp:447-453)
+__global__ __launch_bounds__(256) void k_cov_final(StateLayout sl, uint64_t* __restrict__ state, const uint32_t* __restrict__ carry,
+                                                      const uint32_t* __restrict__ parity, const uint8_t* __restrict__ started)
+{
+    __shared__ uint32_t hist[BQC_COVSIZE + 1];
+    const uint32_t lane = blockIdx.x;
+    if (!started[lane]) return;
+    for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint32_t* c = carry + ((uint64_t)lane * 2 + (parity[lane] & 1u)) * 2000;
+    for (uint32_t i = threadIdx.x; i < 2000; i += blockDim.x) {
+        const uint32_t d = c[i];
+        atomicAdd(&hist[d > BQC_COVSIZE ? BQC_COVSIZE : d], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
+        if (hist[i]) gadd(state + sl.lane_base(lane) + sl.o_poscov + i, hist[i]);
+    if (threadIdx.x == 0) gadd(state + sl.lane_base(lane) + sl.o_covstart, 1);
+}
+
+__global__ void k_cov_flip(uint32_t* __restrict__ parity, const uint8_t* __restrict__ lane_mask, uint32_t n_lanes)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < n_lanes && lane_mask[l]) parity[l] ^= 1u;
+}
+
+__global__ void k_or_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && src[i]) dst[i] = 1;
+}
+
+__global__ void k_add_words(uint64_t* __restrict__ state, const uint64_t* __restrict__ idx, const uint64_t* __restrict__ val, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gadd(state + idx[i], val[i]);
+}
+
+extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_t* state, uint32_t* carry, const uint32_t* parity,
+                               hipStream_t s)
+{
+    if (b.n_cov_tiles == 0) return;
+    hipLaunchKernelGGL(k_cov, dim3(b.n_cov_tiles), dim3(256), 0, s, b, sl, state, carry, parity);
+}
+
+extern "C" void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cov_flip, dim3((n_lanes + 255) / 256), dim3(256), 0, s, parity, lane_mask, n_lanes);
+}
+
+extern "C" void bqc_launch_cov_final(const StateLayout& sl, uint64_t* state, const uint32_t* carry, const uint32_t* parity,
+                                     const uint8_t* started, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cov_final, dim3(sl.n_lanes), dim3(256), 0, s, sl, state, carry, parity, started);
+}
+
+extern "C" void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_add_words, dim3((n + 255) / 256), dim3(256), 0, s, state, idx, val, n);
+}
+
+extern "C" void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_or_bytes, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
+}

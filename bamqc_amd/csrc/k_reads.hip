@@ -1,0 +1,76 @@
+// k_reads.hip — per-read statistics: flag cascade + scalar counters (reference
+// src/bamqualcheck.cpp:318-434) and the per-read histograms of QualityCheck
+// (src/QualityCheck.hpp:168-271: read_length, map_Q, insert_size, mis_match, cigar_count).
+//
+// Thread per read over the lane-grouped order (perm).  Counters are privatised in LDS per
+// workgroup for the read group ("lane") the workgroup is currently in and flushed with one global
+// atomic per non-zero bin; bins beyond the LDS capacity and reads of another lane inside a mixed
+// wave go to global memory directly.  Reads 48 B of fixed columns + the CIGAR words per read.
+#include "kernels_common.h"
+#include "read_stats.h"
+
+__global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
+                                                  uint32_t* __restrict__ err, uint32_t per_block)
+{
+    __shared__ uint32_t lds[RS_WORDS];
+    __shared__ uint32_t s_lane;
+    for (uint32_t i = threadIdx.x; i < RS_WORDS; i += blockDim.x) lds[i] = 0;
+    const uint32_t lo = blockIdx.x * per_block;
+    const uint32_t hi = min(b.n_reads, lo + per_block);
+    uint32_t blane = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += blockDim.x) {
+        const uint32_t k = base + threadIdx.x;
+        const bool live = k < hi;
+        const uint32_t r = live ? (b.perm ? b.perm[k] : k) : 0;
+        const uint32_t lane = live ? b.lane[r] : 0;
+        if (threadIdx.x == 0) s_lane = lane;
+        __syncthreads();
+        const uint32_t fl = s_lane;
+        if (fl != blane) { // block-uniform
+            if (blane != 0xFFFFFFFFu) rs_flush(lds, sl, state, blane);
+            __syncthreads();
+            blane = fl;
+        }
+        read_stats(b, sl, state, refs, err, lds, r, live, live && lane == blane);
+        __syncthreads();
+    }
+    if (blane != 0xFFFFFFFFu) rs_flush(lds, sl, state, blane);
+}
+
+// further integer NM tags of a record: mis_match counts once per tag (QualityCheck.hpp:201-218)
+__global__ void k_nm_extra(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs, uint32_t* __restrict__ err)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b.n_nm_extra) return;
+    const uint32_t r = b.nm_extra_read[e];
+    const uint32_t flag = b.flag[r];
+    if (flag & 0x900) return;
+    const bool first = flag & 0x40, last = !first && (flag & 0x80);
+    if (!first && !last) return;
+    const int32_t rid = b.rid[r];
+    if (!(rid >= 0 && (uint32_t)rid < refs.n_refs && refs.main_chrom[rid]) || (flag & 0x4)) return;
+    const uint32_t* cg = b.cigar + b.cigar_off[r];
+    uint32_t del = 0, ins = 0;
+    for (uint32_t k = 0; k < b.n_cigar[r]; ++k) {
+        const uint32_t c = cg[k], op = c & 15u;
+        if (op == 2u) del += c >> 4; else if (op == 1u) ins += c >> 4;
+    }
+    const uint32_t mm = (uint32_t)b.nm_extra_val[e] - del - ins;
+    if (mm >= sl.hcap) { atomicOr(err, BQC_DEVERR_RANGE); return; }
+    gadd(state + sl.mate_base(b.lane[r], first ? 0u : 1u) + sl.m_mismatch + mm, 1);
+}
+
+extern "C" void bqc_launch_reads(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
+                                 uint32_t n_cu, hipStream_t s)
+{
+    if (b.n_reads == 0) return;
+    // a few workgroups per CU, each owning a contiguous run of reads (multiple of the block size)
+    uint32_t grid = n_cu * 4;
+    uint32_t per = (b.n_reads + grid - 1) / grid;
+    per = ((per + 255) / 256) * 256;
+    grid = (b.n_reads + per - 1) / per;
+    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, b, sl, state, refs, err, per);
+    if (b.n_nm_extra)
+        hipLaunchKernelGGL(k_nm_extra, dim3((b.n_nm_extra + 255) / 256), dim3(256), 0, s, b, sl, state, refs, err);
+}
