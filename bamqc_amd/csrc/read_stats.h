@@ -98,7 +98,8 @@ __device__ __forceinline__ void read_stats(const DevBatch& b, const StateLayout&
     uint64_t* M = state + sl.mate_base(lane, mate);
     uint32_t* LM = lds + RS_MATE + mate * RS_M_WORDS;
     // read_length + qualcount_readnr (QualityCheck.hpp:130,168-176)
-    rs_count(mated && use_lds, LM + RS_M_READNR);
+    rs_count(first && use_lds, lds + RS_MATE + RS_M_READNR);              // rs_count: one address per call
+    rs_count(last && use_lds, lds + RS_MATE + RS_M_WORDS + RS_M_READNR);
     wave_inc(mated && gl, M + sl.m_readnr);
     rs_hist(mated && L <= sl.lcap, use_lds, L <= sl.lcap ? L : 0, RS_CT + 1, LM + RS_M_READLEN, M + sl.m_readlen);
     // ---- main chromosomes only, :392-434
