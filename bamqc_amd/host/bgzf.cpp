@@ -1,0 +1,184 @@
+// bgzf.cpp — see bgzf.h
+#include "bgzf.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace {
+const size_t kMaxBlock = 65536;
+const size_t kWriteBlock = 65280; // uncompressed payload per block (leaves room for incompressible data)
+
+struct BlockRef { size_t off, csize, usize, uoff; };
+
+unsigned default_threads()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char* e = getenv("BQC_IO_THREADS")) n = (unsigned)atoi(e);
+    return std::max(1u, std::min(n, 32u));
+}
+
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F f)
+{
+    if (threads <= 1 || n <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    const unsigned nt = (unsigned)std::min<size_t>(threads, n);
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto& t : th) t.join();
+}
+} // namespace
+
+BgzfReader::~BgzfReader() { if (f_) fclose(f_); }
+
+bool BgzfReader::open(const char* path, std::string& err, unsigned threads)
+{
+    f_ = fopen(path, "rb");
+    if (!f_) { err = std::string("could not open ") + path; return false; }
+    setvbuf(f_, nullptr, _IOFBF, 1 << 22);
+    threads_ = threads ? threads : default_threads();
+    return true;
+}
+
+bool BgzfReader::next_chunk(std::vector<uint8_t>& out, std::string& err)
+{
+    out.clear();
+    if (eof_) return false;
+    const size_t want = (size_t)threads_ * 8 * kMaxBlock; // compressed bytes per round
+    // keep the tail of the previous round (a partial block) at the front of raw_
+    size_t have = raw_.size();
+    raw_.resize(have + want);
+    size_t got = fread(raw_.data() + have, 1, want, f_);
+    cbytes_ += got;
+    raw_.resize(have + got);
+    if (got < want) eof_ = true;
+    std::vector<BlockRef> blocks;
+    size_t p = 0, utotal = 0;
+    while (p + 18 <= raw_.size()) {
+        const uint8_t* h = raw_.data() + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF stream (bad gzip member header)"; return false; }
+        const size_t xlen = h[10] | (h[11] << 8);
+        if (p + 12 + xlen > raw_.size()) break;
+        size_t bsize = 0, x = 12;
+        while (x + 4 <= 12 + xlen) {
+            const size_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize) { err = "BGZF block without BC extra field"; return false; }
+        if (p + bsize > raw_.size()) break;
+        const uint8_t* t = raw_.data() + p + bsize - 8;
+        const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
+        if (isize > kMaxBlock) { err = "BGZF block larger than 64 KiB"; return false; }
+        blocks.push_back(BlockRef{p + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
+        utotal += isize;
+        p += bsize;
+    }
+    if (eof_ && p != raw_.size()) { err = "truncated BGZF file"; return false; }
+    out.resize(utotal);
+    std::atomic<bool> bad{false};
+    parallel_for(blocks.size(), threads_, [&](size_t i) {
+        const BlockRef& b = blocks[i];
+        if (b.usize == 0) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+        zs.next_in = raw_.data() + b.off; zs.avail_in = (uInt)b.csize;
+        zs.next_out = out.data() + b.uoff; zs.avail_out = (uInt)b.usize;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
+        else {
+            const uint8_t* t = raw_.data() + b.off + b.csize;
+            const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (crc32(crc32(0L, Z_NULL, 0), out.data() + b.uoff, (uInt)b.usize) != crc) bad = true;
+        }
+        inflateEnd(&zs);
+    });
+    if (bad) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
+    raw_.erase(raw_.begin(), raw_.begin() + p);
+    if (out.empty() && eof_) return false;
+    return true;
+}
+
+BgzfWriter::~BgzfWriter() { if (f_) close(); }
+
+bool BgzfWriter::open(const char* path, std::string& err, int level, unsigned threads)
+{
+    f_ = fopen(path, "wb");
+    if (!f_) { err = std::string("could not open ") + path + " for writing"; return false; }
+    setvbuf(f_, nullptr, _IOFBF, 1 << 22);
+    level_ = level;
+    threads_ = threads ? threads : default_threads();
+    return true;
+}
+
+static size_t compress_block(const uint8_t* src, size_t n, uint8_t* dst, int level)
+{
+    static const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 0, 0};
+    memcpy(dst, hdr, 18);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n;
+    zs.next_out = dst + 18; zs.avail_out = (uInt)(kMaxBlock - 18 - 8);
+    int rc = deflate(&zs, Z_FINISH);
+    size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) { // incompressible: store
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n;
+        zs.next_out = dst + 18; zs.avail_out = (uInt)(kMaxBlock - 18 - 8);
+        deflate(&zs, Z_FINISH);
+        clen = zs.total_out;
+        deflateEnd(&zs);
+    }
+    const size_t bsize = 18 + clen + 8;
+    dst[16] = (uint8_t)((bsize - 1) & 0xFF); dst[17] = (uint8_t)((bsize - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+    uint8_t* t = dst + 18 + clen;
+    t[0] = crc & 0xFF; t[1] = (crc >> 8) & 0xFF; t[2] = (crc >> 16) & 0xFF; t[3] = (crc >> 24) & 0xFF;
+    t[4] = n & 0xFF; t[5] = (n >> 8) & 0xFF; t[6] = (n >> 16) & 0xFF; t[7] = (n >> 24) & 0xFF;
+    return bsize;
+}
+
+bool BgzfWriter::flush_pending(bool all)
+{
+    const size_t nblk = all ? (pend_.size() + kWriteBlock - 1) / kWriteBlock : pend_.size() / kWriteBlock;
+    if (!nblk) return true;
+    std::vector<uint8_t> out(nblk * kMaxBlock);
+    std::vector<size_t> sz(nblk);
+    parallel_for(nblk, threads_, [&](size_t i) {
+        const size_t off = i * kWriteBlock, n = std::min(kWriteBlock, pend_.size() - off);
+        sz[i] = compress_block(pend_.data() + off, n, out.data() + i * kMaxBlock, level_);
+    });
+    for (size_t i = 0; i < nblk; ++i)
+        if (fwrite(out.data() + i * kMaxBlock, 1, sz[i], f_) != sz[i]) return false;
+    const size_t used = std::min(pend_.size(), nblk * kWriteBlock);
+    pend_.erase(pend_.begin(), pend_.begin() + used);
+    return true;
+}
+
+bool BgzfWriter::write(const void* data, size_t n)
+{
+    const uint8_t* p = (const uint8_t*)data;
+    pend_.insert(pend_.end(), p, p + n);
+    if (pend_.size() >= (size_t)threads_ * 16 * kWriteBlock) return flush_pending(false);
+    return true;
+}
+
+bool BgzfWriter::close()
+{
+    if (!f_) return true;
+    bool ok = flush_pending(true);
+    static const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof, 1, 28, f_) == 28;
+    ok = (fclose(f_) == 0) && ok;
+    f_ = nullptr;
+    return ok;
+}

@@ -1,0 +1,40 @@
+// bgzf.h — BGZF block reader (parallel inflate) and writer (parallel deflate) on zlib.
+// Replaces SeqAn's BAM stream layer (reference src/bamqualcheck.cpp:262, readRecord :306).
+// Format: public SAM/BAM specification (gzip members <= 64 KiB with a "BC" extra field).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+class BgzfReader {
+public:
+    ~BgzfReader();
+    bool open(const char* path, std::string& err, unsigned threads = 0);
+    // Fills `out` with the next run of uncompressed bytes (many blocks at once); returns false at EOF.
+    // On a malformed stream sets err and returns false.
+    bool next_chunk(std::vector<uint8_t>& out, std::string& err);
+    uint64_t compressed_bytes_read() const { return cbytes_; }
+
+private:
+    FILE* f_ = nullptr;
+    unsigned threads_ = 1;
+    uint64_t cbytes_ = 0;
+    bool eof_ = false;
+    std::vector<uint8_t> raw_;
+};
+
+class BgzfWriter {
+public:
+    ~BgzfWriter();
+    bool open(const char* path, std::string& err, int level = 1, unsigned threads = 0);
+    bool write(const void* data, size_t n); // buffered; compresses in parallel when enough data is pending
+    bool close();                           // flushes and appends the 28-byte EOF block
+
+private:
+    bool flush_pending(bool all);
+    FILE* f_ = nullptr;
+    int level_ = 1;
+    unsigned threads_ = 1;
+    std::vector<uint8_t> pend_;
+};
