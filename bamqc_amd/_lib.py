@@ -41,6 +41,24 @@ _SIGNATURES = {
     "bqc_synth_reference": (C.c_int, [C.c_uint64, C.c_int32, C.c_uint64, _abi.u8p]),
     "bqc_synth_batch": (C.c_int, [C.POINTER(_abi.SynthParams), C.POINTER(_abi.u8p), C.POINTER(C.POINTER(_abi.Batch))]),
     "bqc_synth_batch_free": (None, [C.POINTER(_abi.Batch)]),
+    "bqc_synth_write": (C.c_int, [C.POINTER(_abi.SynthParams), C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_uint32]),
+    "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bqc_bam_close": (None, [C.c_void_p]),
+    "bqc_bam_error": (C.c_char_p, [C.c_void_p]),
+    "bqc_bam_n_refs": (C.c_uint32, [C.c_void_p]),
+    "bqc_bam_ref_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "bqc_bam_ref_len": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "bqc_bam_sample_id": (C.c_char_p, [C.c_void_p]),
+    "bqc_bam_lane_count": (C.c_uint32, [C.c_void_p]),
+    "bqc_bam_n_lane_names": (C.c_uint32, [C.c_void_p]),
+    "bqc_bam_lane_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "bqc_bam_lane_index": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "bqc_bam_set_main_chrom": (C.c_int, [C.c_void_p, _abi.u8p]),
+    "bqc_bam_next": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(_abi.Batch))]),
+    "bqc_fasta_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_char_p)),
+                                 C.POINTER(C.POINTER(_abi.u8p)), C.POINTER(_abi.u64p)]),
+    "bqc_fasta_free": (None, [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_abi.u8p), _abi.u64p]),
+    "bqc_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
 }
 
 _LIB = None

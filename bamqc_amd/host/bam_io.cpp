@@ -1,0 +1,278 @@
+// bam_io.cpp — see bam_io.h
+#include "bam_io.h"
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+
+bqc_batch HostBatch::view() const
+{
+    bqc_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_reads = (uint32_t)flag.size();
+    b.flag = flag.data(); b.mapq = mapq.data(); b.lane = lane.data(); b.rid = rid.data(); b.pos = pos.data();
+    b.tlen = tlen.data(); b.nm = nm.data(); b.as = as.data(); b.l_seq = l_seq.data(); b.n_cigar = n_cigar.data();
+    b.seq = seq.data(); b.qual = qual.data(); b.cigar = cigar.data();
+    b.n_nm_extra = (uint32_t)nm_extra_read.size();
+    b.nm_extra_read = nm_extra_read.data(); b.nm_extra_val = nm_extra_val.data();
+    return b;
+}
+void HostBatch::clear()
+{
+    flag.clear(); n_cigar.clear(); mapq.clear(); lane.clear(); seq.clear(); qual.clear(); rid.clear(); pos.clear();
+    tlen.clear(); nm.clear(); as.clear(); nm_extra_val.clear(); l_seq.clear(); cigar.clear(); nm_extra_read.clear();
+}
+
+static inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+bool BamReader::fill(size_t need, std::string& err)
+{
+    while (buf_.size() - cur_ < need) {
+        if (eof_) return false;
+        if (cur_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + cur_); cur_ = 0; }
+        std::string e;
+        if (!bg_.next_chunk(chunk_, e)) {
+            eof_ = true;
+            if (!e.empty()) { err = e; return false; }
+            continue;
+        }
+        buf_.insert(buf_.end(), chunk_.begin(), chunk_.end());
+    }
+    return true;
+}
+
+// getSampleIdAndLaneNames, bamqualcheck.cpp:44-66
+static void parse_read_groups(BamHeader& h)
+{
+    size_t p = 0;
+    const std::string& t = h.text;
+    while (p < t.size()) {
+        size_t e = t.find('\n', p);
+        if (e == std::string::npos) e = t.size();
+        if (e - p >= 3 && t.compare(p, 3, "@RG") == 0) {
+            size_t q = p + 3;
+            while (q < e) {
+                if (t[q] == '\t') { ++q; continue; }
+                size_t f = t.find('\t', q);
+                if (f == std::string::npos || f > e) f = e;
+                if (f - q >= 3 && t[q + 2] == ':') {
+                    const std::string key = t.substr(q, 2);
+                    std::string val = t.substr(q + 3, f - q - 3);
+                    if (!val.empty() && val.back() == '\r') val.pop_back();
+                    if (key == "ID") { const unsigned l = (unsigned)h.lane_names.size(); h.lane_names[val] = l; }
+                    if (key == "SM") h.sample_id = val;
+                }
+                q = f;
+            }
+        }
+        p = e + 1;
+    }
+    h.lane_count = (unsigned)h.lane_names.size();
+}
+
+bool BamReader::open(const char* path, std::string& err)
+{
+    if (!bg_.open(path, err)) return false;
+    std::string e;
+    if (!fill(12, e) || memcmp(buf_.data(), "BAM\1", 4) != 0) { err = e.empty() ? "not a BAM file" : e; return false; }
+    const uint32_t l_text = rd32(buf_.data() + 4);
+    if (!fill(12 + (size_t)l_text, e)) { err = "truncated BAM header"; return false; }
+    hdr_.text.assign((const char*)buf_.data() + 8, l_text);
+    while (!hdr_.text.empty() && hdr_.text.back() == '\0') hdr_.text.pop_back();
+    cur_ = 8 + l_text;
+    const uint32_t n_ref = rd32(buf_.data() + cur_);
+    cur_ += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (!fill(4, e)) { err = "truncated BAM header"; return false; }
+        const uint32_t l_name = rd32(buf_.data() + cur_);
+        if (!fill(8 + (size_t)l_name, e)) { err = "truncated BAM header"; return false; }
+        std::string name((const char*)buf_.data() + cur_ + 4, l_name ? l_name - 1 : 0);
+        hdr_.ref_names.push_back(name);
+        hdr_.ref_lens.push_back(rd32(buf_.data() + cur_ + 4 + l_name));
+        cur_ += 8 + l_name;
+    }
+    parse_read_groups(hdr_);
+    return true;
+}
+
+int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std::string& err, int& err_code)
+{
+    o.clear();
+    size_t bases = 0;
+    err_code = 0;
+    while (o.n() < max_reads && bases < max_bases) {
+        std::string e;
+        if (!fill(4, e)) {
+            if (!e.empty() || buf_.size() != cur_) { err = e.empty() ? "truncated BAM record" : e; err_code = BQC_ERR_IO; return -1; }
+            break;
+        }
+        const uint32_t bs = rd32(buf_.data() + cur_);
+        if (bs < 32 || !fill(4 + (size_t)bs, e)) { err = e.empty() ? "truncated BAM record" : e; err_code = BQC_ERR_IO; return -1; }
+        const uint8_t* r = buf_.data() + cur_ + 4;
+        const int32_t rid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+        const uint32_t l_name = r[8], mapq = r[9];
+        const uint32_t n_cig = rd16(r + 12), flag = rd16(r + 14), l_seq = rd32(r + 16);
+        const int32_t rnext = (int32_t)rd32(r + 20), tlen = (int32_t)rd32(r + 28);
+        const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+        if (var > bs) { err = "corrupt BAM record"; err_code = BQC_ERR_IO; return -1; }
+        const uint8_t* cig = r + 32 + l_name;
+        const uint8_t* sq = cig + 4ull * n_cig;
+        const uint8_t* ql = sq + (l_seq + 1) / 2;
+        const uint8_t* tg = ql + l_seq;
+        const uint8_t* te = r + bs;
+        // one linear tag scan: RG (getLane, bamqualcheck.cpp:72-100), every integer NM (QualityCheck.hpp:201-209),
+        // first AS (TripletCounting.hpp:113-127)
+        int lane = -1;
+        bool rg_seen = false, rg_bad = false, as_seen = false;
+        int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
+        bool nm_seen = false;
+        const uint32_t idx = (uint32_t)o.n();
+        while (tg + 3 <= te) {
+            const char k0 = (char)tg[0], k1 = (char)tg[1], ty = (char)tg[2];
+            const uint8_t* v = tg + 3;
+            size_t len = 0;
+            switch (ty) {
+            case 'A': case 'c': case 'C': len = 1; break;
+            case 's': case 'S': len = 2; break;
+            case 'i': case 'I': case 'f': len = 4; break;
+            case 'Z': case 'H': { const void* z = memchr(v, 0, (size_t)(te - v)); len = z ? (size_t)((const uint8_t*)z - v) + 1 : (size_t)(te - v); break; }
+            case 'B': {
+                if (v + 5 > te) { len = (size_t)(te - v); break; }
+                const char st = (char)v[0];
+                const size_t cnt = rd32(v + 1);
+                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                len = 5 + cnt * es;
+                break;
+            }
+            default: len = (size_t)(te - v); break;
+            }
+            if (v + len > te) { err = "corrupt BAM tags"; err_code = BQC_ERR_IO; return -1; }
+            if (k0 == 'R' && k1 == 'G' && !rg_seen) {
+                rg_seen = true;
+                if (ty == 'Z') {
+                    std::string id((const char*)v, len ? len - 1 : 0);
+                    auto it = hdr_.lane_names.find(id);
+                    if (it == hdr_.lane_names.end()) { hdr_.lane_names[id] = 0; lane = 0; } // std::map::operator[] inserts 0 (:86)
+                    else lane = (int)it->second;
+                } else rg_bad = true;
+            } else if (k0 == 'N' && k1 == 'M' && (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I')) {
+                uint32_t x = 0;
+                switch (ty) {
+                case 'c': x = (uint32_t)(int32_t)(int8_t)v[0]; break;
+                case 'C': x = v[0]; break;
+                case 's': x = (uint32_t)(int32_t)(int16_t)rd16(v); break;
+                case 'S': x = rd16(v); break;
+                default: x = rd32(v); break;
+                }
+                if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
+                else { o.nm_extra_read.push_back(idx); o.nm_extra_val.push_back((int32_t)x); }
+            } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
+                as_seen = true;
+                switch (ty) {
+                case 'A': as = (int32_t)(char)v[0]; break;
+                case 'c': as = (int8_t)v[0]; break;
+                case 'C': as = v[0]; break;
+                case 's': as = (int16_t)rd16(v); break;
+                case 'S': as = rd16(v); break;
+                case 'i': case 'I': as = (int32_t)rd32(v); break;
+                case 'f': { float f; uint32_t u = rd32(v); memcpy(&f, &u, 4); as = (int32_t)f; break; }
+                default: as = BQC_AS_ABSENT; break; // extractTagValue fails -> "Could not read AS tag"
+                }
+            }
+            tg = v + len;
+        }
+        if (rg_bad) { err = "Read does not have Z"; err_code = BQC_ERR_ARG; return -1; }
+        if (!rg_seen) { // DEFINED: the reference falls off the end of getLane() (undefined behaviour)
+            err = "ERROR: read without RG tag (record " + std::to_string(nrec_) + ")";
+            err_code = BQC_ERR_ARG;
+            return -1;
+        }
+        if ((unsigned)lane >= hdr_.lane_count) { err = "ERROR: read group index out of range (no @RG lines in the header?)"; err_code = BQC_ERR_ARG; return -1; }
+        if (nm_seen && nm == BQC_NM_ABSENT) { err = "NM tag value 0xFFFFFFFF is not representable"; err_code = BQC_ERR_RANGE; return -1; }
+        uint32_t f = flag & 0x0FFFu;
+        if (rnext >= 0 && (size_t)rnext < main_.size() && main_[rnext]) f |= BQC_FLAG_MATE_MAIN;
+        if (l_seq > 0 && ql[0] == 0xFF) f |= BQC_FLAG_NO_QUAL;
+        o.flag.push_back((uint16_t)f); o.mapq.push_back((uint8_t)mapq); o.lane.push_back((uint8_t)lane); o.rid.push_back(rid);
+        o.pos.push_back(pos); o.tlen.push_back(tlen); o.nm.push_back(nm); o.as.push_back(as); o.l_seq.push_back(l_seq);
+        o.n_cigar.push_back((uint16_t)n_cig);
+        const size_t c0 = o.cigar.size();
+        o.cigar.resize(c0 + n_cig);
+        if (n_cig) memcpy(o.cigar.data() + c0, cig, 4ull * n_cig);
+        o.seq.insert(o.seq.end(), sq, sq + (l_seq + 1) / 2);
+        o.qual.insert(o.qual.end(), ql, ql + l_seq);
+        bases += l_seq;
+        cur_ += 4 + (size_t)bs;
+        ++nrec_;
+    }
+    return o.n() ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// writer
+// ---------------------------------------------------------------------------------------------------
+static void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x & 0xFF); v.push_back((x >> 8) & 0xFF); v.push_back((x >> 16) & 0xFF); v.push_back((x >> 24) & 0xFF); }
+static void put16(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x & 0xFF); v.push_back((x >> 8) & 0xFF); }
+
+bool BamWriter::open(const char* path, const std::string& text, const std::vector<std::string>& names, const std::vector<uint32_t>& lens,
+                     std::string& err, int level)
+{
+    if (!bg_.open(path, err, level)) return false;
+    std::vector<uint8_t> h;
+    h.insert(h.end(), {'B', 'A', 'M', 1});
+    put32(h, (uint32_t)text.size());
+    h.insert(h.end(), text.begin(), text.end());
+    put32(h, (uint32_t)names.size());
+    for (size_t i = 0; i < names.size(); ++i) {
+        put32(h, (uint32_t)names[i].size() + 1);
+        h.insert(h.end(), names[i].begin(), names[i].end());
+        h.push_back(0);
+        put32(h, lens[i]);
+    }
+    return bg_.write(h.data(), h.size());
+}
+
+static uint32_t reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+bool BamWriter::write_batch(const bqc_batch& b, const std::vector<std::string>& lane_ids, uint64_t first)
+{
+    uint64_t so = 0, qo = 0, co = 0;
+    for (uint32_t i = 0; i < b.n_reads; ++i) {
+        rec_.clear();
+        char name[32];
+        const int nl = snprintf(name, sizeof name, "r%llu", (unsigned long long)(first + i)) + 1;
+        const uint32_t L = b.l_seq[i], nc = b.n_cigar[i];
+        int64_t reflen = 0;
+        for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = b.cigar[co + k] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += b.cigar[co + k] >> 4; }
+        put32(rec_, 0); // block size, patched below
+        put32(rec_, (uint32_t)b.rid[i]); put32(rec_, (uint32_t)b.pos[i]);
+        rec_.push_back((uint8_t)nl); rec_.push_back(b.mapq[i]);
+        put16(rec_, b.pos[i] >= 0 ? reg2bin(b.pos[i], b.pos[i] + (reflen ? reflen : 1)) : 4680);
+        put16(rec_, nc); put16(rec_, b.flag[i] & 0x0FFFu);
+        put32(rec_, L); put32(rec_, (uint32_t)b.rid[i]); put32(rec_, (uint32_t)b.pos[i]); put32(rec_, (uint32_t)b.tlen[i]);
+        rec_.insert(rec_.end(), name, name + nl);
+        for (uint32_t k = 0; k < nc; ++k) put32(rec_, b.cigar[co + k]);
+        rec_.insert(rec_.end(), b.seq + so, b.seq + so + (L + 1) / 2);
+        rec_.insert(rec_.end(), b.qual + qo, b.qual + qo + L);
+        const std::string& rg = lane_ids[b.lane[i]];
+        rec_.insert(rec_.end(), {'R', 'G', 'Z'});
+        rec_.insert(rec_.end(), rg.begin(), rg.end());
+        rec_.push_back(0);
+        if (b.nm[i] != BQC_NM_ABSENT) { rec_.insert(rec_.end(), {'N', 'M', 'i'}); put32(rec_, (uint32_t)b.nm[i]); }
+        if (b.as[i] != BQC_AS_ABSENT) { rec_.insert(rec_.end(), {'A', 'S', 'i'}); put32(rec_, (uint32_t)b.as[i]); }
+        const uint32_t bs = (uint32_t)rec_.size() - 4;
+        rec_[0] = bs & 0xFF; rec_[1] = (bs >> 8) & 0xFF; rec_[2] = (bs >> 16) & 0xFF; rec_[3] = (bs >> 24) & 0xFF;
+        if (!bg_.write(rec_.data(), rec_.size())) return false;
+        so += (L + 1) / 2; qo += L; co += nc;
+    }
+    return true;
+}

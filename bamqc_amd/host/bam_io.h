@@ -1,0 +1,69 @@
+// bam_io.h — BAM header / record decoding straight into the SoA batch of include/bamqc.h, and the
+// matching writer used by the synthetic generator.  Replaces SeqAn's BamStream / readRecord /
+// BamTagsDict (reference src/bamqualcheck.cpp:44-100, 252-267, 303-315; QualityCheck.hpp:201-209;
+// TripletCounting.hpp:110-130).  Formats: public SAM/BAM specification.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bamqc.h"
+#include "bgzf.h"
+
+struct BamHeader {
+    std::string text;
+    std::vector<std::string> ref_names;
+    std::vector<uint32_t> ref_lens;
+    // getSampleIdAndLaneNames (bamqualcheck.cpp:44-66)
+    std::string sample_id;                      // SM of the last @RG that has one
+    std::map<std::string, unsigned> lane_names; // @RG ID -> lane index, iterated lexicographically at output
+    unsigned lane_count = 0;                    // laneNames.size() after the header (bamqualcheck.cpp:297)
+};
+
+struct HostBatch { // owning storage behind a bqc_batch
+    std::vector<uint16_t> flag, n_cigar;
+    std::vector<uint8_t> mapq, lane, seq, qual;
+    std::vector<int32_t> rid, pos, tlen, nm, as, nm_extra_val;
+    std::vector<uint32_t> l_seq, cigar, nm_extra_read;
+    bqc_batch view() const;
+    void clear();
+    size_t n() const { return flag.size(); }
+};
+
+class BamReader {
+public:
+    bool open(const char* path, std::string& err);
+    const BamHeader& header() const { return hdr_; }
+    BamHeader& header() { return hdr_; }
+    void set_main_chrom(const std::vector<uint8_t>& mc) { main_ = mc; }
+    // Decodes up to max_reads records (and at most max_bases bases) into `out`.
+    // Returns 1 = batch filled (maybe partially, more may follow), 0 = end of file and nothing read,
+    // -1 = error (err set; code in err_code: BQC_ERR_IO for a corrupt file, BQC_ERR_ARG for the RG-tag rule).
+    int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code);
+    uint64_t records() const { return nrec_; }
+
+private:
+    bool fill(size_t need, std::string& err); // ensure `need` bytes are available at cur_
+    BgzfReader bg_;
+    BamHeader hdr_;
+    std::vector<uint8_t> buf_, chunk_;
+    size_t cur_ = 0;
+    bool eof_ = false;
+    std::vector<uint8_t> main_;
+    uint64_t nrec_ = 0;
+};
+
+// minimal BAM writer (used by the synthetic generator and tests)
+class BamWriter {
+public:
+    bool open(const char* path, const std::string& header_text, const std::vector<std::string>& ref_names,
+              const std::vector<uint32_t>& ref_lens, std::string& err, int level = 1);
+    // writes every read of the batch; tags: RG:Z:<lane_ids[lane]>, NM:i (if present), AS:i (if present)
+    bool write_batch(const bqc_batch& b, const std::vector<std::string>& lane_ids, uint64_t first_read_index);
+    bool close() { return bg_.close(); }
+
+private:
+    BgzfWriter bg_;
+    std::vector<uint8_t> rec_;
+};

@@ -1,0 +1,476 @@
+// driver.cpp — the `bamqualcheck` program as a library function: drop-in for the reference's main()
+// (src/bamqualcheck.cpp:239-457) and command line (src/CommandLineParser.hpp:43-149), with the
+// record loop's body replaced by the GPU aggregation of include/bamqc.h.  Also: FASTA loader
+// (replaces Genome / SequenceStream, src/TripletCounting.hpp:60-104) and the C wrappers of
+// include/bamqc_host.h around the BAM reader.
+#include <zlib.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bamqc_host.h"
+#include "bam_io.h"
+#include "host_tools.h"
+
+// ---------------------------------------------------------------------------------------------------
+// FASTA
+// ---------------------------------------------------------------------------------------------------
+struct FastaRecord { std::string name; std::vector<uint8_t> codes; };
+
+static inline uint8_t dna5_of_char(char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
+    }
+}
+
+// Loads every record; the id is cut at the first space or tab (TripletCounting.hpp:99-102).
+// `want` (optional) limits which sequences are kept in memory; all records keep their FASTA position.
+static bool load_fasta(const char* path, const std::vector<std::string>* want, std::vector<FastaRecord>& out, std::string& err)
+{
+    gzFile f = gzopen(path, "rb");
+    if (!f) { err = std::string("ERROR: Could not open fasta file ") + path; return false; }
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(1 << 22);
+    FastaRecord* cur = nullptr;
+    bool keep = false, in_header = false;
+    std::string hdr;
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = dna5_of_char((char)i);
+    auto finish_header = [&]() {
+        size_t cut = hdr.find_first_of(" \t");
+        std::string name = hdr.substr(0, cut);
+        if (!name.empty() && name.back() == '\r') name.pop_back();
+        out.push_back(FastaRecord{name, {}});
+        cur = &out.back();
+        keep = true;
+        if (want) {
+            keep = false;
+            for (const auto& w : *want) if (w == name) { keep = true; break; }
+        }
+        hdr.clear();
+    };
+    int n;
+    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
+        for (int i = 0; i < n; ++i) {
+            const char c = buf[i];
+            if (in_header) {
+                if (c == '\n') { in_header = false; finish_header(); }
+                else hdr.push_back(c);
+            } else if (c == '>') {
+                in_header = true;
+            } else if (c != '\n' && c != '\r' && cur && keep) {
+                cur->codes.push_back(lut[(uint8_t)c]);
+            }
+        }
+    }
+    if (in_header) finish_header();
+    gzclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C wrappers around the reader (python drivers, tests)
+// ---------------------------------------------------------------------------------------------------
+struct bqc_bam {
+    BamReader rd;
+    HostBatch hb;
+    bqc_batch view;
+    std::string err;
+    std::vector<std::string> lane_sorted;
+    std::vector<uint32_t> lane_idx;
+    void refresh_lanes()
+    {
+        lane_sorted.clear(); lane_idx.clear();
+        for (auto& kv : rd.header().lane_names) { lane_sorted.push_back(kv.first); lane_idx.push_back(kv.second); }
+    }
+};
+
+extern "C" int bqc_bam_open(const char* path, bqc_bam** out)
+{
+    if (!path || !out) return BQC_ERR_ARG;
+    auto* b = new bqc_bam();
+    if (!b->rd.open(path, b->err)) { *out = b; return BQC_ERR_IO; }
+    b->refresh_lanes();
+    *out = b;
+    return 0;
+}
+extern "C" void bqc_bam_close(bqc_bam* b) { delete b; }
+extern "C" const char* bqc_bam_error(const bqc_bam* b) { return b ? b->err.c_str() : ""; }
+extern "C" uint32_t bqc_bam_n_refs(const bqc_bam* b) { return (uint32_t)b->rd.header().ref_names.size(); }
+extern "C" const char* bqc_bam_ref_name(const bqc_bam* b, uint32_t i) { return b->rd.header().ref_names[i].c_str(); }
+extern "C" uint32_t bqc_bam_ref_len(const bqc_bam* b, uint32_t i) { return b->rd.header().ref_lens[i]; }
+extern "C" const char* bqc_bam_sample_id(const bqc_bam* b) { return b->rd.header().sample_id.c_str(); }
+extern "C" uint32_t bqc_bam_lane_count(const bqc_bam* b) { return b->rd.header().lane_count; }
+extern "C" uint32_t bqc_bam_n_lane_names(bqc_bam* b) { b->refresh_lanes(); return (uint32_t)b->lane_sorted.size(); }
+extern "C" const char* bqc_bam_lane_name(const bqc_bam* b, uint32_t i) { return b->lane_sorted[i].c_str(); }
+extern "C" uint32_t bqc_bam_lane_index(const bqc_bam* b, uint32_t i) { return b->lane_idx[i]; }
+extern "C" int bqc_bam_set_main_chrom(bqc_bam* b, const uint8_t* mc)
+{
+    if (!b || !mc) return BQC_ERR_ARG;
+    b->rd.set_main_chrom(std::vector<uint8_t>(mc, mc + b->rd.header().ref_names.size()));
+    return 0;
+}
+extern "C" int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_batch** out)
+{
+    if (!b || !out) return -BQC_ERR_ARG;
+    int code = 0;
+    const int rc = b->rd.next_batch(b->hb, max_reads, max_bases, b->err, code);
+    if (rc < 0) return -code;
+    b->view = b->hb.view();
+    *out = &b->view;
+    return rc;
+}
+
+extern "C" int bqc_fasta_load(const char* path, uint32_t* n_records, char*** names, uint8_t*** codes, uint64_t** lens)
+{
+    std::vector<FastaRecord> recs;
+    std::string err;
+    if (!load_fasta(path, nullptr, recs, err)) return BQC_ERR_IO;
+    *n_records = (uint32_t)recs.size();
+    *names = (char**)calloc(recs.size() + 1, sizeof(char*));
+    *codes = (uint8_t**)calloc(recs.size() + 1, sizeof(uint8_t*));
+    *lens = (uint64_t*)calloc(recs.size() + 1, sizeof(uint64_t));
+    for (size_t i = 0; i < recs.size(); ++i) {
+        (*names)[i] = strdup(recs[i].name.c_str());
+        (*codes)[i] = (uint8_t*)malloc(recs[i].codes.size() + 1);
+        memcpy((*codes)[i], recs[i].codes.data(), recs[i].codes.size());
+        (*lens)[i] = recs[i].codes.size();
+    }
+    return 0;
+}
+extern "C" void bqc_fasta_free(uint32_t n, char** names, uint8_t** codes, uint64_t* lens)
+{
+    for (uint32_t i = 0; i < n; ++i) { free(names[i]); free(codes[i]); }
+    free(names); free(codes); free(lens);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic BAM + FASTA files
+// ---------------------------------------------------------------------------------------------------
+extern "C" int bqc_synth_write(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
+                               uint32_t batch_reads)
+{
+    if (!p || !bam_path || !ref_names) return BQC_ERR_ARG;
+    std::vector<std::vector<uint8_t>> refs(p->n_refs);
+    std::vector<const uint8_t*> rp(p->n_refs);
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    for (uint32_t c = 0; c < p->n_refs; ++c) {
+        refs[c].resize(p->ref_len[c]);
+        bqc_synth_reference(p->seed, (int32_t)c, p->ref_len[c], refs[c].data());
+        rp[c] = refs[c].data();
+        names.push_back(ref_names[c]);
+        lens.push_back(p->ref_len[c]);
+    }
+    if (fasta_path) {
+        FILE* f = fopen(fasta_path, "wb");
+        if (!f) return BQC_ERR_IO;
+        std::string line;
+        for (uint32_t c = 0; c < p->n_refs; ++c) {
+            fprintf(f, ">%s synthetic contig %u\n", ref_names[c], c);
+            for (uint64_t i = 0; i < refs[c].size(); i += 60) {
+                line.clear();
+                for (uint64_t k = i; k < std::min<uint64_t>(refs[c].size(), i + 60); ++k) line.push_back("ACGTN"[refs[c][k]]);
+                line.push_back('\n');
+                fwrite(line.data(), 1, line.size(), f);
+            }
+        }
+        fclose(f);
+    }
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (uint32_t c = 0; c < p->n_refs; ++c) text += "@SQ\tSN:" + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
+    std::vector<std::string> lane_ids;
+    for (uint32_t l = 0; l < std::max(1u, p->n_lanes); ++l) {
+        lane_ids.push_back("L" + std::to_string(l + 1));
+        text += "@RG\tID:" + lane_ids.back() + "\tSM:SYN\tPL:ILLUMINA\n";
+    }
+    BamWriter w;
+    std::string err;
+    if (!w.open(bam_path, text, names, lens, err)) return BQC_ERR_IO;
+    // One generator call for all reads keeps the coordinate order; written in slices.
+    bqc_batch* b = nullptr;
+    int rc = bqc_synth_batch(p, rp.data(), &b);
+    if (rc) return rc;
+    (void)batch_reads;
+    const bool ok = w.write_batch(*b, lane_ids, p->first_read_index) && w.close();
+    bqc_synth_batch_free(b);
+    return ok ? 0 : BQC_ERR_IO;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// command line (CommandLineParser.hpp:43-149)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct ProgramOptions {
+    std::string bamFile, referenceFile = "genome.fa", outputFile;
+    std::string chroms = "chr1,chr2,chr3,chr4,chr5,chr6,chr7,chr8,chr9,chr10,chr11,chr12,chr13,chr14,chr15,chr16,chr17,chr18,chr19,chr20,chr21,chr22";
+    std::vector<int32_t> klist;
+    std::vector<uint32_t> q_cutoff;
+    double e = 0.01;
+    int seed = 1;
+    int isize = 1000;
+    // extensions (not in the reference)
+    uint32_t max_read_len = 65536, hist_cap = 65536;
+    int device = 0;
+    uint32_t batch_reads = 1u << 20;
+    bool no_sketch = false;
+};
+
+const char* kVersion = "dev"; // src/version.h:12
+
+void usage(FILE* f)
+{
+    fprintf(f,
+            "bamqualcheck - String Modifier\n==============================\n\nSYNOPSIS\n    bamqualcheck [OPTIONS] BAMFILE\n\n"
+            "DESCRIPTION\n    Program for bam quality checks. The program can read from bamfile or stdin(sam format)\n\n"
+            "    -h, --help\n          Displays this help message.\n    --version\n          Display version information\n\n"
+            "  General options:\n    -r, --reference FILENAME\n          Reference genome filename. Default: genome.fa.\n"
+            "    -i, --insert-size INT\n          Upper bound for the insert size in insert size histogram. Default: 1000.\n"
+            "    -c, --chromosomes STRING\n          Comma separated list of the main chromosome names.\n"
+            "    -o, --output-file OUT\n          Output filename.\n\n"
+            "  Kmerstream options:\n    -k, --kmer-size STRING\n          Comma-separated list of k-mer sizes. Default: 32.\n"
+            "    -q, --quality-cutoff STRING\n          Comma-separated list of PHRED quality thresholds. Default: 17.\n"
+            "    -e, --error-rate DOUBLE\n          Error rate guaranteed. Default: 0.01.\n"
+            "    -s, --seed INT\n          Seed value for the randomness. Default: 1.\n\n"
+            "  MI355X options (not in the reference):\n    --device INT, --max-read-len INT, --hist-cap INT, --batch-reads INT, --no-sketch\n\n"
+            "VERSION\n    bamqualcheck version: %s\n    Last update August 2019\n",
+            kVersion);
+}
+
+// returns 0 = ok, 1 = parse error, 2 = help/version printed (exit 0)
+int parse_args(int argc, const char** argv, ProgramOptions& o, std::string& err)
+{
+    std::string kstr = "32", qstr = "17";
+    bool have_r = false, have_o = false;
+    std::vector<std::string> pos;
+    auto need = [&](int& i, const std::string& name, std::string& val, const char* inl) -> bool {
+        if (inl) { val = inl; return true; }
+        if (i + 1 >= argc) { err = "bamqualcheck: option requires an argument -- " + name; return false; }
+        val = argv[++i];
+        return true;
+    };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-") { pos.push_back(a); continue; }
+        if (a == "-h" || a == "--help") { usage(stdout); return 2; }
+        if (a == "--version") { printf("bamqualcheck version: %s\nLast update August 2019\n", kVersion); return 2; }
+        const char* inl = nullptr;
+        std::string key = a;
+        if (a.rfind("--", 0) == 0) {
+            size_t eq = a.find('=');
+            if (eq != std::string::npos) { key = a.substr(0, eq); inl = argv[i] + eq + 1; }
+        } else if (a.size() > 2 && a[0] == '-') { // -ovalue
+            key = a.substr(0, 2);
+            inl = argv[i] + 2;
+        }
+        std::string v;
+        if (key == "-r" || key == "--reference") { if (!need(i, key, v, inl)) return 1; o.referenceFile = v; have_r = true; }
+        else if (key == "-o" || key == "--output-file") { if (!need(i, key, v, inl)) return 1; o.outputFile = v; have_o = true; }
+        else if (key == "-c" || key == "--chromosomes") { if (!need(i, key, v, inl)) return 1; o.chroms = v; }
+        else if (key == "-i" || key == "--insert-size") {
+            if (!need(i, key, v, inl)) return 1;
+            char* end = nullptr;
+            long x = strtol(v.c_str(), &end, 10);
+            if (!end || *end || v.empty()) { err = "bamqualcheck: the given value '" + v + "' cannot be casted to integer"; return 1; }
+            o.isize = (int)x;
+        }
+        else if (key == "-k" || key == "--kmer-size") { if (!need(i, key, v, inl)) return 1; kstr = v; }
+        else if (key == "-q" || key == "--quality-cutoff") { if (!need(i, key, v, inl)) return 1; qstr = v; }
+        else if (key == "-e" || key == "--error-rate") {
+            if (!need(i, key, v, inl)) return 1;
+            char* end = nullptr;
+            o.e = strtod(v.c_str(), &end);
+            if (!end || *end || v.empty()) { err = "bamqualcheck: the given value '" + v + "' cannot be casted to double"; return 1; }
+            if (o.e < 0) { err = "bamqualcheck: the given value '" + v + "' is smaller than the minimum value of 0"; return 1; }
+        }
+        else if (key == "-s" || key == "--seed") { if (!need(i, key, v, inl)) return 1; o.seed = atoi(v.c_str()); }
+        else if (key == "--device") { if (!need(i, key, v, inl)) return 1; o.device = atoi(v.c_str()); }
+        else if (key == "--max-read-len") { if (!need(i, key, v, inl)) return 1; o.max_read_len = (uint32_t)strtoul(v.c_str(), nullptr, 10); }
+        else if (key == "--hist-cap") { if (!need(i, key, v, inl)) return 1; o.hist_cap = (uint32_t)strtoul(v.c_str(), nullptr, 10); }
+        else if (key == "--batch-reads") { if (!need(i, key, v, inl)) return 1; o.batch_reads = (uint32_t)strtoul(v.c_str(), nullptr, 10); }
+        else if (key == "--no-sketch") { o.no_sketch = true; }
+        else if (a[0] == '-') { err = "bamqualcheck: illegal option -- " + a.substr(a.rfind("--", 0) == 0 ? 2 : 1); return 1; }
+        else pos.push_back(a);
+    }
+    if (!have_r) { err = "bamqualcheck: option requires an argument -- r (required option -r/--reference missing)"; return 1; }
+    if (!have_o) { err = "bamqualcheck: option requires an argument -- o (required option -o/--output-file missing)"; return 1; }
+    if (pos.size() != 1) { err = pos.empty() ? "bamqualcheck: Not enough arguments were provided." : "bamqualcheck: Too many arguments were provided!"; return 1; }
+    o.bamFile = pos[0];
+    if (o.bamFile != "-") { // valid values: "- bam sam" (file extension), CommandLineParser.hpp:59-60
+        size_t dot = o.bamFile.rfind('.');
+        std::string ext = dot == std::string::npos ? "" : o.bamFile.substr(dot + 1);
+        if (ext != "bam" && ext != "sam") { err = "bamqualcheck: the given path '" + o.bamFile + "' does not have one of the valid file extensions [*.-, *.bam, *.sam]"; return 1; }
+    }
+    // comma separated lists, parsed like the reference's stringstream loops (:121-143)
+    auto split_nums = [](const std::string& s, auto& out) {
+        size_t p = 0;
+        while (p < s.size()) {
+            char* end = nullptr;
+            long v = strtol(s.c_str() + p, &end, 10);
+            if (end == s.c_str() + p) break;
+            out.push_back((typename std::remove_reference<decltype(out)>::type::value_type)v);
+            p = (size_t)(end - s.c_str());
+            if (p < s.size() && s[p] == ',') ++p;
+        }
+    };
+    split_nums(kstr, o.klist);
+    split_nums(qstr, o.q_cutoff);
+    return 0;
+}
+
+struct BatchQueue { // decode thread -> submit thread
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<HostBatch>> q;
+    bool done = false;
+    int err_code = 0;
+    std::string err;
+};
+} // namespace
+
+extern "C" int bqc_main(int argc, const char** argv)
+{
+    ProgramOptions opt;
+    std::string perr;
+    const int pr = parse_args(argc, argv, opt, perr);
+    if (pr == 2) return 0;
+    if (pr == 1) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
+    if (opt.bamFile == "-" || (opt.bamFile.size() > 4 && opt.bamFile.substr(opt.bamFile.size() - 4) == ".sam")) {
+        fprintf(stderr, "ERROR: SAM input is not supported by this build (BAM only); could not open %s for reading.\n", opt.bamFile.c_str());
+        return 1;
+    }
+    BamReader rd;
+    std::string err;
+    if (!rd.open(opt.bamFile.c_str(), err)) {
+        fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
+        return 1;
+    }
+    FILE* of = fopen(opt.outputFile.c_str(), "wb"); // opened (truncated) before the scan, :278-283
+    if (!of) { fprintf(stderr, "ERROR: Could not open output file %s\n", opt.outputFile.c_str()); return 1; }
+    fclose(of);
+    const BamHeader& H = rd.header();
+    const uint32_t n_refs = (uint32_t)H.ref_names.size();
+    // initChroms (:106-123): names that are not BAM references are silently dropped
+    std::vector<uint8_t> main_chrom(std::max(1u, n_refs), 0);
+    {
+        size_t p = 0;
+        while (p <= opt.chroms.size()) {
+            size_t e = opt.chroms.find(',', p);
+            if (e == std::string::npos) e = opt.chroms.size();
+            const std::string name = opt.chroms.substr(p, e - p);
+            for (uint32_t r = 0; r < n_refs; ++r) if (H.ref_names[r] == name) { main_chrom[r] = 1; break; }
+            p = e + 1;
+        }
+    }
+    rd.set_main_chrom(main_chrom);
+    // reference genome: all contigs that are BAM references, FASTA order kept for the cursor rule
+    std::vector<FastaRecord> fa;
+    std::string ferr;
+    if (!load_fasta(opt.referenceFile.c_str(), &H.ref_names, fa, ferr)) fprintf(stderr, "%s\n", ferr.c_str()); // return value ignored (:291)
+    std::vector<int32_t> fasta_index(std::max(1u, n_refs), -1);
+    for (uint32_t r = 0; r < n_refs; ++r)
+        for (size_t i = 0; i < fa.size(); ++i) if (fa[i].name == H.ref_names[r]) { fasta_index[r] = (int32_t)i; break; }
+
+    if (H.lane_count == 0) { // no @RG: counts is empty; any record is an error, none means an empty output file
+        HostBatch hb;
+        int code = 0;
+        const int rc = rd.next_batch(hb, 1, 1 << 20, err, code);
+        if (rc != 0) { fprintf(stderr, "%s\n", rc < 0 ? err.c_str() : "ERROR: records present but the header has no @RG line"); return 1; }
+        return 0;
+    }
+    bqc_options bo;
+    memset(&bo, 0, sizeof bo);
+    bo.struct_size = sizeof bo;
+    bo.n_lanes = H.lane_count; bo.n_refs = n_refs; bo.isize = opt.isize;
+    bo.max_read_len = opt.max_read_len; bo.hist_cap = opt.hist_cap;
+    bo.main_chrom = main_chrom.data(); bo.fasta_index = fasta_index.data(); bo.device = opt.device;
+    if (!opt.no_sketch) {
+        bo.sketch.n_k = (uint32_t)opt.klist.size(); bo.sketch.klist = opt.klist.data();
+        bo.sketch.n_q = (uint32_t)opt.q_cutoff.size(); bo.sketch.qlist = opt.q_cutoff.data();
+        bo.sketch.e = opt.e; bo.sketch.seed = opt.seed;
+    }
+    bqc_ctx* ctx = nullptr;
+    int rc = bqc_create(&bo, &ctx);
+    if (rc) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(nullptr)); return 1; }
+    for (uint32_t r = 0; r < n_refs; ++r)
+        if (fasta_index[r] >= 0) {
+            const auto& c = fa[fasta_index[r]].codes;
+            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
+        }
+    fa.clear();
+    fa.shrink_to_fit();
+
+    // decode thread feeds batches; this thread submits them
+    BatchQueue Q;
+    std::thread dec([&]() {
+        for (;;) {
+            auto hb = std::make_unique<HostBatch>();
+            int code = 0;
+            std::string e;
+            const int r = rd.next_batch(*hb, opt.batch_reads, 256ull << 20, e, code);
+            std::unique_lock<std::mutex> lk(Q.m);
+            if (r < 0) { Q.err = e; Q.err_code = code; Q.done = true; Q.cv.notify_all(); return; }
+            if (r == 0) { Q.done = true; Q.cv.notify_all(); return; }
+            Q.cv.wait(lk, [&] { return Q.q.size() < 3; });
+            Q.q.push_back(std::move(hb));
+            Q.cv.notify_all();
+        }
+    });
+    int status = 0;
+    bool warned_qual = false;
+    for (;;) {
+        std::unique_ptr<HostBatch> hb;
+        {
+            std::unique_lock<std::mutex> lk(Q.m);
+            Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
+            if (Q.q.empty()) break;
+            hb = std::move(Q.q.front());
+            Q.q.pop_front();
+            Q.cv.notify_all();
+        }
+        if (status) continue; // drain
+        if (!warned_qual)
+            for (uint16_t f : hb->flag) if ((f & BQC_FLAG_NO_QUAL) && !(f & 0x900)) {
+                fprintf(stderr, "ERROR: length of sequence and quality is not the same\n"); // QualityCheck.hpp:73-77 (return value ignored)
+                warned_qual = true;
+                break;
+            }
+        const bqc_batch v = hb->view();
+        if ((rc = bqc_submit(ctx, &v))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
+    }
+    dec.join();
+    if (!status && Q.err_code) {
+        if (Q.err_code == BQC_ERR_IO) fprintf(stderr, "ERROR: Could not read record from BAM File %s\n", opt.bamFile.c_str()); // :308
+        else fprintf(Q.err == "Read does not have Z" ? stdout : stderr, "%s\n", Q.err.c_str());
+        status = 1;
+    }
+    if (status) { bqc_destroy(ctx); return 1; }
+    const bqc_counts* counts = nullptr;
+    if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
+    // writeOutput iterates laneNames (std::map: lexicographic), including IDs inserted by getLane
+    std::vector<const char*> names;
+    std::vector<uint32_t> idx;
+    for (auto& kv : rd.header().lane_names) { names.push_back(kv.first.c_str()); idx.push_back(kv.second); }
+    bqc_header_info hi;
+    hi.sample_id = rd.header().sample_id.c_str();
+    hi.n_names = (uint32_t)names.size();
+    hi.lane_names = names.data();
+    hi.lane_index = idx.data();
+    rc = bqc_write_bamqc(counts, &hi, opt.outputFile.c_str());
+    bqc_destroy(ctx);
+    if (rc) { fprintf(stderr, "ERROR: Could not write output file %s\n", opt.outputFile.c_str()); return 1; }
+    return 0;
+}

@@ -31,6 +31,36 @@ int bqc_synth_reference(uint64_t seed, int32_t rid, uint64_t len, uint8_t* out);
 int bqc_synth_batch(const bqc_synth_params* p, const uint8_t* const* refs, bqc_batch** out);
 void bqc_synth_batch_free(bqc_batch* b);
 
+/* Writes a coordinate-sorted synthetic BAM (+ FASTA when fasta_path != NULL) for the parameters:
+ * header with @SQ per contig and one @RG (ID:L<n>, SM:SYN) per lane; tags RG:Z, NM:i, AS:i. */
+int bqc_synth_write(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
+                    uint32_t batch_reads);
+
+/* ---- BAM / FASTA input (replaces SeqAn BamStream / SequenceStream) --------- */
+typedef struct bqc_bam bqc_bam;
+int bqc_bam_open(const char* path, bqc_bam** out);  /* on failure *out still holds the message */
+void bqc_bam_close(bqc_bam* b);
+const char* bqc_bam_error(const bqc_bam* b);
+uint32_t bqc_bam_n_refs(const bqc_bam* b);
+const char* bqc_bam_ref_name(const bqc_bam* b, uint32_t i);
+uint32_t bqc_bam_ref_len(const bqc_bam* b, uint32_t i);
+const char* bqc_bam_sample_id(const bqc_bam* b);      /* SM of the last @RG (bamqualcheck.cpp:58-61)        */
+uint32_t bqc_bam_lane_count(const bqc_bam* b);        /* number of @RG IDs in the header                    */
+uint32_t bqc_bam_n_lane_names(bqc_bam* b);            /* lane names in output (lexicographic) order,        */
+const char* bqc_bam_lane_name(const bqc_bam* b, uint32_t i); /* including IDs first seen on a read (:86)  */
+uint32_t bqc_bam_lane_index(const bqc_bam* b, uint32_t i);
+int bqc_bam_set_main_chrom(bqc_bam* b, const uint8_t* main_chrom); /* [n_refs], for BQC_FLAG_MATE_MAIN  */
+/* Next batch of decoded records: 1 = batch returned (owned by the reader until the next call),
+ * 0 = end of file, < 0 = -(BQC_ERR_*) with the message in bqc_bam_error. */
+int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_batch** out);
+
+/* Whole FASTA as Dna5 codes; ids cut at the first space/tab (TripletCounting.hpp:99-102). */
+int bqc_fasta_load(const char* path, uint32_t* n_records, char*** names, uint8_t*** codes, uint64_t** lens);
+void bqc_fasta_free(uint32_t n_records, char** names, uint8_t** codes, uint64_t* lens);
+
+/* ---- the program: drop-in for the reference's main() (bamqualcheck.cpp:239-457) ---- */
+int bqc_main(int argc, const char** argv);
+
 #ifdef __cplusplus
 }
 #endif

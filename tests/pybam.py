@@ -1,0 +1,79 @@
+"""Independent pure-Python BAM/FASTA decoding for tests (gzip handles concatenated BGZF members)."""
+import gzip
+import struct
+
+import numpy as np
+
+
+def read_bam(path):
+    data = gzip.open(path, "rb").read()
+    assert data[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    text = data[8:8 + l_text].decode()
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, p)[0]
+    p += 4
+    refs = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", data, p)[0]
+        name = data[p + 4:p + 4 + ln - 1].decode()
+        rl = struct.unpack_from("<i", data, p + 4 + ln)[0]
+        refs.append((name, rl))
+        p += 8 + ln
+    recs = []
+    while p < len(data):
+        bs = struct.unpack_from("<i", data, p)[0]
+        r = data[p + 4:p + 4 + bs]
+        rid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, rnext, pnext, tlen = struct.unpack_from("<iiBBHHHiiii", r, 0)
+        q = 32 + l_name
+        cigar = np.frombuffer(r, dtype="<u4", count=n_cig, offset=q).copy()
+        q += 4 * n_cig
+        seq = np.frombuffer(r, dtype=np.uint8, count=(l_seq + 1) // 2, offset=q).copy()
+        q += (l_seq + 1) // 2
+        qual = np.frombuffer(r, dtype=np.uint8, count=l_seq, offset=q).copy()
+        q += l_seq
+        tags = {}
+        while q < bs:
+            key = r[q:q + 2].decode()
+            ty = chr(r[q + 2])
+            q += 3
+            if ty in "cCA":
+                val = struct.unpack_from("<b" if ty == "c" else "<B", r, q)[0]
+                q += 1
+            elif ty in "sS":
+                val = struct.unpack_from("<h" if ty == "s" else "<H", r, q)[0]
+                q += 2
+            elif ty in "iI":
+                val = struct.unpack_from("<i" if ty == "i" else "<I", r, q)[0]
+                q += 4
+            elif ty == "f":
+                val = struct.unpack_from("<f", r, q)[0]
+                q += 4
+            elif ty in "ZH":
+                e = r.index(b"\0", q)
+                val = r[q:e].decode()
+                q = e + 1
+            else:
+                raise ValueError("tag type " + ty)
+            tags.setdefault(key, []).append((ty, val))
+        recs.append(dict(rid=rid, pos=pos, mapq=mapq, flag=flag, l_seq=l_seq, rnext=rnext, tlen=tlen, cigar=cigar, seq=seq,
+                         qual=qual, tags=tags, name=r[32:32 + l_name - 1].decode()))
+        p += 4 + bs
+    return text, refs, recs
+
+
+def read_fasta(path):
+    out = []
+    name, seq = None, []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if name is not None:
+                out.append((name, "".join(seq)))
+            name = line[1:].split(" ")[0].split("\t")[0]
+            seq = []
+        else:
+            seq.append(line)
+    if name is not None:
+        out.append((name, "".join(seq)))
+    return out

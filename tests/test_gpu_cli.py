@@ -1,0 +1,58 @@
+"""GPU: the `bamqualcheck` program end to end (BAM + FASTA in, `.bamqc` out) against the oracle."""
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+from bamqc_amd import hostio
+from tests.cli_oracle import oracle_bamqualcheck
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bin", "bamqualcheck")
+
+
+def run_cli(*args):
+    return subprocess.run([EXE] + list(args), capture_output=True, text=True)
+
+
+def test_config1_10k_reads_bytes_identical(tmp_path):
+    # BASELINE.json configs[0]: 10k-read 150 bp PE synthetic BAM vs 1 Mb FASTA, -c chr1
+    bam, fa = str(tmp_path / "c1.bam"), str(tmp_path / "c1.fa")
+    hostio.synth_write(bam, fa, seed=1001, n_reads=10_000, ref_names=["chr1"], ref_lens=[1_000_000])
+    got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
+    r = run_cli("-r", fa, "-o", got, "-c", "chr1", "--no-sketch", bam)
+    assert r.returncode == 0, r.stderr
+    assert oracle_bamqualcheck(bam, fa, want, chroms="chr1", klist=(), qlist=()) == 0
+    assert filecmp.cmp(got, want, shallow=False)
+    txt = open(got).read()
+    assert txt.startswith("sample_id SYN\nlane L1\ntotal_read_pairs ") and "triplet_counts_T_2nd_RC" in txt
+
+
+def test_multi_lane_default_chroms_small_batches(tmp_path):
+    bam, fa = str(tmp_path / "m.bam"), str(tmp_path / "m.fa")
+    names = ["chr1", "chr2", "chrX", "chrUn_1"]
+    hostio.synth_write(bam, fa, seed=7, n_reads=30_000, ref_names=names, ref_lens=[400_000, 300_000, 200_000, 50_000], n_lanes=3)
+    got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
+    r = run_cli("--reference", fa, "--output-file=" + got, "-i", "500", "--batch-reads", "7001", "--no-sketch", bam)
+    assert r.returncode == 0, r.stderr
+    assert oracle_bamqualcheck(bam, fa, want, isize=500, klist=(), qlist=(), batch_reads=4000) == 0
+    assert filecmp.cmp(got, want, shallow=False)
+    assert open(got).read().count("sample_id SYN") == 3
+
+
+def test_fasta_missing_is_fatal_only_when_needed(tmp_path):
+    bam, fa = str(tmp_path / "f.bam"), str(tmp_path / "f.fa")
+    hostio.synth_write(bam, fa, seed=9, n_reads=2000, ref_names=["chr1"], ref_lens=[200_000])
+    out = str(tmp_path / "o.bamqc")
+    r = run_cli("-r", str(tmp_path / "nope.fa"), "-o", out, "-c", "chr1", "--no-sketch", bam)
+    assert r.returncode == 1 and "Could not open fasta file" in r.stderr
+    assert os.path.getsize(out) == 0  # output is opened (truncated) before the scan and left empty
+
+
+def test_output_dir_missing(tmp_path):
+    bam, fa = str(tmp_path / "f.bam"), str(tmp_path / "f.fa")
+    hostio.synth_write(bam, fa, seed=9, n_reads=100, ref_names=["chr1"], ref_lens=[100_000])
+    r = run_cli("-r", fa, "-o", str(tmp_path / "no" / "dir" / "o.bamqc"), bam)
+    assert r.returncode == 1 and "Could not open output file" in r.stderr
