@@ -54,6 +54,7 @@ _SIGNATURES = {
     "bqc_bam_lane_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "bqc_bam_lane_index": (C.c_uint32, [C.c_void_p, C.c_uint32]),
     "bqc_bam_set_main_chrom": (C.c_int, [C.c_void_p, _abi.u8p]),
+    "bqc_bam_set_rid_filter": (C.c_int, [C.c_void_p, _abi.u8p, C.c_int]),
     "bqc_bam_next": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(_abi.Batch))]),
     "bqc_fasta_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_char_p)),
                                  C.POINTER(C.POINTER(_abi.u8p)), C.POINTER(_abi.u64p)]),

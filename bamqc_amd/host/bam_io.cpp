@@ -116,6 +116,10 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         const int32_t rnext = (int32_t)rd32(r + 20), tlen = (int32_t)rd32(r + 28);
         const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
         if (var > bs) { err = "corrupt BAM record"; err_code = BQC_ERR_IO; return -1; }
+        if (filter_) {
+            const bool keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
+            if (!keep) { cur_ += 4 + (size_t)bs; ++nrec_; continue; }
+        }
         const uint8_t* cig = r + 32 + l_name;
         const uint8_t* sq = cig + 4ull * n_cig;
         const uint8_t* ql = sq + (l_seq + 1) / 2;

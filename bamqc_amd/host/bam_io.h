@@ -37,6 +37,9 @@ public:
     const BamHeader& header() const { return hdr_; }
     BamHeader& header() { return hdr_; }
     void set_main_chrom(const std::vector<uint8_t>& mc) { main_ = mc; }
+    // keep only records whose refID is selected (keep[rid] != 0; refID -1 follows keep_unplaced): used to shard
+    // a coordinate-sorted BAM by chromosome across ranks
+    void set_rid_filter(const std::vector<uint8_t>& keep, bool keep_unplaced) { keep_ = keep; keep_unplaced_ = keep_unplaced; filter_ = true; }
     // Decodes up to max_reads records (and at most max_bases bases) into `out`.
     // Returns 1 = batch filled (maybe partially, more may follow), 0 = end of file and nothing read,
     // -1 = error (err set; code in err_code: BQC_ERR_IO for a corrupt file, BQC_ERR_ARG for the RG-tag rule).
@@ -50,7 +53,8 @@ private:
     std::vector<uint8_t> buf_, chunk_;
     size_t cur_ = 0;
     bool eof_ = false;
-    std::vector<uint8_t> main_;
+    std::vector<uint8_t> main_, keep_;
+    bool filter_ = false, keep_unplaced_ = true;
     uint64_t nrec_ = 0;
 };
 

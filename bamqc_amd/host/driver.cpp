@@ -123,6 +123,12 @@ extern "C" int bqc_bam_set_main_chrom(bqc_bam* b, const uint8_t* mc)
     b->rd.set_main_chrom(std::vector<uint8_t>(mc, mc + b->rd.header().ref_names.size()));
     return 0;
 }
+extern "C" int bqc_bam_set_rid_filter(bqc_bam* b, const uint8_t* keep, int keep_unplaced)
+{
+    if (!b || !keep) return BQC_ERR_ARG;
+    b->rd.set_rid_filter(std::vector<uint8_t>(keep, keep + b->rd.header().ref_names.size()), keep_unplaced != 0);
+    return 0;
+}
 extern "C" int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_batch** out)
 {
     if (!b || !out) return -BQC_ERR_ARG;

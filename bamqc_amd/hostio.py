@@ -55,6 +55,11 @@ class BamFile:
         assert len(a) == len(self.ref_names)
         self.lib.bqc_bam_set_main_chrom(self.h, a.ctypes.data_as(_abi.u8p))
 
+    def set_rid_filter(self, keep, keep_unplaced):
+        a = np.ascontiguousarray(keep, np.uint8)
+        assert len(a) == len(self.ref_names)
+        self.lib.bqc_bam_set_rid_filter(self.h, a.ctypes.data_as(_abi.u8p), 1 if keep_unplaced else 0)
+
     def batches(self, max_reads=1 << 20, max_bases=1 << 28):
         while True:
             p = C.POINTER(_abi.Batch)()

@@ -50,6 +50,9 @@ uint32_t bqc_bam_n_lane_names(bqc_bam* b);            /* lane names in output (l
 const char* bqc_bam_lane_name(const bqc_bam* b, uint32_t i); /* including IDs first seen on a read (:86)  */
 uint32_t bqc_bam_lane_index(const bqc_bam* b, uint32_t i);
 int bqc_bam_set_main_chrom(bqc_bam* b, const uint8_t* main_chrom); /* [n_refs], for BQC_FLAG_MATE_MAIN  */
+/* Keep only records whose refID is selected (refID -1 follows keep_unplaced): lets each rank of a
+ * multi-GPU run take whole chromosomes of a coordinate-sorted BAM. */
+int bqc_bam_set_rid_filter(bqc_bam* b, const uint8_t* keep, int keep_unplaced);
 /* Next batch of decoded records: 1 = batch returned (owned by the reader until the next call),
  * 0 = end of file, < 0 = -(BQC_ERR_*) with the message in bqc_bam_error. */
 int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_batch** out);
