@@ -1,0 +1,458 @@
+// sketch.hip — k-mer sketch on the GPU: ReadQualityHasher::operator()
+// (reference src/ReadQualityHasher.hpp:30-68) feeding RepHash (src/kmerstream/RepHash.hpp:28-122,
+// seeded as RepHash.cpp:4-17) and StreamCounter (src/kmerstream/StreamCounter.hpp:23-356).
+//
+// Thread per read walks the read in sequencing orientation (reverse strand: index L-1-j, complemented
+// char), keeps the 128-bit cyclic-polynomial state of both strands in registers and emits
+// hash = h.lo ^ ht.lo for every window of k consecutive valid bases.  StreamCounter state is a
+// commutative monoid (StreamCounter::join :95-112), so per hash we do: sumCount (ballot), F2 table
+// (exact counts, privatised in LDS as u32, 32768 bins), and the level-w 4-bit saturating counter as
+// a u32 global counter that is only incremented while its value is < 15 (value = min(15, raw)).
+// Levels whose 524288 counters are all saturated are skipped entirely (the reference's M[w] early-out,
+// StreamCounter.hpp:81-83), which removes almost all global traffic on large inputs.
+// Estimators F0 / f1 / F2 (doubles, log/pow) run on the host exactly as the reference's.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "kernels_common.h"
+#include "sketch.h"
+
+namespace {
+struct u128 { uint64_t hi, lo; };
+
+// ---- host: MT19937 seeding of the character table (mersennetwister.h:194-208,298-329; RepHash.cpp:4-17)
+struct MT {
+    uint32_t st[624];
+    int next = 0, left = 0;
+    explicit MT(uint32_t seed)
+    {
+        st[0] = seed;
+        for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
+    }
+    static uint32_t twist(uint32_t m, uint32_t s0, uint32_t s1)
+    {
+        return m ^ (((s0 & 0x80000000u) | (s1 & 0x7fffffffu)) >> 1) ^ ((uint32_t)(-(int32_t)(s1 & 1u)) & 0x9908b0dfu);
+    }
+    void reload()
+    {
+        uint32_t* p = st;
+        int i;
+        for (i = 624 - 397; i--; ++p) *p = twist(p[397], p[0], p[1]);
+        for (i = 397; --i; ++p) *p = twist(p[397 - 624], p[0], p[1]);
+        *p = twist(p[397 - 624], p[0], st[0]);
+        left = 624; next = 0;
+    }
+    uint32_t rand_int()
+    {
+        if (left == 0) reload();
+        --left;
+        uint32_t s1 = st[next++];
+        s1 ^= (s1 >> 11);
+        s1 ^= (s1 << 7) & 0x9d2c5680u;
+        s1 ^= (s1 << 15) & 0xefc60000u;
+        return s1 ^ (s1 >> 18);
+    }
+};
+
+size_t round_up_pow2(size_t size)
+{
+    size--;
+    size |= size >> 1; size |= size >> 2; size |= size >> 4; size |= size >> 8; size |= size >> 16; size |= size >> 32;
+    return size + 1;
+}
+
+const unsigned char kTwin[32] = {0, 20, 2, 7, 4, 5, 6, 3, 8, 9, 10, 11, 12, 13, 14, 15,
+                                 16, 17, 18, 19, 1, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31}; // RepHash.hpp:8-13
+// nibble -> (char & 31) for "=ACMGRSVTWYHKDBN" and for the complemented character (reverse strand)
+const unsigned char kIdxFwd[16] = {29, 1, 3, 13, 7, 18, 19, 22, 20, 23, 25, 8, 11, 4, 2, 14};
+const unsigned char kIdxRc[16] = {29, 20, 7, 11, 3, 25, 19, 2, 1, 23, 18, 4, 13, 8, 22, 14};
+
+struct PairParams { // one (q, k) sketch
+    uint32_t k, q;
+    int32_t q_thr;      // (signed char)(33 + q): base valid iff (signed char)(phred + 33) >= q_thr
+    uint32_t f2_mask;   // F2size - 1
+    uint32_t ctr_mask;  // size*16 - 1
+    uint32_t levels;    // MAX_TABLE = 32
+    uint64_t ctr_per_level;
+};
+
+struct DevSketch { // device pointers of one (lane, pair)
+    uint32_t* counters; // [levels][ctr_per_level] raw counts (value = min(15, raw))
+    uint64_t* f2;       // [F2size]
+    uint64_t* misc;     // [0] sumCount, [1..32] M[w] = successful increments, [40] saturated-level mask
+};
+} // namespace
+
+struct SketchDevice {
+    bqc_sketch_options so{};
+    std::vector<int32_t> ks;
+    std::vector<uint32_t> qs;
+    uint32_t n_lanes = 0, n_pairs = 0;
+    size_t ctr_per_level = 0, f2size = 0;
+    std::vector<PairParams> pp;
+    std::vector<DevSketch> ds; // [lane][pair]
+    DevSketch* d_ds = nullptr;
+    PairParams* d_pp = nullptr;
+    uint4* d_hv = nullptr; // [pair][2][32]: hvals and rotl_k(hvals) as (hi.x hi.y lo.x lo.y) -> stored as two u64 {hi, lo}
+    uint8_t* d_idx = nullptr; // [2][16] nibble -> char&31, twin table [32]
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<uint8_t> h_ctr; // finalize scratch
+};
+
+// ---------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rotl1_128(uint64_t& hi, uint64_t& lo)
+{
+    const uint64_t nh = (hi << 1) | (lo >> 63), nl = (lo << 1) | (hi >> 63);
+    hi = nh; lo = nl;
+}
+__device__ __forceinline__ void rotr1_128(uint64_t& hi, uint64_t& lo)
+{
+    const uint64_t nh = (hi >> 1) | (lo << 63), nl = (lo >> 1) | (hi << 63);
+    hi = nh; lo = nl;
+}
+__device__ __forceinline__ void rotl_128(uint64_t& hi, uint64_t& lo, uint32_t t) // 0 <= t < 64
+{
+    if (t == 0) return;
+    const uint64_t nh = (hi << t) | (lo >> (64 - t)), nl = (lo << t) | (hi >> (64 - t));
+    hi = nh; lo = nl;
+}
+
+#define SK_F2 32768
+#define SK_THREADS 1024
+
+__global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps,
+                                                          const uint64_t* __restrict__ hv_all, const uint8_t* __restrict__ idx_tab,
+                                                          uint32_t n_pairs, uint32_t per_block)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t* f2 = lds;                                   // [SK_F2]
+    uint64_t* hv = (uint64_t*)(lds + SK_F2);              // [2][32][2]: table, table rotated by k
+    uint32_t* lm = lds + SK_F2 + 256;                     // [32] successful increments per level, [32] = sumCount
+    uint8_t* ix = (uint8_t*)(lds + SK_F2 + 256 + 64);     // [2][16] nibble -> idx, [32] twin
+    const uint32_t pair = blockIdx.y;
+    const PairParams P = pps[pair];
+    for (uint32_t i = threadIdx.x; i < SK_F2; i += blockDim.x) f2[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) hv[i] = hv_all[pair * 128 + i];
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) lm[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) ix[i] = idx_tab[i];
+    __syncthreads();
+    const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_reads, lo_r + per_block);
+    uint32_t blane = 0xFFFFFFFFu;
+    uint32_t& s_lane = lm[63]; // (no static __shared__: it would mis-align the dynamic LDS base)
+    uint64_t sat_mask = 0;
+    for (uint32_t base = lo_r; base < hi_r; base += blockDim.x) {
+        const uint32_t kk = base + threadIdx.x;
+        const bool live = kk < hi_r;
+        const uint32_t r = live ? (b.perm ? b.perm[kk] : kk) : 0;
+        const uint32_t lane = live ? b.lane[r] : 0;
+        if (threadIdx.x == 0) s_lane = lane;
+        __syncthreads();
+        const uint32_t fl = s_lane;
+        if (fl != blane) { // block-uniform: flush the privatised F2 / M counters of the previous lane
+            if (blane != 0xFFFFFFFFu) {
+                const DevSketch D = dsk[blane * n_pairs + pair];
+                for (uint32_t i = threadIdx.x; i < SK_F2; i += blockDim.x) { const uint32_t v = f2[i]; if (v) { gadd(D.f2 + i, v); f2[i] = 0; } }
+                if (threadIdx.x < 33) { const uint32_t v = lm[threadIdx.x]; if (v) { gadd(D.misc + (threadIdx.x == 32 ? 0 : 1 + threadIdx.x), v); lm[threadIdx.x] = 0; } }
+            }
+            blane = fl;
+            sat_mask = dsk[blane * n_pairs + pair].misc[40];
+            __syncthreads();
+        }
+        const DevSketch D = dsk[lane * n_pairs + pair];
+        const bool mine = live && lane == blane; // reads of another lane inside a mixed block use global memory only
+        uint32_t flag = live ? b.flag[r] : 0x900u;
+        const uint32_t L = live ? b.l_seq[r] : 0;
+        // RunBamStream only for !QCfail && !dup primary records (bamqualcheck.cpp:439-442); needs first/last like every
+        // record that reaches that line; DEFINED: records without qualities are skipped
+        const bool run = live && !(flag & 0x900) && !(flag & 0x600) && (flag & 0xC0) && !(flag & BQC_FLAG_NO_QUAL) && L >= P.k;
+        if (run) {
+            const bool rc = flag & 0x10;
+            const uint8_t* __restrict__ sq = b.seq + b.seq_off[r];
+            const uint8_t* __restrict__ ql = b.qual + b.qual_off[r];
+            const uint8_t* nidx = ix + (rc ? 16 : 0);
+            const uint8_t* tw = ix + 32;
+            uint64_t hh = 0, hl = 0, th = 0, tl = 0;
+            uint32_t t = 0; // number of consecutive valid bases ending at the current one
+            uint32_t n_hash = 0;
+            for (uint32_t j = 0; j < L; ++j) {
+                const uint32_t i = rc ? L - 1 - j : j;
+                const uint32_t by = sq[i >> 1];
+                const uint32_t nib = (i & 1u) ? (by & 15u) : (by >> 4);
+                const int32_t qc = (int32_t)(int8_t)(uint8_t)(ql[i] + 33u);
+                if (nib == 15u || qc < P.q_thr) { t = 0; continue; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
+                const uint32_t c = nidx[nib];
+                if (t < P.k) { // RepHash::init(const char*) built incrementally, :85-97
+                    if (t == 0) { hh = hl = th = tl = 0; }
+                    rotl1_128(hh, hl);
+                    hh ^= hv[2 * c]; hl ^= hv[2 * c + 1];
+                    uint64_t xh = hv[2 * tw[c]], xl = hv[2 * tw[c] + 1];
+                    rotl_128(xh, xl, t); // reverse-strand hash: sum_u rotl^u(hvals[twin[s_u]])
+                    th ^= xh; tl ^= xl;
+                    ++t;
+                    if (t < P.k) continue;
+                } else { // RepHash::update(out, in), :99-113
+                    const uint32_t jo = j - P.k, io = rc ? L - 1 - jo : jo;
+                    const uint32_t bo = sq[io >> 1];
+                    const uint32_t co = nidx[(io & 1u) ? (bo & 15u) : (bo >> 4)];
+                    rotl1_128(hh, hl);
+                    hh ^= hv[64 + 2 * co] ^ hv[2 * c];         // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
+                    hl ^= hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
+                    th ^= hv[2 * tw[co]] ^ hv[64 + 2 * tw[c]]; // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
+                    tl ^= hv[2 * tw[co] + 1] ^ hv[64 + 2 * tw[c] + 1];
+                    rotr1_128(th, tl);
+                }
+                // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
+                const uint64_t hash = hl ^ tl;
+                ++n_hash;
+                if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
+                else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
+                uint32_t w = hash ? (uint32_t)__ffsll((unsigned long long)hash) - 1u : 63u; // bitScanForward (lsb.cpp:26-29)
+                if (w >= P.levels) w = P.levels - 1;
+                if (mine && ((sat_mask >> w) & 1ull)) continue; // M[w] == size*countsPerLong*maxVal: every counter is 15
+                const uint64_t index = (hash >> (w + 1)) & (uint64_t)P.ctr_mask;
+                uint32_t* ctr = D.counters + (uint64_t)w * P.ctr_per_level + index;
+                if (*(volatile uint32_t*)ctr < 15u) {
+                    const uint32_t old = atomicAdd(ctr, 1u);
+                    if (old < 15u) { if (mine) atomicAdd(&lm[w], 1u); else gadd(D.misc + 1 + w, 1); }
+                }
+            }
+            if (mine) atomicAdd(&lm[32], n_hash); else if (n_hash) gadd(D.misc, n_hash);
+        }
+        __syncthreads();
+    }
+    if (blane != 0xFFFFFFFFu) {
+        const DevSketch D = dsk[blane * n_pairs + pair];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < SK_F2; i += blockDim.x) { const uint32_t v = f2[i]; if (v) gadd(D.f2 + i, v); }
+        if (threadIdx.x < 33) { const uint32_t v = lm[threadIdx.x]; if (v) gadd(D.misc + (threadIdx.x == 32 ? 0 : 1 + threadIdx.x), v); }
+    }
+}
+
+// after every batch: levels whose successful-increment count reached 15 * counters are fully saturated
+__global__ void k_sketch_levels(const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps, uint32_t n_pairs, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevSketch D = dsk[i];
+    const PairParams P = pps[i % n_pairs];
+    uint64_t m = 0;
+    for (uint32_t w = 0; w < P.levels; ++w)
+        if (D.misc[1 + w] >= 15ull * P.ctr_per_level) m |= 1ull << w;
+    D.misc[40] = m;
+}
+
+// state vector <-> device tables: [sumCount][F2 table][counters as saturated bytes, 8 per word]
+__global__ void k_sketch_export(DevSketch D, uint64_t* __restrict__ dst, uint64_t f2size, uint64_t n_ctr)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) dst[0] = D.misc[0];
+    if (i < f2size) dst[1 + i] = D.f2[i];
+    if (i < n_ctr / 8) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; ++k) { const uint32_t v = D.counters[i * 8 + k]; w |= (uint64_t)(v > 15u ? 15u : v) << (8 * k); }
+        dst[1 + f2size + i] = w;
+    }
+}
+__global__ void k_sketch_import(DevSketch D, const uint64_t* __restrict__ src, uint64_t f2size, uint64_t n_ctr, uint64_t ctr_per_level)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) D.misc[0] = src[0];
+    if (i < f2size) D.f2[i] = src[1 + i];
+    if (i < n_ctr / 8) {
+        const uint64_t w = src[1 + f2size + i];
+        for (int k = 0; k < 8; ++k) D.counters[i * 8 + k] = (uint32_t)((w >> (8 * k)) & 255u); // sums of per-rank min(15, .) ; clamped on use
+    }
+    if (i < 32) D.misc[1 + i] = 0; // successful-increment counts are not part of the vector: recomputed lazily (levels stay enabled)
+    if (i == 0) D.misc[40] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------
+SketchDevice* sketch_create(const bqc_sketch_options& so, uint32_t n_lanes, hipStream_t s, std::string& err)
+{
+    if (so.seed == 0) { err = "seed 0 (time based) is not reproducible; pass -s <nonzero>"; return nullptr; }
+    if (!(so.e > 0)) { err = "error rate must be > 0"; return nullptr; }
+    auto* sk = new SketchDevice();
+    sk->so = so;
+    sk->ks.assign(so.klist, so.klist + so.n_k);
+    sk->qs.assign(so.qlist, so.qlist + so.n_q);
+    for (int k : sk->ks) if (k < 1 || k > 63) { err = "k must be in 1..63"; delete sk; return nullptr; }
+    sk->n_lanes = n_lanes;
+    sk->n_pairs = so.n_q * so.n_k;
+    // StreamCounter ctor, StreamCounter.hpp:25-46
+    size_t numcounts = (size_t)(48.0 / (so.e * so.e) + 1);
+    sk->f2size = round_up_pow2((size_t)(2.0 / (so.e * so.e) + 1));
+    if (numcounts < 8192) numcounts = 8192;
+    size_t size = round_up_pow2((numcounts + 15) / 16);
+    sk->ctr_per_level = size * 16;
+    if (sk->f2size != SK_F2) { err = "only error rates with a 32768-entry F2 table (e.g. the default 0.01) are supported on the GPU"; delete sk; return nullptr; }
+    // character tables
+    std::vector<uint64_t> hv((size_t)sk->n_pairs * 128);
+    MT mt((uint32_t)so.seed);
+    u128 base[32];
+    for (int i = 0; i < 32; ++i) { // (randInt()<<32)|randInt(): g++ evaluates the left operand first (pinned in tests)
+        uint64_t a = mt.rand_int(), b = mt.rand_int(), c = mt.rand_int(), d = mt.rand_int();
+        base[i].hi = (a << 32) | b;
+        base[i].lo = (c << 32) | d;
+    }
+    for (uint32_t qi = 0; qi < so.n_q; ++qi)
+        for (uint32_t ki = 0; ki < so.n_k; ++ki) {
+            const uint32_t p = qi * so.n_k + ki, k = (uint32_t)sk->ks[ki];
+            PairParams P{};
+            P.k = k; P.q = sk->qs[qi];
+            P.q_thr = (int32_t)(int8_t)(uint8_t)(33u + P.q);
+            P.f2_mask = (uint32_t)sk->f2size - 1; P.ctr_mask = (uint32_t)sk->ctr_per_level - 1; P.levels = 32;
+            P.ctr_per_level = sk->ctr_per_level;
+            sk->pp.push_back(P);
+            for (int i = 0; i < 32; ++i) {
+                hv[p * 128 + 2 * i] = base[i].hi; hv[p * 128 + 2 * i + 1] = base[i].lo;
+                const uint64_t h = base[i].hi, l = base[i].lo; // fastleftshiftk, RepHash.hpp:56-60
+                hv[p * 128 + 64 + 2 * i] = (h << k) | (l >> (64 - k));
+                hv[p * 128 + 64 + 2 * i + 1] = (l << k) | (h >> (64 - k));
+            }
+        }
+    uint8_t idx[64];
+    memcpy(idx, kIdxFwd, 16); memcpy(idx + 16, kIdxRc, 16); memcpy(idx + 32, kTwin, 32);
+    // one arena: per (lane, pair): counters u32[32*ctr], f2 u64[f2size], misc u64[64]
+    const size_t per = sk->ctr_per_level * 32 * 4 + sk->f2size * 8 + 64 * 8;
+    const size_t n = (size_t)n_lanes * sk->n_pairs;
+    sk->arena_bytes = per * n + hv.size() * 8 + 64 + sizeof(DevSketch) * n + sizeof(PairParams) * sk->n_pairs + 4096;
+    if (hipMalloc(&sk->arena, sk->arena_bytes) != hipSuccess) { err = "hipMalloc failed for the sketch tables"; delete sk; return nullptr; }
+    char* p = (char*)sk->arena;
+    (void)hipMemsetAsync(sk->arena, 0, sk->arena_bytes, s);
+    for (size_t i = 0; i < n; ++i) {
+        DevSketch d;
+        d.counters = (uint32_t*)p; p += sk->ctr_per_level * 32 * 4;
+        d.f2 = (uint64_t*)p; p += sk->f2size * 8;
+        d.misc = (uint64_t*)p; p += 64 * 8;
+        sk->ds.push_back(d);
+    }
+    sk->d_hv = (uint4*)p; p += hv.size() * 8;
+    sk->d_idx = (uint8_t*)p; p += 64;
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    sk->d_ds = (DevSketch*)p; p += sizeof(DevSketch) * n;
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    sk->d_pp = (PairParams*)p;
+    (void)hipStreamSynchronize(s);
+    bool ok = hipMemcpy(sk->d_hv, hv.data(), hv.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(sk->d_idx, idx, 64, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(sk->d_ds, sk->ds.data(), sizeof(DevSketch) * n, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(sk->d_pp, sk->pp.data(), sizeof(PairParams) * sk->n_pairs, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sketch), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (SK_F2 + 256 + 64 + 16) * 4) == hipSuccess;
+    if (!ok) { err = "sketch table upload failed"; sketch_destroy(sk); return nullptr; }
+    return sk;
+}
+
+void sketch_destroy(SketchDevice* sk)
+{
+    if (!sk) return;
+    (void)hipFree(sk->arena);
+    delete sk;
+}
+
+void sketch_reset(SketchDevice* sk, hipStream_t s)
+{
+    const size_t per = sk->ctr_per_level * 32 * 4 + sk->f2size * 8 + 64 * 8;
+    (void)hipMemsetAsync(sk->arena, 0, per * sk->n_lanes * sk->n_pairs, s);
+}
+
+void sketch_process(SketchDevice* sk, const DevBatch& b, hipStream_t s)
+{
+    if (b.n_reads == 0) return;
+    uint32_t grid = 256;
+    uint32_t per = (b.n_reads + grid - 1) / grid;
+    per = ((per + SK_THREADS - 1) / SK_THREADS) * SK_THREADS;
+    grid = (b.n_reads + per - 1) / per;
+    hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), (SK_F2 + 256 + 64 + 16) * 4, s, b, sk->d_ds, sk->d_pp,
+                       (const uint64_t*)sk->d_hv, sk->d_idx, sk->n_pairs, per);
+    const uint32_t n = sk->n_lanes * sk->n_pairs;
+    hipLaunchKernelGGL(k_sketch_levels, dim3((n + 63) / 64), dim3(64), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs, n);
+}
+
+static uint64_t words_per_sketch(const SketchDevice* sk) { return 1 + sk->f2size + sk->ctr_per_level * 32 / 8; }
+uint64_t sketch_state_words(const SketchDevice* sk) { return words_per_sketch(sk) * sk->n_lanes * sk->n_pairs; }
+
+void sketch_state_export(SketchDevice* sk, uint64_t* dst, hipStream_t s)
+{
+    const uint64_t n_ctr = sk->ctr_per_level * 32, wps = words_per_sketch(sk);
+    const uint32_t blocks = (uint32_t)((std::max<uint64_t>(n_ctr / 8, sk->f2size) + 255) / 256);
+    for (size_t i = 0; i < sk->ds.size(); ++i)
+        hipLaunchKernelGGL(k_sketch_export, dim3(blocks), dim3(256), 0, s, sk->ds[i], dst + i * wps, (uint64_t)sk->f2size, n_ctr);
+}
+void sketch_state_import(SketchDevice* sk, const uint64_t* src, hipStream_t s)
+{
+    const uint64_t n_ctr = sk->ctr_per_level * 32, wps = words_per_sketch(sk);
+    const uint32_t blocks = (uint32_t)((std::max<uint64_t>(n_ctr / 8, sk->f2size) + 255) / 256);
+    for (size_t i = 0; i < sk->ds.size(); ++i)
+        hipLaunchKernelGGL(k_sketch_import, dim3(blocks), dim3(256), 0, s, sk->ds[i], src + i * wps, (uint64_t)sk->f2size, n_ctr,
+                           (uint64_t)sk->ctr_per_level);
+}
+
+bool sketch_finalize(SketchDevice* sk, uint32_t lane, std::vector<bqc_sketch_counts>& out, hipStream_t s, std::string& err)
+{
+    out.clear();
+    const size_t R = sk->ctr_per_level, n_ctr = R * 32;
+    std::vector<uint32_t> raw(n_ctr);
+    std::vector<uint64_t> f2(sk->f2size);
+    for (uint32_t p = 0; p < sk->n_pairs; ++p) {
+        const DevSketch& D = sk->ds[(size_t)lane * sk->n_pairs + p];
+        uint64_t sum_count = 0;
+        (void)hipStreamSynchronize(s);
+        if (hipMemcpy(raw.data(), D.counters, n_ctr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(f2.data(), D.f2, sk->f2size * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&sum_count, D.misc, 8, hipMemcpyDeviceToHost) != hipSuccess) { err = "device copy failed"; return false; }
+        bqc_sketch_counts c{};
+        c.q = sk->pp[p].q; c.k = sk->pp[p].k; c.sumCount = sum_count;
+        // per level: number of counters > 0, == 0, == 1 (value = min(15, raw))
+        std::vector<size_t> nz(32, 0), r0(32, 0), r1(32, 0);
+        for (size_t w = 0; w < 32; ++w) {
+            const uint32_t* t = raw.data() + w * R;
+            size_t a = 0, b1 = 0;
+            for (size_t j = 0; j < R; ++j) { a += t[j] == 0; b1 += t[j] == 1; }
+            r0[w] = a; r1[w] = b1; nz[w] = R - a;
+        }
+        { // F0, StreamCounter.hpp:114-140
+            double sum = 0; int n = 0; double limit = 0.2;
+            while (n == 0 && limit > 1e-8) {
+                for (size_t i = 0; i < 32; i++) {
+                    const size_t ts = nz[i];
+                    if (ts <= (1 - limit) * R && ts >= limit * R) {
+                        double est = (log(1.0 - ts / ((double)R)) / log(1.0 - 1.0 / R)) * pow(2.0, i + 1);
+                        sum += est; n++;
+                        break;
+                    }
+                }
+                limit = limit / 1.5;
+            }
+            c.F0 = n ? (size_t)(sum / n) : 9223372036854775808ull; // (size_t)NaN as the reference's g++ build yields it
+        }
+        { // f1, :142-172
+            double sum = 0; int n = 0; double limit = 0.2;
+            while (n == 0 && limit > 1e-8) {
+                for (size_t i = 0; i < 32; i++) {
+                    if ((r0[i] <= (1 - limit) * R) && (r0[i] >= limit * R)) {
+                        sum += (R - 1) * (r1[i] / ((double)r0[i])) * pow(2.0, i + 1);
+                        n++;
+                        break;
+                    }
+                }
+                limit = limit / 1.5;
+            }
+            c.f1 = n ? (size_t)(sum / n) : 9223372036854775808ull;
+        }
+        { // F2, :308-317
+            double sum = 0, sqsum = 0;
+            for (size_t i = 0; i < sk->f2size; i++) { double v = (double)f2[i]; sum += v; sqsum += v * v; }
+            c.F2 = (size_t)(sqsum + (sqsum - sum * sum) / sk->f2size);
+        }
+        out.push_back(c);
+    }
+    return true;
+}
