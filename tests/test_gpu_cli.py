@@ -22,10 +22,11 @@ def test_config1_10k_reads_bytes_identical(tmp_path):
     bam, fa = str(tmp_path / "c1.bam"), str(tmp_path / "c1.fa")
     hostio.synth_write(bam, fa, seed=1001, n_reads=10_000, ref_names=["chr1"], ref_lens=[1_000_000])
     got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
-    r = run_cli("-r", fa, "-o", got, "-c", "chr1", "--no-sketch", bam)
+    r = run_cli("-r", fa, "-o", got, "-c", "chr1", bam)  # default -k 32 -q 17 -e 0.01 -s 1: sketch lines included
     assert r.returncode == 0, r.stderr
-    assert oracle_bamqualcheck(bam, fa, want, chroms="chr1", klist=(), qlist=()) == 0
+    assert oracle_bamqualcheck(bam, fa, want, chroms="chr1") == 0
     assert filecmp.cmp(got, want, shallow=False)
+    assert filecmp.cmp(got, os.path.join(ROOT, "tests", "golden", "config1.bamqc"), shallow=False)  # committed fixture
     txt = open(got).read()
     assert txt.startswith("sample_id SYN\nlane L1\ntotal_read_pairs ") and "triplet_counts_T_2nd_RC" in txt
 
@@ -35,9 +36,9 @@ def test_multi_lane_default_chroms_small_batches(tmp_path):
     names = ["chr1", "chr2", "chrX", "chrUn_1"]
     hostio.synth_write(bam, fa, seed=7, n_reads=30_000, ref_names=names, ref_lens=[400_000, 300_000, 200_000, 50_000], n_lanes=3)
     got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
-    r = run_cli("--reference", fa, "--output-file=" + got, "-i", "500", "--batch-reads", "7001", "--no-sketch", bam)
+    r = run_cli("--reference", fa, "--output-file=" + got, "-i", "500", "--batch-reads", "7001", "-k", "21,32", "-q", "10", bam)
     assert r.returncode == 0, r.stderr
-    assert oracle_bamqualcheck(bam, fa, want, isize=500, klist=(), qlist=(), batch_reads=4000) == 0
+    assert oracle_bamqualcheck(bam, fa, want, isize=500, klist=(21, 32), qlist=(10,), batch_reads=4000) == 0
     assert filecmp.cmp(got, want, shallow=False)
     assert open(got).read().count("sample_id SYN") == 3
 
