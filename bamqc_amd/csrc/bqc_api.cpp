@@ -18,14 +18,18 @@
 #include "sketch.h"
 
 extern "C" {
-void bqc_launch_reads(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t n_cu, hipStream_t);
+void bqc_launch_reads_chunks(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t n_cu, hipStream_t);
+void bqc_launch_nm_extra(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
 void bqc_launch_bases(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, int variant, hipStream_t);
 void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, const uint32_t* parity, hipStream_t);
 void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
+void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, hipStream_t);
+void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_kernels_init();
+hipError_t bqc_short_init();
 }
 
 static thread_local char g_create_err[512];
@@ -69,8 +73,11 @@ struct bqc_ctx {
     uint8_t* d_started = nullptr; // [lane]
     // references
     std::vector<uint8_t*> d_ref;
+    std::vector<uint32_t*> d_refn; // one-hot nibble copy for the short-read fast path
     std::vector<uint64_t> ref_len;
     uint8_t** d_ref_ptrs = nullptr;
+    uint32_t** d_refn_ptrs = nullptr;
+    bool no_fast = false;          // BQC_NO_FAST=1: every read takes the generic kernel
     uint64_t* d_ref_len = nullptr;
     uint8_t* d_main = nullptr;
     // coverage / genome host state
@@ -122,6 +129,7 @@ static int upload_ref_tables(bqc_ctx* c)
 {
     HIPCHK(c, hipMemcpyAsync(c->d_ref_ptrs, c->d_ref.data(), sizeof(uint8_t*) * c->d_ref.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ref_len, c->ref_len.data(), sizeof(uint64_t) * c->ref_len.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_refn_ptrs, c->d_refn.data(), sizeof(uint32_t*) * c->d_refn.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -150,9 +158,12 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     c->sl = make_state_layout(opt->n_lanes, opt->max_read_len, opt->hist_cap, (uint32_t)opt->isize + 1);
     c->cov.assign(opt->n_lanes, LaneCov());
     c->d_ref.assign(nr, nullptr);
+    c->d_refn.assign(nr, nullptr);
     c->ref_len.assign(nr, 0);
     const char* v = getenv("BQC_BASES_SPLIT");
     c->bases_variant = (v && v[0] == '1') ? 1 : 0;
+    v = getenv("BQC_NO_FAST");
+    c->no_fast = v && v[0] == '1';
 #define CCHK(call)                                                                                            \
     do {                                                                                                      \
         hipError_t e_ = (call);                                                                               \
@@ -168,6 +179,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
     CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CCHK(bqc_kernels_init());
+    CCHK(bqc_short_init());
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err, 64));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
@@ -175,6 +187,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMalloc(&c->d_started, opt->n_lanes));
     CCHK(hipMalloc(&c->d_ref_ptrs, sizeof(uint8_t*) * nr));
     CCHK(hipMalloc(&c->d_ref_len, sizeof(uint64_t) * nr));
+    CCHK(hipMalloc(&c->d_refn_ptrs, sizeof(uint32_t*) * nr));
     CCHK(hipMalloc(&c->d_main, nr));
     CCHK(hipMemcpy(c->d_main, c->main_chrom.data(), nr, hipMemcpyHostToDevice));
     CCHK(hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
@@ -204,6 +217,8 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto p : c->d_ref) if (p) (void)hipFree(p);
+    for (auto p : c->d_refn) if (p) (void)hipFree(p);
+    (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
     (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
     (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
@@ -217,10 +232,17 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
     if (!c || rid < 0 || (uint32_t)rid >= c->opt.n_refs || (!dna5 && len)) return fail(c, BQC_ERR_ARG, "bqc_set_reference: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->d_ref[rid]) { HIPCHK(c, hipFree(c->d_ref[rid])); c->d_ref[rid] = nullptr; }
+    if (c->d_refn[rid]) { HIPCHK(c, hipFree(c->d_refn[rid])); c->d_refn[rid] = nullptr; }
     uint8_t* p = nullptr;
     HIPCHK(c, hipMalloc(&p, len ? len : 1));
     HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
+    const uint64_t ndw = (len + 7) / 8 + 2; // two zero dwords behind the last base
+    uint32_t* pn = nullptr;
+    HIPCHK(c, hipMalloc(&pn, ndw * 4));
+    bqc_launch_ref_nibbles(p, len, pn, ndw, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->d_ref[rid] = p;
+    c->d_refn[rid] = pn;
     c->ref_len[rid] = len;
     return upload_ref_tables(c);
 }
@@ -232,7 +254,9 @@ namespace {
 struct Prep {
     std::vector<uint16_t> flag, cov_off;
     std::vector<uint32_t> cov_win, seq_off, qual_off, cigar_off, perm, cov_list;
-    std::vector<Chunk> chunks;
+    std::vector<Chunk> chunks, chunks_fast, trip_chunks;
+    std::vector<uint32_t> trip_list;
+    uint32_t fast_w = 10;
     std::vector<CovTile> tiles;
     std::vector<uint8_t> lane_mask;
     std::vector<uint64_t> add_idx, add_val;
@@ -338,21 +362,43 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         P.perm.resize(n);
         for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
     }
-    {
+    { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> generic (chunks)
+        uint32_t maxfast = 0;
+        if (!c->no_fast)
+            for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
+        P.fast_w = std::max(10u, (maxfast + 7) / 8); // >= 10 keeps the per-wave staging tile within its LDS budget
+        const uint32_t fast_reads = 16u * (64u / P.fast_w) * 3u; // three groups per wave and chunk
         uint32_t start = 0, count = 0, bases = 0, cl = 0;
+        bool cfast = false;
+        auto close = [&]() {
+            if (!count) return;
+            (cfast ? P.chunks_fast : P.chunks).push_back(Chunk{start, count, cl, 0});
+            count = 0; bases = 0;
+        };
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t r = P.identity ? k : P.perm[k];
             const uint32_t L = b->l_seq[r], lane = b->lane[r];
+            const bool fast = !c->no_fast && L <= BQC_FAST_MAXLEN;
             const bool huge = L > BQC_CHUNK_BASES;
-            if (count && (lane != cl || count == BQC_CHUNK_READS || bases + L > BQC_CHUNK_BASES || huge)) {
-                P.chunks.push_back(Chunk{start, count, cl, 0});
-                count = 0; bases = 0;
-            }
-            if (!count) { start = k; cl = lane; }
+            if (count && (lane != cl || fast != cfast || count == (cfast ? fast_reads : (uint32_t)BQC_CHUNK_READS) ||
+                          (!cfast && bases + L > BQC_CHUNK_BASES) || huge))
+                close();
+            if (!count) { start = k; cl = lane; cfast = fast; }
             if (huge) { P.chunks.push_back(Chunk{k, 1, lane, 1}); continue; }
             ++count; bases += L;
+            // fast-path triplets assume chromPos = pos + i: reads with several CIGAR operations take the generic walk
+            if (fast && (P.flag[r] & BQC_FLAG_TRIPLET) && (b->n_cigar[r] != 1 || b->pos[r] < 0)) P.trip_list.push_back(r);
         }
-        if (count) P.chunks.push_back(Chunk{start, count, cl, 0});
+        close();
+        // chunks over the triplet list (already grouped by lane because it follows perm order)
+        uint32_t ts = 0, tc = 0, tl = 0, tb = 0;
+        for (uint32_t k = 0; k < P.trip_list.size(); ++k) {
+            const uint32_t r = P.trip_list[k], lane = b->lane[r], L = b->l_seq[r];
+            if (tc && (lane != tl || tc == BQC_CHUNK_READS || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0}); tc = 0; tb = 0; }
+            if (!tc) { ts = k; tl = lane; }
+            ++tc; tb += L;
+        }
+        if (tc) P.trip_chunks.push_back(Chunk{ts, tc, tl, 0});
     }
     // ---- coverage tiles
     for (uint32_t l = 0; l < nl; ++l) {
@@ -436,7 +482,8 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_ncig = cv.take(2ull * n), o_coff = cv.take(2ull * n), o_cwin = cv.take(4ull * n), o_soff = cv.take(4ull * n),
                  o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 16), o_qual = cv.take(P.qual_bytes + 16),
                  o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * n),
-                 o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
+                 o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
+                 o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
                  o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
                  o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
@@ -458,6 +505,9 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     UP(o_cig, b->cigar, 4 * P.cigar_words);
     if (!P.identity) UP(o_perm, P.perm.data(), 4ull * n);
     UP(o_chunks, P.chunks.data(), sizeof(Chunk) * P.chunks.size());
+    UP(o_chf, P.chunks_fast.data(), sizeof(Chunk) * P.chunks_fast.size());
+    UP(o_tl, P.trip_list.data(), 4ull * P.trip_list.size());
+    UP(o_tch, P.trip_chunks.data(), sizeof(Chunk) * P.trip_chunks.size());
     UP(o_xr, b->nm_extra_read, 4ull * b->n_nm_extra); UP(o_xv, b->nm_extra_val, 4ull * b->n_nm_extra);
     UP(o_clist, P.cov_list.data(), 4ull * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
     UP(o_mask, P.lane_mask.data(), c->opt.n_lanes);
@@ -477,6 +527,8 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.seq = (const uint8_t*)(base + o_seq); d.qual = (const uint8_t*)(base + o_qual); d.cigar = (const uint32_t*)(base + o_cig);
     d.perm = P.identity ? nullptr : (const uint32_t*)(base + o_perm);
     d.chunks = (const Chunk*)(base + o_chunks); d.n_chunks = (uint32_t)P.chunks.size();
+    d.chunks_fast = (const Chunk*)(base + o_chf); d.n_chunks_fast = (uint32_t)P.chunks_fast.size(); d.fast_w = P.fast_w;
+    d.trip_list = (const uint32_t*)(base + o_tl); d.trip_chunks = (const Chunk*)(base + o_tch); d.n_trip_chunks = (uint32_t)P.trip_chunks.size();
     d.nm_extra_read = (const uint32_t*)(base + o_xr); d.nm_extra_val = (const int32_t*)(base + o_xv); d.n_nm_extra = b->n_nm_extra;
     d.cov_list = (const uint32_t*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
     db->d_lane_mask = (uint8_t*)(base + o_mask);
@@ -518,7 +570,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
     if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_process after bqc_flush (call bqc_reset first)");
     HIPCHK(c, hipSetDevice(c->device));
-    DevRefs refs{(const uint8_t* const*)c->d_ref_ptrs, c->d_ref_len, c->d_main, c->opt.n_refs};
+    DevRefs refs{(const uint8_t* const*)c->d_ref_ptrs, c->d_ref_len, c->d_main, c->opt.n_refs, (const uint32_t* const*)c->d_refn_ptrs};
     if (db->seq > c->state_seq) { // re-processing after bqc_reset: this batch (uploaded on a fresh context) defines the stream state again
         c->cov = db->cov_after;
         c->fasta_cursor = db->fasta_cursor_after;
@@ -526,19 +578,34 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     }
     bqc_launch_or_bytes(c->d_started, db->d_started_after, c->opt.n_lanes, c->stream);
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
-    bqc_launch_reads(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
-    tick(c, "k_reads");
-    if (c->bases_variant == 0) {
-        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);
-        tick(c, "k_bases");
-    } else {
-        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 1, c->stream);
-        tick(c, "k_bases<cyc>");
-        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 2, c->stream);
-        tick(c, "k_bases<8mer>");
-        bqc_launch_bases(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
-        tick(c, "k_bases<trip>");
+    DevBatch slow = db->d; // generic kernels see only the reads that are not on the fast path
+    if (db->d.n_chunks_fast) {
+        // k_short does the per-read statistics of its own chunks; k_reads would double count them
+        bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
+        tick(c, "k_short");
+        if (db->d.n_trip_chunks) {
+            DevBatch t = db->d;
+            t.perm = db->d.trip_list; t.chunks = db->d.trip_chunks; t.n_chunks = db->d.n_trip_chunks;
+            bqc_launch_bases(t, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
+            tick(c, "k_bases<trip>");
+        }
     }
+    if (slow.n_chunks) {
+        bqc_launch_reads_chunks(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
+        tick(c, "k_reads");
+        if (c->bases_variant == 0) {
+            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);
+            tick(c, "k_bases");
+        } else {
+            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 1, c->stream);
+            tick(c, "k_bases<cyc>");
+            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 2, c->stream);
+            tick(c, "k_bases<8mer>");
+            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
+            tick(c, "k_bases<trip>");
+        }
+    }
+    if (db->d.n_nm_extra) bqc_launch_nm_extra(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
     if (db->d.n_cov_tiles) {
         bqc_launch_cov(db->d, c->sl, c->d_state, c->d_carry, c->d_parity, c->stream);
         bqc_launch_cov_flip(c->d_parity, db->d_lane_mask, c->opt.n_lanes, c->stream);

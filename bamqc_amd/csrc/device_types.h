@@ -11,6 +11,7 @@
 #define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
 #define BQC_CHUNK_READS 128      // max reads per chunk
 #define BQC_CHUNK_BASES 24576    // max bases per chunk (bounds the u16 8-mer counters, see k_bases)
+#define BQC_FAST_MAXLEN 256      // reads up to this length take the short-read fast path (k_short)
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
 
@@ -64,6 +65,14 @@ struct DevBatch {
     const uint32_t* cov_list;
     const CovTile* cov_tiles;
     uint32_t n_cov_tiles;
+    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 8 * fast_w
+    const Chunk* chunks_fast;
+    uint32_t n_chunks_fast;
+    uint32_t fast_w;           // lanes per read = ceil(max fast read length / 8)
+    // triplet-eligible fast reads whose CIGAR has more than one operation: generic triplet walk
+    const uint32_t* trip_list; // read ids, grouped like perm
+    const Chunk* trip_chunks;  // `first` indexes trip_list
+    uint32_t n_trip_chunks;
 };
 
 struct DevRefs {
@@ -71,4 +80,7 @@ struct DevRefs {
     const uint64_t* len;
     const uint8_t* main_chrom; // [n_refs]
     uint32_t n_refs;
+    // same contigs as one-hot nibbles (A=1 C=2 G=4 T=8, N -> A as Dna5->Dna does), 8 bases per dword,
+    // first base in the top nibble; two zero dwords of padding behind the last base
+    const uint32_t* const* refn;
 };

@@ -2,7 +2,8 @@
 // src/bamqualcheck.cpp:318-434) and the per-read histograms of QualityCheck
 // (src/QualityCheck.hpp:168-271: read_length, map_Q, insert_size, mis_match, cigar_count).
 //
-// Thread per read over the lane-grouped order (perm).  Counters are privatised in LDS per
+// Thread per read over the lane-uniform chunks of the generic path (the short-read fast path calls
+// read_stats from k_short).  Counters are privatised in LDS per
 // workgroup for the read group ("lane") the workgroup is currently in and flushed with one global
 // atomic per non-zero bin; bins beyond the LDS capacity and reads of another lane inside a mixed
 // wave go to global memory directly.  Reads 48 B of fixed columns + the CIGAR words per read.
@@ -10,30 +11,24 @@
 #include "read_stats.h"
 
 __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                  uint32_t* __restrict__ err, uint32_t per_block)
+                                                  uint32_t* __restrict__ err)
 {
     __shared__ uint32_t lds[RS_WORDS];
-    __shared__ uint32_t s_lane;
     for (uint32_t i = threadIdx.x; i < RS_WORDS; i += blockDim.x) lds[i] = 0;
-    const uint32_t lo = blockIdx.x * per_block;
-    const uint32_t hi = min(b.n_reads, lo + per_block);
     uint32_t blane = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t base = lo; base < hi; base += blockDim.x) {
-        const uint32_t k = base + threadIdx.x;
-        const bool live = k < hi;
-        const uint32_t r = live ? (b.perm ? b.perm[k] : k) : 0;
-        const uint32_t lane = live ? b.lane[r] : 0;
-        if (threadIdx.x == 0) s_lane = lane;
-        __syncthreads();
-        const uint32_t fl = s_lane;
-        if (fl != blane) { // block-uniform
+    for (uint32_t ci = blockIdx.x; ci < b.n_chunks; ci += gridDim.x) { // lane-uniform chunks (generic-path reads only)
+        const Chunk ch = b.chunks[ci];
+        if (ch.lane != blane) { // block-uniform
             if (blane != 0xFFFFFFFFu) rs_flush(lds, sl, state, blane);
-            __syncthreads();
-            blane = fl;
+            blane = ch.lane;
         }
-        read_stats(b, sl, state, refs, err, lds, r, live, live && lane == blane);
-        __syncthreads();
+        for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
+            const uint32_t t = t0 + threadIdx.x;
+            const bool live = t < ch.count;
+            const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            if (__ballot(live)) read_stats(b, sl, state, refs, err, lds, r, live, live);
+        }
     }
     if (blane != 0xFFFFFFFFu) rs_flush(lds, sl, state, blane);
 }
@@ -61,16 +56,16 @@ __global__ void k_nm_extra(DevBatch b, StateLayout sl, uint64_t* __restrict__ st
     gadd(state + sl.mate_base(b.lane[r], first ? 0u : 1u) + sl.m_mismatch + mm, 1);
 }
 
-extern "C" void bqc_launch_reads(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                 uint32_t n_cu, hipStream_t s)
+extern "C" void bqc_launch_reads_chunks(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
+                                        uint32_t n_cu, hipStream_t s)
 {
-    if (b.n_reads == 0) return;
-    // a few workgroups per CU, each owning a contiguous run of reads (multiple of the block size)
-    uint32_t grid = n_cu * 4;
-    uint32_t per = (b.n_reads + grid - 1) / grid;
-    per = ((per + 255) / 256) * 256;
-    grid = (b.n_reads + per - 1) / per;
-    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, b, sl, state, refs, err, per);
+    if (b.n_chunks == 0) return;
+    const uint32_t grid = b.n_chunks < n_cu * 8 ? b.n_chunks : n_cu * 8;
+    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, b, sl, state, refs, err);
+}
+
+extern "C" void bqc_launch_nm_extra(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err, hipStream_t s)
+{
     if (b.n_nm_extra)
         hipLaunchKernelGGL(k_nm_extra, dim3((b.n_nm_extra + 255) / 256), dim3(256), 0, s, b, sl, state, refs, err);
 }

@@ -1,0 +1,466 @@
+// k_short.hip — short-read fast path (reads up to 256 bases, i.e. all Illumina-style data).
+//
+// One workgroup (16 waves) per CU walks lane-uniform chunks.  Inside a wave, `rpw = 64 / W` reads are
+// processed at once; lane (s, w) owns the 8 sequencing cycles 8w..8w+7 of read slot s, so a whole
+// dword of 4-bit bases / two dwords of qualities are handled per lane with SWAR arithmetic:
+//
+//   staging    each lane copies its dword of packed bases, its two dwords of qualities and (for
+//              triplets) the matching 8 reference bases into a per-wave LDS tile (wave-local: no
+//              workgroup barrier in the main loop); the next group is prefetched into registers.
+//   cycles     reverse-strand reads are turned into sequencing orientation by a funnel shift +
+//              v_bfrev (bit reversal = reversed base order AND complemented one-hot nibbles).  Base
+//              counts per cycle are accumulated bit-sliced in registers (4-bit then 8-bit vertical
+//              counters, flushed to LDS every 255 reads), quality sums as packed 16-bit sums
+//              (QualityCheck.hpp:122-166).
+//   8-mers     2-bit codes of 16 consecutive cycles are packed into one register; the 8 windows of a
+//              lane are bit-field extracts; counters live in a 64 KiB LDS table of packed u8 fields with
+//              exact carry accounting on the (rare) wrap (OverallNumbers.hpp:137-168).
+//   triplets   BAM orientation: read and reference as one-hot nibbles, flank test = XOR + zero-nibble
+//              detection on 8 positions at once; context index from a 2-bit reference stream
+//              (TripletCounting.hpp:195-236).  Reads whose CIGAR has more than one operation go to
+//              the generic kernel (k_bases_generic.hip).
+//   per-read   flag cascade / histograms by thread-per-read at the start of every chunk (read_stats.h).
+#include "kernels_common.h"
+#include "read_stats.h"
+
+#define KS_THREADS 1024
+#define KS_WAVES (KS_THREADS / 64)
+#define KS_CT 256                                  // cycles held in LDS ( = BQC_FAST_MAXLEN )
+// LDS map (uint32 words)
+#define KS_T8    0                                 // 16384: 65536 u8 8-mer counters, four per dword
+#define KS_TRIP  (KS_T8 + 16384)                   // 1024
+#define KS_CYC   (KS_TRIP + 1024)                  // [2 sets: all reads, first-mate reads][6: A C G T other qual][KS_CT]
+#define KS_NC    (KS_CYC + 2 * 6 * KS_CT)          // [2 mates][KS_CT + 1]
+#define KS_GC    (KS_NC + 2 * (KS_CT + 1))
+#define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
+#define KS_AC    (KS_AQ + 512)
+#define KS_RS    (KS_AC + 512)                     // read_stats counters
+#define KS_STAGE (KS_RS + RS_WORDS)                // per-wave staging tiles
+#define KS_WS    384                               // words per wave: rpw * (5W + 10) <= 360 for 10 <= W <= 32
+#define KS_WORDS (KS_STAGE + KS_WAVES * KS_WS)
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(x, off, w); }
+
+// 8 nibble-spaced 2-bit values (bits [1:0] of every nibble) -> 16 contiguous bits, first nibble on top
+__device__ __forceinline__ uint32_t squeeze2(uint32_t c)
+{
+    c = (c | (c >> 2)) & 0x0F0F0F0Fu;
+    c = (c | (c >> 4)) & 0x00FF00FFu;
+    return (c | (c >> 8)) & 0xFFFFu;
+}
+// 8 nibble-LSB flags -> 8 contiguous bits, first nibble on top
+__device__ __forceinline__ uint32_t squeeze1(uint32_t m)
+{
+    m = (m | (m >> 3)) & 0x03030303u;
+    m = (m | (m >> 6)) & 0x000F000Fu;
+    return (m | (m >> 12)) & 0xFFu;
+}
+
+struct Planes { uint32_t a, c, g, t, oh, n; }; // one-hot masked planes, one-hot mask, literal-N mask (nibble LSBs)
+__device__ __forceinline__ Planes planes_of(uint32_t x)
+{
+    const uint32_t M = 0x11111111u;
+    const uint32_t p0 = x & M, p1 = (x >> 1) & M, p2 = (x >> 2) & M, p3 = (x >> 3) & M;
+    const uint32_t s = p0 + p1 + p2 + p3;          // per-nibble popcount (0..4)
+    Planes P;
+    P.oh = s & ~(s >> 1) & ~(s >> 2) & M;           // popcount == 1
+    P.n = (s >> 2) & M;                             // popcount == 4: literal 'N' (code 15)
+    P.a = p0 & P.oh; P.c = p1 & P.oh; P.g = p2 & P.oh; P.t = p3 & P.oh;
+    return P;
+}
+
+// exact accounting when a packed u8 counter wraps: every wrap of field f is worth +256 for its bin and,
+// because the carry spills into field f+1, -1 for the next bin (see header)
+__device__ __noinline__ void t8_wrap(uint64_t* __restrict__ em, uint32_t h, uint32_t old)
+{
+    uint32_t f = h & 3u;
+    uint32_t bin = h;
+    while (f < 4u && ((old >> (8u * f)) & 0xFFu) == 0xFFu) {
+        gadd(em + bin, 256);
+        if (f < 3u) gadd(em + bin + 1, (uint64_t)-1ll);
+        ++f; ++bin;
+    }
+}
+
+__device__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
+{
+    const uint64_t lb = sl.lane_base(lane);
+    for (uint32_t i = threadIdx.x; i < 65536; i += blockDim.x) {
+        const uint32_t v = (lds[KS_T8 + (i >> 2)] >> (8u * (i & 3u))) & 0xFFu;
+        if (v) gadd(state + lb + sl.o_eightmer + i, v);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) lds[KS_T8 + i] = 0;
+    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const uint32_t v = lds[KS_TRIP + i];
+        if (v) { gadd(state + lb + sl.o_triplet + i, v); lds[KS_TRIP + i] = 0; }
+    }
+    // per-cycle counters: set 0 = all reads, set 1 = first-mate reads; second mate = difference
+    for (uint32_t i = threadIdx.x; i < 6 * KS_CT; i += blockDim.x) {
+        const uint32_t all = lds[KS_CYC + i], m0 = lds[KS_CYC + 6 * KS_CT + i];
+        const uint32_t c = i / KS_CT, j = i % KS_CT;
+        lds[KS_CYC + i] = 0; lds[KS_CYC + 6 * KS_CT + i] = 0;
+        if (j >= sl.lcap) continue;
+        const uint32_t off = (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j;
+        if (m0) gadd(state + sl.mate_base(lane, 0) + off, m0);
+        if (all - m0) gadd(state + sl.mate_base(lane, 1) + off, all - m0);
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * (KS_CT + 1); i += blockDim.x) {
+        const uint32_t m = i / (KS_CT + 1), j = i % (KS_CT + 1);
+        const uint64_t mb = sl.mate_base(lane, m);
+        uint32_t v = lds[KS_NC + i];
+        if (v && j <= sl.lcap) gadd(state + mb + sl.m_ncount + j, v);
+        lds[KS_NC + i] = 0;
+        v = lds[KS_GC + i];
+        if (v && j <= sl.lcap) gadd(state + mb + sl.m_gccount + j, v);
+        lds[KS_GC + i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) {
+        const uint64_t mb = sl.mate_base(lane, i >> 8);
+        uint32_t v = lds[KS_AQ + i];
+        if (v) gadd(state + mb + sl.m_avgqual + (i & 255), v);
+        lds[KS_AQ + i] = 0;
+        v = lds[KS_AC + i];
+        if (v) gadd(state + mb + sl.m_avgceil + (i & 255), v);
+        lds[KS_AC + i] = 0;
+    }
+    rs_flush(lds + KS_RS, sl, state, lane);
+}
+
+// bit-sliced per-cycle counters of one lane (cycle group w of its slot)
+struct CycAcc {
+    uint32_t l1[2][5];      // 4-bit vertical counters (nibble t <-> cycle 8w + 7 - t): [set][A C G T other]
+    uint32_t l2[2][5][2];   // 8-bit: [..][0] nibbles 0,2,4,6  [..][1] nibbles 1,3,5,7
+    uint32_t q[2][4];       // quality sums, 16-bit fields: [set][e0 o0 e1 o1]
+    uint32_t n1, n2;        // groups since the last level-1 spill / level-2 flush
+};
+
+__device__ __forceinline__ void cyc_spill(CycAcc& A)
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            A.l2[s][p][0] += A.l1[s][p] & 0x0F0F0F0Fu;
+            A.l2[s][p][1] += (A.l1[s][p] >> 4) & 0x0F0F0F0Fu;
+            A.l1[s][p] = 0;
+        }
+    A.n1 = 0;
+}
+
+__device__ __noinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t w)
+{
+    cyc_spill(A);
+    const uint32_t c0 = 8u * w;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint32_t* base = lds + KS_CYC + s * 6 * KS_CT;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t v0 = (A.l2[s][p][0] >> (8 * b)) & 0xFFu, v1 = (A.l2[s][p][1] >> (8 * b)) & 0xFFu;
+                const uint32_t cy0 = c0 + 7u - 2u * b, cy1 = c0 + 6u - 2u * b;
+                if (v0 && cy0 < KS_CT) atomicAdd(base + p * KS_CT + cy0, v0);
+                if (v1 && cy1 < KS_CT) atomicAdd(base + p * KS_CT + cy1, v1);
+            }
+            A.l2[s][p][0] = 0; A.l2[s][p][1] = 0;
+        }
+        // quality: qa bytes = cycles c0..c0+3 (e0: +0,+2  o0: +1,+3), qb bytes = c0+4..c0+7
+        const uint32_t cyq[8] = {c0, c0 + 2, c0 + 1, c0 + 3, c0 + 4, c0 + 6, c0 + 5, c0 + 7};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = A.q[s][k] & 0xFFFFu, hi = A.q[s][k] >> 16;
+            if (lo && cyq[2 * k] < KS_CT) atomicAdd(base + 5 * KS_CT + cyq[2 * k], lo);
+            if (hi && cyq[2 * k + 1] < KS_CT) atomicAdd(base + 5 * KS_CT + cyq[2 * k + 1], hi);
+            A.q[s][k] = 0;
+        }
+    }
+    A.n2 = 0;
+}
+
+__global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
+                                                         uint32_t* __restrict__ err)
+{
+    extern __shared__ uint32_t lds[];
+    for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t W = b.fast_w, rpw = 64u / W;
+    const uint32_t slot = ln / W, w = ln % W;
+    const bool lane_used = slot < rpw;
+    // per-wave staging tile: SEQ [rpw][W+2] | QUAL [rpw][2W+4] | REFN [rpw][W+2] | REF2 [rpw][W+2]
+    volatile uint32_t* T = lds + KS_STAGE + wave * KS_WS;
+    volatile uint32_t* SEQ = T + slot * (W + 2);
+    volatile uint32_t* QUAL = T + rpw * (W + 2) + slot * (2 * W + 4);
+    volatile uint32_t* REFN = T + rpw * (3 * W + 6) + slot * (W + 2);
+    volatile uint32_t* REF2 = T + rpw * (4 * W + 8) + slot * (W + 2);
+    CycAcc A;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) { A.l1[s][p] = 0; A.l2[s][p][0] = 0; A.l2[s][p][1] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.q[s][k] = 0;
+    }
+    A.n1 = 0; A.n2 = 0;
+    uint32_t cur_lane = 0xFFFFFFFFu;
+
+    for (uint32_t ci = blockIdx.x; ci < b.n_chunks_fast; ci += gridDim.x) {
+        const Chunk ch = b.chunks_fast[ci];
+        if (ch.lane != cur_lane) { // block-uniform
+            if (cur_lane != 0xFFFFFFFFu) {
+                if (lane_used) cyc_flush(A, lds, w);
+                __syncthreads();
+                ks_flush(lds, sl, state, cur_lane);
+                __syncthreads();
+            }
+            cur_lane = ch.lane;
+        }
+        const uint64_t lb = sl.lane_base(cur_lane);
+        uint64_t* em = state + lb + sl.o_eightmer;
+        // ---- per-read statistics: thread per read of the chunk (counters privatised in LDS, no barrier needed)
+        for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
+            const uint32_t t = t0 + threadIdx.x;
+            const bool live = t < ch.count;
+            const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            if (__ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, r, live, live);
+        }
+        // ---- per-base statistics: groups of rpw reads per wave
+        const uint32_t n_groups = (ch.count + rpw - 1) / rpw;
+        for (uint32_t g = wave; g < n_groups; g += KS_WAVES) {
+            const uint32_t k = g * rpw + slot;
+            const bool have = lane_used && k < ch.count;
+            uint32_t flag = 0x900u, L = 0, ncig = 0, n0 = 0, r = 0;
+            int32_t pos = 0, rid = -1;
+            if (have) {
+                r = b.perm ? b.perm[ch.first + k] : ch.first + k;
+                flag = b.flag[r]; L = b.l_seq[r]; pos = b.pos[r]; rid = b.rid[r]; ncig = b.n_cigar[r];
+            }
+            const bool prim = have && !(flag & 0x900u) && (flag & 0xC0u); // records that reach get_count / count8mers
+            if (!prim) L = 0;
+            const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
+            const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
+            const uint32_t nd = (L + 7u) >> 3;           // dwords / cycle groups of this read
+            const bool trip = prim && (flag & BQC_FLAG_TRIPLET) && ncig == 1 && L >= 3 && !noqual && rid >= 0 &&
+                              (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
+            // ---------------- staging (global -> LDS tile of this wave)
+            if (lane_used) {
+                uint32_t sv = 0, q0 = 0, q1 = 0;
+                if (w < nd) {
+                    const uint32_t sb = (L + 1u) >> 1; // packed bytes
+                    const uint8_t* sp = b.seq + b.seq_off[r] + 4u * w;
+                    uint32_t v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+                    const uint32_t nb = min(4u, sb - 4u * w);
+                    if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
+                    sv = bswap32(v); // big-endian: base 8w in the top nibble
+                    const uint32_t nv = min(8u, L - 8u * w);
+                    if (nv < 8u) sv &= 0xFFFFFFFFu << (4u * (8u - nv)); // clear the padding nibble of an odd-length read
+                    if (!noqual) {
+                        const uint8_t* qp = b.qual + b.qual_off[r] + 8u * w;
+                        q0 = (uint32_t)qp[0] | ((uint32_t)qp[1] << 8) | ((uint32_t)qp[2] << 16) | ((uint32_t)qp[3] << 24);
+                        q1 = (uint32_t)qp[4] | ((uint32_t)qp[5] << 8) | ((uint32_t)qp[6] << 16) | ((uint32_t)qp[7] << 24);
+                        if (nv < 8u) {
+                            if (nv <= 4u) { q1 = 0; if (nv < 4u) q0 &= (1u << (8u * nv)) - 1u; }
+                            else q1 &= (1u << (8u * (nv - 4u))) - 1u;
+                        }
+                        if ((q0 | q1) & 0x80808080u) { // some Phred >= 128: check the 222 limit precisely
+                            bool bad = false;
+#pragma unroll
+                            for (int k8 = 0; k8 < 4; ++k8) bad |= ((q0 >> (8 * k8)) & 0xFFu) > 222u || ((q1 >> (8 * k8)) & 0xFFu) > 222u;
+                            if (bad) atomicOr(err, BQC_DEVERR_QUAL);
+                        }
+                    }
+                }
+                SEQ[1 + w] = sv;
+                QUAL[2 + 2 * w] = q0;
+                QUAL[3 + 2 * w] = q1;
+                if (trip) { // reference bases pos+8w .. pos+8w+7 (and pos-8 .. pos-1 by lane 0), one-hot nibbles
+                    const uint32_t* rn = refs.refn[rid];
+                    const uint64_t p8 = (uint64_t)(uint32_t)pos + 8u * w; // pos >= 0 for fast-path triplet reads (host)
+                    const uint64_t di = p8 >> 3;
+                    const uint32_t sh = ((uint32_t)p8 & 7u) * 4u;
+                    const bool inr = p8 < refs.len[rid] + 8u;           // else: past the contig (two zero dwords of padding exist)
+                    const uint32_t d0 = inr ? rn[di] : 0u, d1 = inr ? rn[di + 1] : 0u;
+                    const uint32_t v = sh ? alignbit(d0, d1, 32u - sh) : d0;
+                    REFN[1 + w] = v;
+                    const uint32_t c = (((v >> 1) | (v >> 3)) & 0x11111111u) | ((((v >> 2) | (v >> 3)) & 0x11111111u) << 1);
+                    REF2[1 + w] = squeeze2(c);
+                    if (w == 0) {
+                        uint32_t pv = 0;
+                        if ((uint32_t)pos >= 8u && inr) {
+                            const uint32_t e0 = rn[di - 1];
+                            pv = sh ? alignbit(e0, d0, 32u - sh) : e0;
+                        } else if (pos > 0 && inr) {
+                            pv = rn[0] >> (4u * (8u - (uint32_t)pos));
+                        }
+                        REFN[0] = pv;
+                        const uint32_t pc = (((pv >> 1) | (pv >> 3)) & 0x11111111u) | ((((pv >> 2) | (pv >> 3)) & 0x11111111u) << 1);
+                        REF2[0] = squeeze2(pc);
+                    }
+                }
+            }
+            // LDS operations of one wave execute in order: the tile is visible to every lane of this wave
+            __builtin_amdgcn_wave_barrier();
+
+            // ---------------- sequencing-orientation dword X (cycles 8w .. 8w+7)
+            uint32_t X = 0, qa = 0, qb = 0;
+            if (lane_used && w < nd) {
+                if (!rc) {
+                    X = SEQ[1 + w];
+                    qa = QUAL[2 + 2 * w]; qb = QUAL[3 + 2 * w];
+                } else {
+                    const int32_t o = (int32_t)L - 8 - 8 * (int32_t)w; // first base of the group, may be negative (> -8)
+                    const int32_t d0i = o >> 3;                          // floor: -1 addresses the zero pad
+                    const uint32_t shn = (uint32_t)(o - 8 * d0i) * 4u;
+                    const uint32_t hi = SEQ[1 + d0i], lo = SEQ[2 + d0i];
+                    const uint32_t Y = shn ? alignbit(hi, lo, 32u - shn) : hi;
+                    X = __brev(Y); // reversed base order, complemented one-hot codes (IUPAC masks complement the same way)
+                    const uint32_t bo = (uint32_t)(8 + o);              // byte offset into QUAL (data starts at byte 8)
+                    const uint32_t qd = bo >> 2, bs = bo & 3u;
+                    const uint32_t a0 = QUAL[qd], a1 = QUAL[qd + 1], a2 = QUAL[qd + 2];
+                    const uint32_t y0 = alignbyte(a1, a0, bs), y1 = alignbyte(a2, a1, bs);
+                    qa = bswap32(y1); qb = bswap32(y0);
+                }
+            }
+            const Planes P = planes_of(X);
+            const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u;
+            const uint32_t vm = nv ? (0x11111111u & (0xFFFFFFFFu << (4u * (8u - nv)))) : 0u; // valid-cycle mask
+            const uint32_t other = vm & ~P.oh;
+            // ---- bit-sliced accumulation
+            {
+                const uint32_t m0 = mate == 0 ? 0xFFFFFFFFu : 0u;
+                A.l1[0][0] += P.a; A.l1[0][1] += P.c; A.l1[0][2] += P.g; A.l1[0][3] += P.t; A.l1[0][4] += other;
+                A.l1[1][0] += P.a & m0; A.l1[1][1] += P.c & m0; A.l1[1][2] += P.g & m0; A.l1[1][3] += P.t & m0; A.l1[1][4] += other & m0;
+                const uint32_t e0 = qa & 0x00FF00FFu, o0 = (qa >> 8) & 0x00FF00FFu, e1 = qb & 0x00FF00FFu, o1 = (qb >> 8) & 0x00FF00FFu;
+                A.q[0][0] += e0; A.q[0][1] += o0; A.q[0][2] += e1; A.q[0][3] += o1;
+                A.q[1][0] += e0 & m0; A.q[1][1] += o0 & m0; A.q[1][2] += e1 & m0; A.q[1][3] += o1 & m0;
+                ++A.n1; ++A.n2;
+                if (A.n1 == 15u) cyc_spill(A);
+                if (A.n2 == 255u) cyc_flush(A, lds, w);
+            }
+            // ---- per-read sums: N count, GC count, quality sum (segmented reduction over the W lanes of a slot)
+            {
+                uint32_t v1 = __builtin_amdgcn_sad_u8(qa, 0u, 0u) + __builtin_amdgcn_sad_u8(qb, 0u, 0u);
+                uint32_t v2 = (uint32_t)__popc(P.n) | ((uint32_t)__popc(P.c | P.g) << 16);
+                for (uint32_t d = 1; d < W; d <<= 1) {
+                    const uint32_t t1 = (uint32_t)__shfl_down((int)v1, d), t2 = (uint32_t)__shfl_down((int)v2, d);
+                    if (w + d < W) { v1 += t1; v2 += t2; }
+                }
+                if (prim && w == 0) {
+                    const uint32_t nN = v2 & 0xFFFFu, nGC = v2 >> 16, qs = v1;
+                    atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + nN], 1u);
+                    atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + nGC], 1u);
+                    if (L > 0) {
+                        const uint32_t rnd = (2u * qs + L) / (2u * L), cl = (qs + L - 1u) / L;
+                        atomicAdd(&lds[KS_AQ + mate * 256 + (rnd & 255u)], 1u);
+                        atomicAdd(&lds[KS_AC + mate * 256 + (cl & 255u)], 1u);
+                    }
+                }
+            }
+            // ---- 8-mers: windows starting at cycles 8w .. 8w+7
+            const uint32_t cn = (P.c | P.t) | ((P.g | P.t) << 1);  // 2-bit code per nibble; non-ACGT -> A (char -> Dna after RC)
+            const uint32_t c16 = squeeze2(cn);
+            {
+                uint32_t n8 = squeeze1(P.n) | (nv < 8u ? (0xFFu >> nv) : 0u); // literal N or past the end blocks a window
+                uint32_t cx = (uint32_t)__shfl_down((int)c16, 1), nx = (uint32_t)__shfl_down((int)n8, 1);
+                if (w + 1u >= W || ln == 63u) { cx = 0; nx = 0xFFu; }
+                const uint32_t c32 = (c16 << 16) | cx, n16 = (n8 << 8) | nx;
+                if (nv) {
+#pragma unroll
+                    for (int kw = 0; kw < 8; ++kw) {
+                        if (bfe(n16, 8 - kw, 8) == 0u) {
+                            const uint32_t h = bfe(c32, 16 - 2 * kw, 16);
+                            const uint32_t old = atomicAdd(&lds[KS_T8 + (h >> 2)], 1u << (8u * (h & 3u)));
+                            if (((old >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) t8_wrap(em, h, old);
+                        }
+                    }
+                }
+            }
+            // ---- triplets (BAM orientation, single-operation CIGAR: chromPos = pos + i)
+            if (__ballot(trip)) {
+                uint32_t Xf = X, c16f = c16;
+                Planes F = P;
+                if (rc) { // forward-orientation dword
+                    Xf = (lane_used && w < nd) ? SEQ[1 + w] : 0u;
+                    F = planes_of(Xf);
+                    c16f = squeeze2((F.c | F.t) | ((F.g | F.t) << 1));
+                }
+                // canonical nibbles: one-hot kept, literal N -> 0 (never matches), other -> A (char -> Dna)
+                const uint32_t Z = (Xf & (F.oh * 15u)) | (0x11111111u & ~F.oh & ~F.n & (nv ? 0xFFFFFFFFu : 0u));
+                uint32_t Zp = (uint32_t)__shfl_up((int)Z, 1), Zn = (uint32_t)__shfl_down((int)Z, 1);
+                if (w == 0) Zp = 0;
+                if (w + 1u >= W || ln == 63u) Zn = 0;
+                if (trip && w < nd) {
+                    const uint32_t ZL = alignbit(Zp, Z, 4), ZR = alignbit(Z, Zn, 28);           // neighbours i-1 / i+1
+                    const uint32_t r0 = REFN[w], r1 = REFN[1 + w], r2 = REFN[2 + w];
+                    const uint32_t RL = alignbit(r0, r1, 4), RR = alignbit(r1, r2, 28);
+                    uint32_t u = (ZL ^ RL) | (ZR ^ RR);
+                    u |= u >> 1; u |= u >> 2;
+                    uint32_t cm = ~u & F.oh;                                                     // flanks match, base is A/C/G/T
+                    // positions 1 <= i <= L-2, and i < n0 when the single CIGAR op is shorter than the read
+                    n0 = b.cigar[b.cigar_off[r]] >> 4;
+                    uint32_t lim = L - 1u;
+                    if (n0 != 0u && n0 < lim) lim = n0;
+                    const uint32_t cnt = lim > 8u * w ? min(8u, lim - 8u * w) : 0u;
+                    uint32_t pm = cnt ? (0xFFFFFFFFu << (4u * (8u - cnt))) : 0u;
+                    if (w == 0) pm &= 0x0FFFFFFFu;
+                    cm &= pm;
+                    if (cm) {
+                        const uint32_t f0 = QUAL[2 + 2 * w], f1 = QUAL[3 + 2 * w];                  // forward qualities
+                        const uint32_t r2s = ((REF2[w] & 3u) << 18) | (REF2[1 + w] << 2) | (REF2[2 + w] >> 14); // codes of pos-1 .. pos+8
+                        const uint32_t grp = (rc ? 2u : 0u) + mate;
+#pragma unroll
+                        for (int kp = 0; kp < 8; ++kp) {
+                            const uint32_t q = bfe(kp < 4 ? f0 : f1, 8 * (kp & 3), 8);
+                            if (((cm >> (28 - 4 * kp)) & 1u) && (q - 20u) <= 74u) {             // (signed char)(q+33) >= '5'
+                                const uint32_t ctx = bfe(r2s, 14 - 2 * kp, 6), base = bfe(c16f, 14 - 2 * kp, 2);
+                                atomicAdd(&lds[KS_TRIP + ctx * 16u + grp * 4u + base], 1u);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); // the tile is rewritten by the next group
+        }
+    }
+    if (cur_lane != 0xFFFFFFFFu) {
+        if (lane_used) cyc_flush(A, lds, w);
+        __syncthreads();
+        ks_flush(lds, sl, state, cur_lane);
+    }
+}
+
+// Dna5 bytes -> one-hot nibbles, 8 bases per dword, first base in the top nibble; N (4) -> A like Dna5 -> Dna
+__global__ void k_ref_nibbles(const uint8_t* __restrict__ dna5, uint64_t len, uint32_t* __restrict__ out, uint64_t n_dwords)
+{
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dwords) return;
+    uint32_t v = 0;
+    for (uint32_t t = 0; t < 8; ++t) {
+        const uint64_t p = d * 8 + t;
+        if (p < len) v |= (1u << (dna5[p] & 3u)) << (28u - 4u * t);
+    }
+    out[d] = v;
+}
+
+extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((n_dwords + 255) / 256)), dim3(256), 0, s, dna5, len, out, n_dwords);
+}
+
+extern "C" hipError_t bqc_short_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_short), hipFuncAttributeMaxDynamicSharedMemorySize, KS_WORDS * 4);
+}
+
+extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
+                                 uint32_t grid, hipStream_t s)
+{
+    if (b.n_chunks_fast == 0) return;
+    if (grid > b.n_chunks_fast) grid = b.n_chunks_fast;
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err);
+}
