@@ -367,7 +367,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
         P.fast_w = std::max(10u, (maxfast + 7) / 8); // >= 10 keeps the per-wave staging tile within its LDS budget
-        const uint32_t fast_reads = 16u * (64u / P.fast_w) * 3u; // three groups per wave and chunk
+        const uint32_t per_pass = 16u * (64u / P.fast_w);
+        const uint32_t fast_reads = (1008u / per_pass) * per_pass; // <= KS_CHUNK (k_short keeps one record per read in LDS)
         uint32_t start = 0, count = 0, bases = 0, cl = 0;
         bool cfast = false;
         auto close = [&]() {

@@ -23,7 +23,9 @@
 #include "kernels_common.h"
 #include "read_stats.h"
 
+#ifndef KS_THREADS
 #define KS_THREADS 1024
+#endif
 #define KS_WAVES (KS_THREADS / 64)
 #define KS_CT 256                                  // cycles held in LDS ( = BQC_FAST_MAXLEN )
 // LDS map (uint32 words)
@@ -37,7 +39,10 @@
 #define KS_RS    (KS_AC + 512)                     // read_stats counters
 #define KS_STAGE (KS_RS + RS_WORDS)                // per-wave staging tiles
 #define KS_WS    384                               // words per wave: rpw * (5W + 10) <= 360 for 10 <= W <= 32
-#define KS_WORDS (KS_STAGE + KS_WAVES * KS_WS)
+#define KS_META  (KS_STAGE + KS_WAVES * KS_WS)      // per-read records of the current chunk
+#define KS_CHUNK 1008
+#define KS_MW    7                                 // flag|ncig<<16, L, seq_off, qual_off, pos, rid, n0
+#define KS_WORDS (KS_META + KS_CHUNK * KS_MW)
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
@@ -85,7 +90,7 @@ __device__ __noinline__ void t8_wrap(uint64_t* __restrict__ em, uint32_t h, uint
     }
 }
 
-__device__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
+__device__ __noinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
 {
     const uint64_t lb = sl.lane_base(lane);
     for (uint32_t i = threadIdx.x; i < 65536; i += blockDim.x) {
@@ -132,18 +137,27 @@ __device__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restr
 
 // bit-sliced per-cycle counters of one lane (cycle group w of its slot)
 struct CycAcc {
-    uint32_t l1[2][5];      // 4-bit vertical counters (nibble t <-> cycle 8w + 7 - t): [set][A C G T other]
-    uint32_t l2[2][5][2];   // 8-bit: [..][0] nibbles 0,2,4,6  [..][1] nibbles 1,3,5,7
+    uint32_t l1[2][4];      // 4-bit vertical counters (nibble t <-> cycle 8w + 7 - t): [set][A C G T]
+    uint32_t l2[2][4][2];   // 8-bit: [..][0] nibbles 0,2,4,6  [..][1] nibbles 1,3,5,7
     uint32_t q[2][4];       // quality sums, 16-bit fields: [set][e0 o0 e1 o1]
     uint32_t n1, n2;        // groups since the last level-1 spill / level-2 flush
 };
+
+__device__ __forceinline__ void cyc_zero(CycAcc& A)
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { A.l1[s][p] = 0; A.l2[s][p][0] = 0; A.l2[s][p][1] = 0; A.q[s][p] = 0; }
+    A.n1 = 0; A.n2 = 0;
+}
 
 __device__ __forceinline__ void cyc_spill(CycAcc& A)
 {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
+        for (int p = 0; p < 4; ++p) {
             A.l2[s][p][0] += A.l1[s][p] & 0x0F0F0F0Fu;
             A.l2[s][p][1] += (A.l1[s][p] >> 4) & 0x0F0F0F0Fu;
             A.l1[s][p] = 0;
@@ -151,39 +165,52 @@ __device__ __forceinline__ void cyc_spill(CycAcc& A)
     A.n1 = 0;
 }
 
-__device__ __noinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t w)
+// Rare (every 255 groups / at a lane switch): the counters are copied to a small local array and handed to a real
+// function, so that the accumulators themselves never have their address taken (which would move them to scratch).
+__device__ __noinline__ void cyc_flush_arr(const uint32_t* v, uint32_t* lds, uint32_t w)
 {
-    cyc_spill(A);
     const uint32_t c0 = 8u * w;
-#pragma unroll
     for (int s = 0; s < 2; ++s) {
         uint32_t* base = lds + KS_CYC + s * 6 * KS_CT;
-#pragma unroll
-        for (int p = 0; p < 5; ++p) {
-#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t a0 = v[(s * 4 + p) * 2], a1 = v[(s * 4 + p) * 2 + 1];
             for (int b = 0; b < 4; ++b) {
-                const uint32_t v0 = (A.l2[s][p][0] >> (8 * b)) & 0xFFu, v1 = (A.l2[s][p][1] >> (8 * b)) & 0xFFu;
+                const uint32_t v0 = (a0 >> (8 * b)) & 0xFFu, v1 = (a1 >> (8 * b)) & 0xFFu;
                 const uint32_t cy0 = c0 + 7u - 2u * b, cy1 = c0 + 6u - 2u * b;
                 if (v0 && cy0 < KS_CT) atomicAdd(base + p * KS_CT + cy0, v0);
                 if (v1 && cy1 < KS_CT) atomicAdd(base + p * KS_CT + cy1, v1);
             }
-            A.l2[s][p][0] = 0; A.l2[s][p][1] = 0;
         }
         // quality: qa bytes = cycles c0..c0+3 (e0: +0,+2  o0: +1,+3), qb bytes = c0+4..c0+7
-        const uint32_t cyq[8] = {c0, c0 + 2, c0 + 1, c0 + 3, c0 + 4, c0 + 6, c0 + 5, c0 + 7};
-#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = A.q[s][k] & 0xFFFFu, hi = A.q[s][k] >> 16;
-            if (lo && cyq[2 * k] < KS_CT) atomicAdd(base + 5 * KS_CT + cyq[2 * k], lo);
-            if (hi && cyq[2 * k + 1] < KS_CT) atomicAdd(base + 5 * KS_CT + cyq[2 * k + 1], hi);
-            A.q[s][k] = 0;
+            const uint32_t ca = c0 + (k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5), cb = ca + 2;
+            const uint32_t x = v[16 + s * 4 + k], lo = x & 0xFFFFu, hi = x >> 16;
+            if (lo && ca < KS_CT) atomicAdd(base + 5 * KS_CT + ca, lo);
+            if (hi && cb < KS_CT) atomicAdd(base + 5 * KS_CT + cb, hi);
         }
     }
-    A.n2 = 0;
+}
+__device__ __forceinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t w)
+{
+    cyc_spill(A);
+    uint32_t v[24];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { v[(s * 4 + p) * 2] = A.l2[s][p][0]; v[(s * 4 + p) * 2 + 1] = A.l2[s][p][1]; v[16 + s * 4 + p] = A.q[s][p]; }
+    cyc_flush_arr(v, lds, w);
+    cyc_zero(A);
+}
+
+struct Pre { uint32_t sv, q0, q1, d0, d1, e0; }; // raw dwords of the NEXT group, in flight while the current one is computed
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-endian dword (merged into one global_load_dword)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
 __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                         uint32_t* __restrict__ err)
+                                                         uint32_t* __restrict__ err, uint32_t parts)
 {
     extern __shared__ uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
@@ -193,21 +220,42 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     const uint32_t slot = ln / W, w = ln % W;
     const bool lane_used = slot < rpw;
     // per-wave staging tile: SEQ [rpw][W+2] | QUAL [rpw][2W+4] | REFN [rpw][W+2] | REF2 [rpw][W+2]
-    volatile uint32_t* T = lds + KS_STAGE + wave * KS_WS;
-    volatile uint32_t* SEQ = T + slot * (W + 2);
-    volatile uint32_t* QUAL = T + rpw * (W + 2) + slot * (2 * W + 4);
-    volatile uint32_t* REFN = T + rpw * (3 * W + 6) + slot * (W + 2);
-    volatile uint32_t* REF2 = T + rpw * (4 * W + 8) + slot * (W + 2);
+    uint32_t* T = lds + KS_STAGE + wave * KS_WS;
+    uint32_t* SEQ = T + slot * (W + 2);
+    uint32_t* QUAL = T + rpw * (W + 2) + slot * (2 * W + 4);
+    uint32_t* REFN = T + rpw * (3 * W + 6) + slot * (W + 2);
+    uint32_t* REF2 = T + rpw * (4 * W + 8) + slot * (W + 2);
+    uint32_t* META = lds + KS_META;
     CycAcc A;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int p = 0; p < 5; ++p) { A.l1[s][p] = 0; A.l2[s][p][0] = 0; A.l2[s][p][1] = 0; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) A.q[s][k] = 0;
-    }
-    A.n1 = 0; A.n2 = 0;
+    cyc_zero(A);
     uint32_t cur_lane = 0xFFFFFFFFu;
+
+    // issue the global loads of group g for this lane (meta comes from the chunk's LDS records)
+    auto prefetch = [&](uint32_t g, uint32_t count) -> Pre {
+        Pre P{0, 0, 0, 0, 0, 0};
+        const uint32_t k = g * rpw + slot;
+        if (!(lane_used && k < count)) return P;
+        const uint32_t* M = META + k * KS_MW;
+        const uint32_t fl = M[0] & 0xFFFFu, nc = M[0] >> 16, L = M[1];
+        const bool prim = !(fl & 0x900u) && (fl & 0xC0u);
+        if (!prim || 8u * w >= L) return P;
+        P.sv = ld32u(b.seq + M[2] + 4u * w);
+        if (!(fl & BQC_FLAG_NO_QUAL)) {
+            const uint8_t* qp = b.qual + M[3] + 8u * w;
+            P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
+        }
+        const int32_t rid = (int32_t)M[5];
+        if ((parts & 4u) && (fl & BQC_FLAG_TRIPLET) && nc == 1 && L >= 3 && !(fl & BQC_FLAG_NO_QUAL) && rid >= 0 && (uint32_t)rid < refs.n_refs) {
+            const uint32_t* rn = refs.refn[rid];
+            const uint64_t p8 = (uint64_t)M[4] + 8u * w; // pos >= 0 for fast-path triplet reads (host)
+            if (rn && p8 < refs.len[rid] + 8u) {          // else: past the contig -> zero nibbles, nothing matches
+                const uint64_t di = p8 >> 3;
+                P.d0 = rn[di]; P.d1 = rn[di + 1];
+                if (w == 0) P.e0 = M[4] >= 8u ? rn[di - 1] : (M[4] > 0u ? rn[0] : 0u);
+            }
+        }
+        return P;
+    };
 
     for (uint32_t ci = blockIdx.x; ci < b.n_chunks_fast; ci += gridDim.x) {
         const Chunk ch = b.chunks_fast[ci];
@@ -222,47 +270,54 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
-        // ---- per-read statistics: thread per read of the chunk (counters privatised in LDS, no barrier needed)
+        // ---- phase A: thread per read — per-read statistics, and the read's record for phase B into LDS
         for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
             const uint32_t t = t0 + threadIdx.x;
             const bool live = t < ch.count;
             const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
-            if (__ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, r, live, live);
+            if (live) {
+                const uint32_t fl = b.flag[r], nc = b.n_cigar[r];
+                uint32_t* M = META + t * KS_MW;
+                M[0] = fl | (nc << 16); M[1] = b.l_seq[r]; M[2] = b.seq_off[r]; M[3] = b.qual_off[r];
+                M[4] = (uint32_t)b.pos[r]; M[5] = (uint32_t)b.rid[r];
+                M[6] = ((fl & BQC_FLAG_TRIPLET) && nc == 1) ? (b.cigar[b.cigar_off[r]] >> 4) : 0u;
+            }
+            if ((parts & 8u) && __ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, r, live, live);
         }
-        // ---- per-base statistics: groups of rpw reads per wave
+        __syncthreads();
+        // ---- phase B: groups of rpw reads per wave; the next group's data is loaded while this one is processed
         const uint32_t n_groups = (ch.count + rpw - 1) / rpw;
+        Pre nxt = wave < n_groups ? prefetch(wave, ch.count) : Pre{0, 0, 0, 0, 0, 0};
         for (uint32_t g = wave; g < n_groups; g += KS_WAVES) {
+            const Pre cur = nxt;
+            if (g + KS_WAVES < n_groups) nxt = prefetch(g + KS_WAVES, ch.count);
             const uint32_t k = g * rpw + slot;
             const bool have = lane_used && k < ch.count;
-            uint32_t flag = 0x900u, L = 0, ncig = 0, n0 = 0, r = 0;
-            int32_t pos = 0, rid = -1;
-            if (have) {
-                r = b.perm ? b.perm[ch.first + k] : ch.first + k;
-                flag = b.flag[r]; L = b.l_seq[r]; pos = b.pos[r]; rid = b.rid[r]; ncig = b.n_cigar[r];
-            }
+            const uint32_t* M = META + (have ? k : 0u) * KS_MW;
+            uint32_t flag = 0x900u, L = 0, ncig = 0;
+            int32_t rid = -1;
+            uint32_t pos = 0;
+            if (have) { flag = M[0] & 0xFFFFu; ncig = M[0] >> 16; L = M[1]; pos = M[4]; rid = (int32_t)M[5]; }
             const bool prim = have && !(flag & 0x900u) && (flag & 0xC0u); // records that reach get_count / count8mers
             if (!prim) L = 0;
             const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
             const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
             const uint32_t nd = (L + 7u) >> 3;           // dwords / cycle groups of this read
-            const bool trip = prim && (flag & BQC_FLAG_TRIPLET) && ncig == 1 && L >= 3 && !noqual && rid >= 0 &&
+            const bool trip = (parts & 4u) && prim && (flag & BQC_FLAG_TRIPLET) && ncig == 1 && L >= 3 && !noqual && rid >= 0 &&
                               (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
-            // ---------------- staging (global -> LDS tile of this wave)
+            const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u; // valid cycles of this lane
+            // ---------------- staging (registers -> LDS tile of this wave), with the tails masked to zero
             if (lane_used) {
                 uint32_t sv = 0, q0 = 0, q1 = 0;
-                if (w < nd) {
+                if (nv) {
                     const uint32_t sb = (L + 1u) >> 1; // packed bytes
-                    const uint8_t* sp = b.seq + b.seq_off[r] + 4u * w;
-                    uint32_t v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+                    uint32_t v = cur.sv;
                     const uint32_t nb = min(4u, sb - 4u * w);
                     if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
                     sv = bswap32(v); // big-endian: base 8w in the top nibble
-                    const uint32_t nv = min(8u, L - 8u * w);
                     if (nv < 8u) sv &= 0xFFFFFFFFu << (4u * (8u - nv)); // clear the padding nibble of an odd-length read
                     if (!noqual) {
-                        const uint8_t* qp = b.qual + b.qual_off[r] + 8u * w;
-                        q0 = (uint32_t)qp[0] | ((uint32_t)qp[1] << 8) | ((uint32_t)qp[2] << 16) | ((uint32_t)qp[3] << 24);
-                        q1 = (uint32_t)qp[4] | ((uint32_t)qp[5] << 8) | ((uint32_t)qp[6] << 16) | ((uint32_t)qp[7] << 24);
+                        q0 = cur.q0; q1 = cur.q1;
                         if (nv < 8u) {
                             if (nv <= 4u) { q1 = 0; if (nv < 4u) q0 &= (1u << (8u * nv)) - 1u; }
                             else q1 &= (1u << (8u * (nv - 4u))) - 1u;
@@ -279,36 +334,28 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 QUAL[2 + 2 * w] = q0;
                 QUAL[3 + 2 * w] = q1;
                 if (trip) { // reference bases pos+8w .. pos+8w+7 (and pos-8 .. pos-1 by lane 0), one-hot nibbles
-                    const uint32_t* rn = refs.refn[rid];
-                    const uint64_t p8 = (uint64_t)(uint32_t)pos + 8u * w; // pos >= 0 for fast-path triplet reads (host)
-                    const uint64_t di = p8 >> 3;
-                    const uint32_t sh = ((uint32_t)p8 & 7u) * 4u;
-                    const bool inr = p8 < refs.len[rid] + 8u;           // else: past the contig (two zero dwords of padding exist)
-                    const uint32_t d0 = inr ? rn[di] : 0u, d1 = inr ? rn[di + 1] : 0u;
-                    const uint32_t v = sh ? alignbit(d0, d1, 32u - sh) : d0;
+                    const uint32_t sh = ((pos + 8u * w) & 7u) * 4u;
+                    const uint32_t v = sh ? alignbit(cur.d0, cur.d1, 32u - sh) : cur.d0;
                     REFN[1 + w] = v;
                     const uint32_t c = (((v >> 1) | (v >> 3)) & 0x11111111u) | ((((v >> 2) | (v >> 3)) & 0x11111111u) << 1);
                     REF2[1 + w] = squeeze2(c);
                     if (w == 0) {
                         uint32_t pv = 0;
-                        if ((uint32_t)pos >= 8u && inr) {
-                            const uint32_t e0 = rn[di - 1];
-                            pv = sh ? alignbit(e0, d0, 32u - sh) : e0;
-                        } else if (pos > 0 && inr) {
-                            pv = rn[0] >> (4u * (8u - (uint32_t)pos));
-                        }
+                        if (pos >= 8u) pv = sh ? alignbit(cur.e0, cur.d0, 32u - sh) : cur.e0;
+                        else if (pos > 0u) pv = cur.e0 >> (4u * (8u - pos));
                         REFN[0] = pv;
                         const uint32_t pc = (((pv >> 1) | (pv >> 3)) & 0x11111111u) | ((((pv >> 2) | (pv >> 3)) & 0x11111111u) << 1);
                         REF2[0] = squeeze2(pc);
                     }
                 }
             }
-            // LDS operations of one wave execute in order: the tile is visible to every lane of this wave
+            // LDS operations of one wave execute in order; the fence only stops the compiler from moving them
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
             // ---------------- sequencing-orientation dword X (cycles 8w .. 8w+7)
             uint32_t X = 0, qa = 0, qb = 0;
-            if (lane_used && w < nd) {
+            if (nv) {
                 if (!rc) {
                     X = SEQ[1 + w];
                     qa = QUAL[2 + 2 * w]; qb = QUAL[3 + 2 * w];
@@ -327,23 +374,29 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 }
             }
             const Planes P = planes_of(X);
-            const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u;
-            const uint32_t vm = nv ? (0x11111111u & (0xFFFFFFFFu << (4u * (8u - nv)))) : 0u; // valid-cycle mask
-            const uint32_t other = vm & ~P.oh;
             // ---- bit-sliced accumulation
-            {
+            if (parts & 1u) {
                 const uint32_t m0 = mate == 0 ? 0xFFFFFFFFu : 0u;
-                A.l1[0][0] += P.a; A.l1[0][1] += P.c; A.l1[0][2] += P.g; A.l1[0][3] += P.t; A.l1[0][4] += other;
-                A.l1[1][0] += P.a & m0; A.l1[1][1] += P.c & m0; A.l1[1][2] += P.g & m0; A.l1[1][3] += P.t & m0; A.l1[1][4] += other & m0;
+                A.l1[0][0] += P.a; A.l1[0][1] += P.c; A.l1[0][2] += P.g; A.l1[0][3] += P.t;
+                A.l1[1][0] += P.a & m0; A.l1[1][1] += P.c & m0; A.l1[1][2] += P.g & m0; A.l1[1][3] += P.t & m0;
                 const uint32_t e0 = qa & 0x00FF00FFu, o0 = (qa >> 8) & 0x00FF00FFu, e1 = qb & 0x00FF00FFu, o1 = (qb >> 8) & 0x00FF00FFu;
                 A.q[0][0] += e0; A.q[0][1] += o0; A.q[0][2] += e1; A.q[0][3] += o1;
                 A.q[1][0] += e0 & m0; A.q[1][1] += o0 & m0; A.q[1][2] += e1 & m0; A.q[1][3] += o1 & m0;
                 ++A.n1; ++A.n2;
                 if (A.n1 == 15u) cyc_spill(A);
                 if (A.n2 == 255u) cyc_flush(A, lds, w);
+                // cycles holding anything but A/C/G/T (Dna5 'N' bin) are rare: counted directly
+                uint32_t other = nv ? (0x11111111u & (0xFFFFFFFFu << (4u * (8u - nv))) & ~P.oh) : 0u;
+                while (other) {
+                    const uint32_t bit = (uint32_t)__ffs((int)other) - 1u;
+                    other &= other - 1u;
+                    const uint32_t cy = 8u * w + 7u - (bit >> 2);
+                    atomicAdd(&lds[KS_CYC + 4 * KS_CT + cy], 1u);
+                    if (mate == 0) atomicAdd(&lds[KS_CYC + 6 * KS_CT + 4 * KS_CT + cy], 1u);
+                }
             }
             // ---- per-read sums: N count, GC count, quality sum (segmented reduction over the W lanes of a slot)
-            {
+            if (parts & 1u) {
                 uint32_t v1 = __builtin_amdgcn_sad_u8(qa, 0u, 0u) + __builtin_amdgcn_sad_u8(qb, 0u, 0u);
                 uint32_t v2 = (uint32_t)__popc(P.n) | ((uint32_t)__popc(P.c | P.g) << 16);
                 for (uint32_t d = 1; d < W; d <<= 1) {
@@ -364,7 +417,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             // ---- 8-mers: windows starting at cycles 8w .. 8w+7
             const uint32_t cn = (P.c | P.t) | ((P.g | P.t) << 1);  // 2-bit code per nibble; non-ACGT -> A (char -> Dna after RC)
             const uint32_t c16 = squeeze2(cn);
-            {
+            if (parts & 2u) {
                 uint32_t n8 = squeeze1(P.n) | (nv < 8u ? (0xFFu >> nv) : 0u); // literal N or past the end blocks a window
                 uint32_t cx = (uint32_t)__shfl_down((int)c16, 1), nx = (uint32_t)__shfl_down((int)n8, 1);
                 if (w + 1u >= W || ln == 63u) { cx = 0; nx = 0xFFu; }
@@ -381,11 +434,11 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 }
             }
             // ---- triplets (BAM orientation, single-operation CIGAR: chromPos = pos + i)
-            if (__ballot(trip)) {
+            if ((parts & 4u) && __ballot(trip)) {
                 uint32_t Xf = X, c16f = c16;
                 Planes F = P;
                 if (rc) { // forward-orientation dword
-                    Xf = (lane_used && w < nd) ? SEQ[1 + w] : 0u;
+                    Xf = nv ? SEQ[1 + w] : 0u;
                     F = planes_of(Xf);
                     c16f = squeeze2((F.c | F.t) | ((F.g | F.t) << 1));
                 }
@@ -394,7 +447,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 uint32_t Zp = (uint32_t)__shfl_up((int)Z, 1), Zn = (uint32_t)__shfl_down((int)Z, 1);
                 if (w == 0) Zp = 0;
                 if (w + 1u >= W || ln == 63u) Zn = 0;
-                if (trip && w < nd) {
+                if (trip && nv) {
                     const uint32_t ZL = alignbit(Zp, Z, 4), ZR = alignbit(Z, Zn, 28);           // neighbours i-1 / i+1
                     const uint32_t r0 = REFN[w], r1 = REFN[1 + w], r2 = REFN[2 + w];
                     const uint32_t RL = alignbit(r0, r1, 4), RR = alignbit(r1, r2, 28);
@@ -402,7 +455,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     u |= u >> 1; u |= u >> 2;
                     uint32_t cm = ~u & F.oh;                                                     // flanks match, base is A/C/G/T
                     // positions 1 <= i <= L-2, and i < n0 when the single CIGAR op is shorter than the read
-                    n0 = b.cigar[b.cigar_off[r]] >> 4;
+                    const uint32_t n0 = M[6];
                     uint32_t lim = L - 1u;
                     if (n0 != 0u && n0 < lim) lim = n0;
                     const uint32_t cnt = lim > 8u * w ? min(8u, lim - 8u * w) : 0u;
@@ -424,8 +477,10 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier(); // the tile is rewritten by the next group
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the tile is rewritten by the next group
+            __builtin_amdgcn_wave_barrier();
         }
+        __syncthreads(); // META is rewritten by the next chunk
     }
     if (cur_lane != 0xFFFFFFFFu) {
         if (lane_used) cyc_flush(A, lds, w);
@@ -462,5 +517,7 @@ extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint6
 {
     if (b.n_chunks_fast == 0) return;
     if (grid > b.n_chunks_fast) grid = b.n_chunks_fast;
-    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err);
+    static uint32_t parts = 0xFFFFFFFFu; // BQC_SHORT_PARTS: ablation switch for profiling (1 cycles, 2 8-mers, 4 triplets, 8 per-read)
+    if (parts == 0xFFFFFFFFu) { const char* e = getenv("BQC_SHORT_PARTS"); parts = e ? (uint32_t)atoi(e) : 15u; }
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, parts);
 }

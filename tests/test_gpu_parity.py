@@ -199,7 +199,7 @@ def test_reset_and_device_resident_reprocess():
         a.process(db)
     a.sync()
     t = a.last_timing()
-    assert "k_bases" in t and t["k_bases"] > 0
+    assert "k_short" in t and t["k_short"] > 0
     a.reset()
     a.process(db)
     cg = a.finalize()
