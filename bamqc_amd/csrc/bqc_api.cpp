@@ -581,7 +581,10 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
     DevBatch slow = db->d; // generic kernels see only the reads that are not on the fast path
     if (db->d.n_chunks_fast) {
-        // k_short does the per-read statistics of its own chunks; k_reads would double count them
+        DevBatch fr = db->d; // per-read statistics of the fast chunks
+        fr.chunks = db->d.chunks_fast; fr.n_chunks = db->d.n_chunks_fast;
+        bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
+        tick(c, "k_reads");
         bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
         tick(c, "k_short");
         if (db->d.n_trip_chunks) {
@@ -593,7 +596,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     }
     if (slow.n_chunks) {
         bqc_launch_reads_chunks(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
-        tick(c, "k_reads");
+        tick(c, "k_reads(generic)");
         if (c->bases_variant == 0) {
             bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);
             tick(c, "k_bases");

@@ -19,9 +19,8 @@
 //              detection on 8 positions at once; context index from a 2-bit reference stream
 //              (TripletCounting.hpp:195-236).  Reads whose CIGAR has more than one operation go to
 //              the generic kernel (k_bases_generic.hip).
-//   per-read   flag cascade / histograms by thread-per-read at the start of every chunk (read_stats.h).
+//   per-read   flag cascade / histograms stay in k_reads (k_reads.hip), launched over the same chunks.
 #include "kernels_common.h"
-#include "read_stats.h"
 
 #ifndef KS_THREADS
 #define KS_THREADS 1024
@@ -36,12 +35,11 @@
 #define KS_GC    (KS_NC + 2 * (KS_CT + 1))
 #define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
 #define KS_AC    (KS_AQ + 512)
-#define KS_RS    (KS_AC + 512)                     // read_stats counters
-#define KS_STAGE (KS_RS + RS_WORDS)                // per-wave staging tiles
+#define KS_STAGE (KS_AC + 512)                     // per-wave staging tiles
 #define KS_WS    384                               // words per wave: rpw * (5W + 10) <= 360 for 10 <= W <= 32
 #define KS_META  (KS_STAGE + KS_WAVES * KS_WS)      // per-read records of the current chunk
 #define KS_CHUNK 1008
-#define KS_MW    7                                 // flag|ncig<<16, L, seq_off, qual_off, pos, rid, n0
+#define KS_MW    9                                 // flags, L, seq_off, qual_off, pos, n0, ref limit, refn pointer (2)
 #define KS_WORDS (KS_META + KS_CHUNK * KS_MW)
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
@@ -90,7 +88,7 @@ __device__ __noinline__ void t8_wrap(uint64_t* __restrict__ em, uint32_t h, uint
     }
 }
 
-__device__ __noinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
+__device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
 {
     const uint64_t lb = sl.lane_base(lane);
     for (uint32_t i = threadIdx.x; i < 65536; i += blockDim.x) {
@@ -132,7 +130,6 @@ __device__ __noinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint
         if (v) gadd(state + mb + sl.m_avgceil + (i & 255), v);
         lds[KS_AC + i] = 0;
     }
-    rs_flush(lds + KS_RS, sl, state, lane);
 }
 
 // bit-sliced per-cycle counters of one lane (cycle group w of its slot)
@@ -202,11 +199,52 @@ __device__ __forceinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t w)
     cyc_zero(A);
 }
 
+// explicit global-address-space loads: pointers that were themselves loaded from memory (refs.refn[rid]) are generic to
+// the compiler, and generic (flat) loads count on lgkmcnt too, which would make every LDS wait also wait for the prefetch
+typedef const __attribute__((address_space(1))) uint32_t* g_u32p;
+typedef const __attribute__((address_space(1))) uint8_t* g_u8p;
+__device__ __forceinline__ uint32_t gld32(const uint32_t* p) { return *(g_u32p)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t gld8(const uint8_t* p) { return *(g_u8p)(uintptr_t)p; }
+
 struct Pre { uint32_t sv, q0, q1, d0, d1, e0; }; // raw dwords of the NEXT group, in flight while the current one is computed
 
-__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-endian dword (merged into one global_load_dword)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-endian dword: one global_load_dword
 {
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    return *(const __attribute__((address_space(1))) u32_unaligned*)(uintptr_t)p;
+}
+
+// record of one read in the chunk's LDS table (written by phase A)
+#define KM_PRIM   0x10000u   // primary record with first/last flag: reaches get_count / count8mers
+#define KM_TRIP   0x20000u   // triplet-eligible with a single CIGAR operation and a loaded reference
+// word 0: BAM flag (low 16 bits) | KM_*, 1: L, 2: seq_off, 3: qual_off, 4: pos, 5: n0, 6: contig length + 8 (saturated),
+// 7-8: pointer to the contig's nibble table
+
+// issue the global loads of group g for this lane (meta comes from the chunk's LDS records)
+__device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, bool in_chunk, uint32_t w, const uint8_t* seq,
+                                           const uint8_t* qual)
+{
+    Pre P{0, 0, 0, 0, 0, 0};
+    if (!in_chunk) return P;
+    const uint32_t* M = META + k * KS_MW;
+    const uint32_t m0 = M[0], L = M[1];
+    if (!(m0 & KM_PRIM) || 8u * w >= L) return P;
+    P.sv = ld32u(seq + M[2] + 4u * w);
+    if (!(m0 & BQC_FLAG_NO_QUAL)) {
+        const uint8_t* qp = qual + M[3] + 8u * w;
+        P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
+    }
+    if (m0 & KM_TRIP) {
+        const uint32_t pos = M[4];
+        const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)M[7] | ((uint64_t)M[8] << 32));
+        const uint64_t p8 = (uint64_t)pos + 8u * w; // pos >= 0 for fast-path triplet reads (host)
+        if (p8 < (uint64_t)M[6]) {                   // else: past the contig -> zero nibbles, nothing matches
+            const uint64_t di = p8 >> 3;
+            P.d0 = gld32(rn + di); P.d1 = gld32(rn + di + 1);
+            if (w == 0) P.e0 = pos >= 8u ? gld32(rn + di - 1) : (pos > 0u ? gld32(rn) : 0u);
+        }
+    }
+    return P;
 }
 
 __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
@@ -230,35 +268,13 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     cyc_zero(A);
     uint32_t cur_lane = 0xFFFFFFFFu;
 
-    // issue the global loads of group g for this lane (meta comes from the chunk's LDS records)
-    auto prefetch = [&](uint32_t g, uint32_t count) -> Pre {
-        Pre P{0, 0, 0, 0, 0, 0};
-        const uint32_t k = g * rpw + slot;
-        if (!(lane_used && k < count)) return P;
-        const uint32_t* M = META + k * KS_MW;
-        const uint32_t fl = M[0] & 0xFFFFu, nc = M[0] >> 16, L = M[1];
-        const bool prim = !(fl & 0x900u) && (fl & 0xC0u);
-        if (!prim || 8u * w >= L) return P;
-        P.sv = ld32u(b.seq + M[2] + 4u * w);
-        if (!(fl & BQC_FLAG_NO_QUAL)) {
-            const uint8_t* qp = b.qual + M[3] + 8u * w;
-            P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
-        }
-        const int32_t rid = (int32_t)M[5];
-        if ((parts & 4u) && (fl & BQC_FLAG_TRIPLET) && nc == 1 && L >= 3 && !(fl & BQC_FLAG_NO_QUAL) && rid >= 0 && (uint32_t)rid < refs.n_refs) {
-            const uint32_t* rn = refs.refn[rid];
-            const uint64_t p8 = (uint64_t)M[4] + 8u * w; // pos >= 0 for fast-path triplet reads (host)
-            if (rn && p8 < refs.len[rid] + 8u) {          // else: past the contig -> zero nibbles, nothing matches
-                const uint64_t di = p8 >> 3;
-                P.d0 = rn[di]; P.d1 = rn[di + 1];
-                if (w == 0) P.e0 = M[4] >= 8u ? rn[di - 1] : (M[4] > 0u ? rn[0] : 0u);
-            }
-        }
-        return P;
-    };
-
-    for (uint32_t ci = blockIdx.x; ci < b.n_chunks_fast; ci += gridDim.x) {
-        const Chunk ch = b.chunks_fast[ci];
+    const uint8_t* const g_seq = b.seq;
+    const uint8_t* const g_qual = b.qual;
+    const uint32_t n_chunks = b.n_chunks_fast;
+    for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane (single call site)
+        const bool done = ci >= n_chunks;
+        Chunk ch{0, 0, 0xFFFFFFFFu, 0};
+        if (!done) ch = b.chunks_fast[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
                 if (lane_used) cyc_flush(A, lds, w);
@@ -268,43 +284,51 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             }
             cur_lane = ch.lane;
         }
+        if (done) break;
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
-        // ---- phase A: thread per read — per-read statistics, and the read's record for phase B into LDS
-        for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
-            const uint32_t t = t0 + threadIdx.x;
-            const bool live = t < ch.count;
-            const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
-            if (live) {
-                const uint32_t fl = b.flag[r], nc = b.n_cigar[r];
-                uint32_t* M = META + t * KS_MW;
-                M[0] = fl | (nc << 16); M[1] = b.l_seq[r]; M[2] = b.seq_off[r]; M[3] = b.qual_off[r];
-                M[4] = (uint32_t)b.pos[r]; M[5] = (uint32_t)b.rid[r];
-                M[6] = ((fl & BQC_FLAG_TRIPLET) && nc == 1) ? (b.cigar[b.cigar_off[r]] >> 4) : 0u;
+        // ---- phase A: thread per read — the read's record for phase B into LDS
+        for (uint32_t t = threadIdx.x; t < ch.count; t += blockDim.x) {
+            const uint32_t r = b.perm ? b.perm[ch.first + t] : ch.first + t;
+            const uint32_t fl = b.flag[r], nc = b.n_cigar[r], L = b.l_seq[r];
+            const int32_t rid = b.rid[r];
+            uint32_t m0 = fl & 0xFFFFu;
+            if (!(fl & 0x900u) && (fl & 0xC0u)) m0 |= KM_PRIM;
+            uint32_t n0 = 0, lim = 0;
+            uint64_t rn = 0;
+            if ((m0 & KM_PRIM) && (fl & BQC_FLAG_TRIPLET) && nc == 1 && L >= 3 && !(fl & BQC_FLAG_NO_QUAL) && rid >= 0 &&
+                (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr) {
+                m0 |= KM_TRIP;
+                n0 = b.cigar[b.cigar_off[r]] >> 4;
+                rn = (uint64_t)(uintptr_t)refs.refn[rid];
+                const uint64_t l8 = refs.len[rid] + 8u;
+                lim = l8 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l8;
             }
-            if ((parts & 8u) && __ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, r, live, live);
+            uint32_t* M = META + t * KS_MW;
+            M[0] = m0; M[1] = L; M[2] = b.seq_off[r]; M[3] = b.qual_off[r]; M[4] = (uint32_t)b.pos[r]; M[5] = n0; M[6] = lim;
+            M[7] = (uint32_t)rn; M[8] = (uint32_t)(rn >> 32);
         }
         __syncthreads();
         // ---- phase B: groups of rpw reads per wave; the next group's data is loaded while this one is processed
         const uint32_t n_groups = (ch.count + rpw - 1) / rpw;
-        Pre nxt = wave < n_groups ? prefetch(wave, ch.count) : Pre{0, 0, 0, 0, 0, 0};
+        Pre nxt = ks_prefetch(META, wave * rpw + slot, lane_used && wave * rpw + slot < ch.count, w, g_seq, g_qual);
         for (uint32_t g = wave; g < n_groups; g += KS_WAVES) {
             const Pre cur = nxt;
-            if (g + KS_WAVES < n_groups) nxt = prefetch(g + KS_WAVES, ch.count);
+            {
+                const uint32_t kn = (g + KS_WAVES) * rpw + slot;
+                nxt = ks_prefetch(META, kn, lane_used && kn < ch.count, w, g_seq, g_qual);
+            }
             const uint32_t k = g * rpw + slot;
             const bool have = lane_used && k < ch.count;
             const uint32_t* M = META + (have ? k : 0u) * KS_MW;
-            uint32_t flag = 0x900u, L = 0, ncig = 0;
-            int32_t rid = -1;
-            uint32_t pos = 0;
-            if (have) { flag = M[0] & 0xFFFFu; ncig = M[0] >> 16; L = M[1]; pos = M[4]; rid = (int32_t)M[5]; }
-            const bool prim = have && !(flag & 0x900u) && (flag & 0xC0u); // records that reach get_count / count8mers
+            uint32_t flag = 0, L = 0, pos = 0;
+            if (have) { flag = M[0]; L = M[1]; pos = M[4]; }
+            const bool prim = flag & KM_PRIM; // records that reach get_count / count8mers
             if (!prim) L = 0;
             const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
             const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
             const uint32_t nd = (L + 7u) >> 3;           // dwords / cycle groups of this read
-            const bool trip = (parts & 4u) && prim && (flag & BQC_FLAG_TRIPLET) && ncig == 1 && L >= 3 && !noqual && rid >= 0 &&
-                              (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
+            const bool trip = (parts & 4u) && (flag & KM_TRIP);
             const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u; // valid cycles of this lane
             // ---------------- staging (registers -> LDS tile of this wave), with the tails masked to zero
             if (lane_used) {
@@ -349,8 +373,10 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     }
                 }
             }
-            // LDS operations of one wave execute in order; the fence only stops the compiler from moving them
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // LDS operations of one wave execute in order, so other lanes' ds_writes above are visible to the ds_reads
+            // below; only the COMPILER must not reorder them.  (A fence or volatile accesses would insert
+            // s_waitcnt vmcnt(0) and so wait for the prefetch loads that were just issued.)
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 
             // ---------------- sequencing-orientation dword X (cycles 8w .. 8w+7)
@@ -455,7 +481,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     u |= u >> 1; u |= u >> 2;
                     uint32_t cm = ~u & F.oh;                                                     // flanks match, base is A/C/G/T
                     // positions 1 <= i <= L-2, and i < n0 when the single CIGAR op is shorter than the read
-                    const uint32_t n0 = M[6];
+                    const uint32_t n0 = M[5];
                     uint32_t lim = L - 1u;
                     if (n0 != 0u && n0 < lim) lim = n0;
                     const uint32_t cnt = lim > 8u * w ? min(8u, lim - 8u * w) : 0u;
@@ -477,15 +503,10 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the tile is rewritten by the next group
+            asm volatile("" ::: "memory"); // the tile is rewritten by the next group
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads(); // META is rewritten by the next chunk
-    }
-    if (cur_lane != 0xFFFFFFFFu) {
-        if (lane_used) cyc_flush(A, lds, w);
-        __syncthreads();
-        ks_flush(lds, sl, state, cur_lane);
     }
 }
 

@@ -36,7 +36,7 @@ __device__ __forceinline__ void rs_hist(bool pred, bool use_lds, uint32_t bin, u
     wave_inc(pred && !in_lds, g_base + bin);
 }
 
-__device__ __noinline__ void read_stats(const DevBatch& b, const StateLayout& sl, uint64_t* __restrict__ state, const DevRefs& refs,
+__device__ __forceinline__ void read_stats(const DevBatch& b, const StateLayout& sl, uint64_t* __restrict__ state, const DevRefs& refs,
                                            uint32_t* __restrict__ err, uint32_t* lds, uint32_t r, bool live, bool use_lds)
 {
     uint32_t flag = 0, L = 0, mapq = 0, ncig = 0, lane = 0;
