@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
     const uint32_t* cin = carry + ((uint64_t)t.lane * 2 + par) * 2000;
     uint32_t* cout = carry + ((uint64_t)t.lane * 2 + (par ^ 1u)) * 2000;
     int32_t run = off;
+    uint32_t run_bin = 0xFFFFFFFFu, run_n = 0; // consecutive positions mostly share a depth: one LDS atomic per run
     for (uint32_t j = 0; j < per; ++j) {
         const uint32_t p = s0 + j;
         if (p >= BQC_COV_TILE) break;
@@ -73,9 +74,13 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         uint32_t depth = (uint32_t)run;
         if (vp < 2 * BQC_VSIZE) depth += cin[vp]; // partial windows carried over from the previous batch
         const uint32_t win = t.win_lo + p / BQC_VSIZE;
-        if (win < t.win_final) atomicAdd(&hist[depth > BQC_COVSIZE ? BQC_COVSIZE : depth], 1u); // update_coverage :66-77
-        else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
+        if (win < t.win_final) { // update_coverage :66-77
+            const uint32_t bin = depth > BQC_COVSIZE ? BQC_COVSIZE : depth;
+            if (bin == run_bin) ++run_n;
+            else { if (run_n) atomicAdd(&hist[run_bin], run_n); run_bin = bin; run_n = 1; }
+        } else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
     }
+    if (run_n) atomicAdd(&hist[run_bin], run_n);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
         if (hist[i]) gadd(state + sl.lane_base(t.lane) + sl.o_poscov + i, hist[i]);

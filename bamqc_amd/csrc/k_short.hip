@@ -39,13 +39,33 @@
 #define KS_WS    384                               // words per wave: rpw * (5W + 10) <= 360 for 10 <= W <= 32
 #define KS_META  (KS_STAGE + KS_WAVES * KS_WS)      // per-read records of the current chunk
 #define KS_CHUNK 1008
-#define KS_MW    9                                 // flags, L, seq_off, qual_off, pos, n0, ref limit, refn pointer (2)
+#define KS_MW    8                                 // flags|L<<20, pos, n0, ref limit | seq_off, qual_off, refn pointer (2)
 #define KS_WORDS (KS_META + KS_CHUNK * KS_MW)
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(x, off, w); }
+
+// cross-lane moves on the VALU (DPP) instead of ds_bpermute: no LDS round trip
+__device__ __forceinline__ uint32_t lane_next(uint32_t x) // value of lane + 1 (0 for lane 63)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) // value of lane - 1 (0 for lane 0)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) // inclusive prefix sum over the 64 lanes
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return v;
+}
 
 // 8 nibble-spaced 2-bit values (bits [1:0] of every nibble) -> 16 contiguous bits, first nibble on top
 __device__ __forceinline__ uint32_t squeeze2(uint32_t c)
@@ -217,8 +237,8 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-
 // record of one read in the chunk's LDS table (written by phase A)
 #define KM_PRIM   0x10000u   // primary record with first/last flag: reaches get_count / count8mers
 #define KM_TRIP   0x20000u   // triplet-eligible with a single CIGAR operation and a loaded reference
-// word 0: BAM flag (low 16 bits) | KM_*, 1: L, 2: seq_off, 3: qual_off, 4: pos, 5: n0, 6: contig length + 8 (saturated),
-// 7-8: pointer to the contig's nibble table
+// word 0: BAM flag (low 16 bits) | KM_* | L << 20, 1: pos, 2: n0, 3: contig length + 8 (saturated),
+// 4: seq_off, 5: qual_off, 6-7: pointer to the contig's nibble table
 
 // issue the global loads of group g for this lane (meta comes from the chunk's LDS records)
 __device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, bool in_chunk, uint32_t w, const uint8_t* seq,
@@ -226,19 +246,19 @@ __device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, boo
 {
     Pre P{0, 0, 0, 0, 0, 0};
     if (!in_chunk) return P;
-    const uint32_t* M = META + k * KS_MW;
-    const uint32_t m0 = M[0], L = M[1];
+    const uint4 ma = *(const uint4*)(META + k * KS_MW), mb = *(const uint4*)(META + k * KS_MW + 4);
+    const uint32_t m0 = ma.x, L = m0 >> 20;
     if (!(m0 & KM_PRIM) || 8u * w >= L) return P;
-    P.sv = ld32u(seq + M[2] + 4u * w);
+    P.sv = ld32u(seq + mb.x + 4u * w);
     if (!(m0 & BQC_FLAG_NO_QUAL)) {
-        const uint8_t* qp = qual + M[3] + 8u * w;
+        const uint8_t* qp = qual + mb.y + 8u * w;
         P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
     }
     if (m0 & KM_TRIP) {
-        const uint32_t pos = M[4];
-        const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)M[7] | ((uint64_t)M[8] << 32));
+        const uint32_t pos = ma.y;
+        const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)mb.z | ((uint64_t)mb.w << 32));
         const uint64_t p8 = (uint64_t)pos + 8u * w; // pos >= 0 for fast-path triplet reads (host)
-        if (p8 < (uint64_t)M[6]) {                   // else: past the contig -> zero nibbles, nothing matches
+        if (p8 < (uint64_t)ma.w) {                   // else: past the contig -> zero nibbles, nothing matches
             const uint64_t di = p8 >> 3;
             P.d0 = gld32(rn + di); P.d1 = gld32(rn + di + 1);
             if (w == 0) P.e0 = pos >= 8u ? gld32(rn + di - 1) : (pos > 0u ? gld32(rn) : 0u);
@@ -304,9 +324,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint64_t l8 = refs.len[rid] + 8u;
                 lim = l8 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l8;
             }
-            uint32_t* M = META + t * KS_MW;
-            M[0] = m0; M[1] = L; M[2] = b.seq_off[r]; M[3] = b.qual_off[r]; M[4] = (uint32_t)b.pos[r]; M[5] = n0; M[6] = lim;
-            M[7] = (uint32_t)rn; M[8] = (uint32_t)(rn >> 32);
+            uint4* M = (uint4*)(META + t * KS_MW);
+            M[0] = make_uint4(m0 | (L << 20), (uint32_t)b.pos[r], n0, lim);
+            M[1] = make_uint4(b.seq_off[r], b.qual_off[r], (uint32_t)rn, (uint32_t)(rn >> 32));
         }
         __syncthreads();
         // ---- phase B: groups of rpw reads per wave; the next group's data is loaded while this one is processed
@@ -320,9 +340,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             }
             const uint32_t k = g * rpw + slot;
             const bool have = lane_used && k < ch.count;
-            const uint32_t* M = META + (have ? k : 0u) * KS_MW;
-            uint32_t flag = 0, L = 0, pos = 0;
-            if (have) { flag = M[0]; L = M[1]; pos = M[4]; }
+            uint32_t flag = 0, L = 0, pos = 0, n0 = 0;
+            if (have) { const uint4 ma = *(const uint4*)(META + k * KS_MW); flag = ma.x; L = ma.x >> 20; pos = ma.y; n0 = ma.z; }
             const bool prim = flag & KM_PRIM; // records that reach get_count / count8mers
             if (!prim) L = 0;
             const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
@@ -421,16 +440,16 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     if (mate == 0) atomicAdd(&lds[KS_CYC + 6 * KS_CT + 4 * KS_CT + cy], 1u);
                 }
             }
-            // ---- per-read sums: N count, GC count, quality sum (segmented reduction over the W lanes of a slot)
+            // ---- per-read sums: N count, GC count, quality sum.  Wave-wide inclusive scans on the VALU; the total of a
+            //      slot is the scan value at its last lane minus the one at the previous slot's last lane.
             if (parts & 1u) {
-                uint32_t v1 = __builtin_amdgcn_sad_u8(qa, 0u, 0u) + __builtin_amdgcn_sad_u8(qb, 0u, 0u);
-                uint32_t v2 = (uint32_t)__popc(P.n) | ((uint32_t)__popc(P.c | P.g) << 16);
-                for (uint32_t d = 1; d < W; d <<= 1) {
-                    const uint32_t t1 = (uint32_t)__shfl_down((int)v1, d), t2 = (uint32_t)__shfl_down((int)v2, d);
-                    if (w + d < W) { v1 += t1; v2 += t2; }
-                }
+                const uint32_t s1 = wave_scan_incl(__builtin_amdgcn_sad_u8(qa, 0u, 0u) + __builtin_amdgcn_sad_u8(qb, 0u, 0u));
+                const uint32_t s2 = wave_scan_incl((uint32_t)__popc(P.n) | ((uint32_t)__popc(P.c | P.g) << 16)); // <= 64*8 per field
+                const uint32_t last = (slot + 1u) * W - 1u;                    // last lane of this slot (< 64 for used lanes)
+                const uint32_t e1 = (uint32_t)__shfl((int)s1, (int)(last & 63u)), e2 = (uint32_t)__shfl((int)s2, (int)(last & 63u));
+                const uint32_t b1 = lane_prev(s1), b2 = lane_prev(s2);         // scan value just before this lane (w == 0: slot start)
                 if (prim && w == 0) {
-                    const uint32_t nN = v2 & 0xFFFFu, nGC = v2 >> 16, qs = v1;
+                    const uint32_t qs = e1 - b1, v2 = e2 - b2, nN = v2 & 0xFFFFu, nGC = v2 >> 16;
                     atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + nN], 1u);
                     atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + nGC], 1u);
                     if (L > 0) {
@@ -444,18 +463,30 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             const uint32_t cn = (P.c | P.t) | ((P.g | P.t) << 1);  // 2-bit code per nibble; non-ACGT -> A (char -> Dna after RC)
             const uint32_t c16 = squeeze2(cn);
             if (parts & 2u) {
-                uint32_t n8 = squeeze1(P.n) | (nv < 8u ? (0xFFu >> nv) : 0u); // literal N or past the end blocks a window
-                uint32_t cx = (uint32_t)__shfl_down((int)c16, 1), nx = (uint32_t)__shfl_down((int)n8, 1);
+                const uint32_t n8 = squeeze1(P.n) | (nv < 8u ? (0xFFu >> nv) : 0u); // literal N or past the end blocks a window
+                uint32_t cx = lane_next(c16), nx = lane_next(n8);
                 if (w + 1u >= W || ln == 63u) { cx = 0; nx = 0xFFu; }
                 const uint32_t c32 = (c16 << 16) | cx, n16 = (n8 << 8) | nx;
                 if (nv) {
+                    uint32_t old[8];
+                    uint32_t ovf = 0;
 #pragma unroll
-                    for (int kw = 0; kw < 8; ++kw) {
+                    for (int kw = 0; kw < 8; ++kw) { // issue all returning atomics first, look at the old values afterwards
+                        old[kw] = 0;
                         if (bfe(n16, 8 - kw, 8) == 0u) {
                             const uint32_t h = bfe(c32, 16 - 2 * kw, 16);
-                            const uint32_t old = atomicAdd(&lds[KS_T8 + (h >> 2)], 1u << (8u * (h & 3u)));
-                            if (((old >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) t8_wrap(em, h, old);
+                            old[kw] = atomicAdd(&lds[KS_T8 + (h >> 2)], 1u << (8u * (h & 3u)));
                         }
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 8; ++kw) {
+                        const uint32_t h = bfe(c32, 16 - 2 * kw, 16);
+                        ovf |= (((old[kw] >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) ? (1u << kw) : 0u; // old == 0 for skipped windows
+                    }
+                    if (ovf) { // rare: some packed u8 counter wrapped
+#pragma unroll
+                        for (int kw = 0; kw < 8; ++kw)
+                            if ((ovf >> kw) & 1u) t8_wrap(em, bfe(c32, 16 - 2 * kw, 16), old[kw]);
                     }
                 }
             }
@@ -470,7 +501,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 }
                 // canonical nibbles: one-hot kept, literal N -> 0 (never matches), other -> A (char -> Dna)
                 const uint32_t Z = (Xf & (F.oh * 15u)) | (0x11111111u & ~F.oh & ~F.n & (nv ? 0xFFFFFFFFu : 0u));
-                uint32_t Zp = (uint32_t)__shfl_up((int)Z, 1), Zn = (uint32_t)__shfl_down((int)Z, 1);
+                uint32_t Zp = lane_prev(Z), Zn = lane_next(Z);
                 if (w == 0) Zp = 0;
                 if (w + 1u >= W || ln == 63u) Zn = 0;
                 if (trip && nv) {
@@ -481,7 +512,6 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     u |= u >> 1; u |= u >> 2;
                     uint32_t cm = ~u & F.oh;                                                     // flanks match, base is A/C/G/T
                     // positions 1 <= i <= L-2, and i < n0 when the single CIGAR op is shorter than the read
-                    const uint32_t n0 = M[5];
                     uint32_t lim = L - 1u;
                     if (n0 != 0u && n0 < lim) lim = n0;
                     const uint32_t cnt = lim > 8u * w ? min(8u, lim - 8u * w) : 0u;
