@@ -30,6 +30,7 @@ void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevR
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_kernels_init();
 hipError_t bqc_short_init();
+void bqc_launch_trip_list(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t n_cu, hipStream_t);
 }
 
 static thread_local char g_create_err[512];
@@ -395,7 +396,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         uint32_t ts = 0, tc = 0, tl = 0, tb = 0;
         for (uint32_t k = 0; k < P.trip_list.size(); ++k) {
             const uint32_t r = P.trip_list[k], lane = b->lane[r], L = b->l_seq[r];
-            if (tc && (lane != tl || tc == BQC_CHUNK_READS || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0}); tc = 0; tb = 0; }
+            if (tc && (lane != tl || tc == 32u || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0}); tc = 0; tb = 0; }
             if (!tc) { ts = k; tl = lane; }
             ++tc; tb += L;
         }
@@ -588,10 +589,8 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
         bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
         tick(c, "k_short");
         if (db->d.n_trip_chunks) {
-            DevBatch t = db->d;
-            t.perm = db->d.trip_list; t.chunks = db->d.trip_chunks; t.n_chunks = db->d.n_trip_chunks;
-            bqc_launch_bases(t, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
-            tick(c, "k_bases<trip>");
+            bqc_launch_trip_list(db->d, c->sl, c->d_state, refs, c->n_cu, c->stream);
+            tick(c, "k_trip_list");
         }
     }
     if (slow.n_chunks) {

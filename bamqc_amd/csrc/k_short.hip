@@ -344,34 +344,23 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             if (have) { const uint4 ma = *(const uint4*)(META + k * KS_MW); flag = ma.x; L = ma.x >> 20; pos = ma.y; n0 = ma.z; }
             const bool prim = flag & KM_PRIM; // records that reach get_count / count8mers
             if (!prim) L = 0;
-            const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
+            const bool rc = flag & 0x10u;
             const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
             const uint32_t nd = (L + 7u) >> 3;           // dwords / cycle groups of this read
             const bool trip = (parts & 4u) && (flag & KM_TRIP);
             const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u; // valid cycles of this lane
             // ---------------- staging (registers -> LDS tile of this wave), with the tails masked to zero
             if (lane_used) {
-                uint32_t sv = 0, q0 = 0, q1 = 0;
-                if (nv) {
-                    const uint32_t sb = (L + 1u) >> 1; // packed bytes
-                    uint32_t v = cur.sv;
-                    const uint32_t nb = min(4u, sb - 4u * w);
-                    if (nb < 4u) v &= (1u << (8u * nb)) - 1u;
-                    sv = bswap32(v); // big-endian: base 8w in the top nibble
-                    if (nv < 8u) sv &= 0xFFFFFFFFu << (4u * (8u - nv)); // clear the padding nibble of an odd-length read
-                    if (!noqual) {
-                        q0 = cur.q0; q1 = cur.q1;
-                        if (nv < 8u) {
-                            if (nv <= 4u) { q1 = 0; if (nv < 4u) q0 &= (1u << (8u * nv)) - 1u; }
-                            else q1 &= (1u << (8u * (nv - 4u))) - 1u;
-                        }
-                        if ((q0 | q1) & 0x80808080u) { // some Phred >= 128: check the 222 limit precisely
-                            bool bad = false;
+                // the prefetch returns zeros for lanes without data; only the tail dword of a read needs masking:
+                // keep the top nv nibbles (also clears the pad nibble of an odd-length read) / the low nv quality bytes
+                const uint32_t sv = nv ? (bswap32(cur.sv) & (0xFFFFFFFFu << (4u * (8u - nv)))) : 0u; // big-endian: base 8w on top
+                const uint64_t qm = nv >= 8u ? ~0ull : ((1ull << (8u * nv)) - 1ull);
+                const uint32_t q0 = cur.q0 & (uint32_t)qm, q1 = cur.q1 & (uint32_t)(qm >> 32);
+                if ((q0 | q1) & 0x80808080u) { // some Phred >= 128: check the 222 limit precisely
+                    bool bad = false;
 #pragma unroll
-                            for (int k8 = 0; k8 < 4; ++k8) bad |= ((q0 >> (8 * k8)) & 0xFFu) > 222u || ((q1 >> (8 * k8)) & 0xFFu) > 222u;
-                            if (bad) atomicOr(err, BQC_DEVERR_QUAL);
-                        }
-                    }
+                    for (int k8 = 0; k8 < 4; ++k8) bad |= ((q0 >> (8 * k8)) & 0xFFu) > 222u || ((q1 >> (8 * k8)) & 0xFFu) > 222u;
+                    if (bad) atomicOr(err, BQC_DEVERR_QUAL);
                 }
                 SEQ[1 + w] = sv;
                 QUAL[2 + 2 * w] = q0;
@@ -448,15 +437,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t last = (slot + 1u) * W - 1u;                    // last lane of this slot (< 64 for used lanes)
                 const uint32_t e1 = (uint32_t)__shfl((int)s1, (int)(last & 63u)), e2 = (uint32_t)__shfl((int)s2, (int)(last & 63u));
                 const uint32_t b1 = lane_prev(s1), b2 = lane_prev(s2);         // scan value just before this lane (w == 0: slot start)
-                if (prim && w == 0) {
-                    const uint32_t qs = e1 - b1, v2 = e2 - b2, nN = v2 & 0xFFFFu, nGC = v2 >> 16;
-                    atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + nN], 1u);
-                    atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + nGC], 1u);
-                    if (L > 0) {
-                        const uint32_t rnd = (2u * qs + L) / (2u * L), cl = (qs + L - 1u) / L;
-                        atomicAdd(&lds[KS_AQ + mate * 256 + (rnd & 255u)], 1u);
-                        atomicAdd(&lds[KS_AC + mate * 256 + (cl & 255u)], 1u);
-                    }
+                if (prim && w == 0) { // keep the read's sums in its LDS record (pos / n0 are no longer needed by this lane)
+                    META[k * KS_MW + 1] = e1 - b1;  // quality sum
+                    META[k * KS_MW + 2] = e2 - b2;  // N count | GC count << 16
                 }
             }
             // ---- 8-mers: windows starting at cycles 8w .. 8w+7
@@ -536,6 +519,21 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             asm volatile("" ::: "memory"); // the tile is rewritten by the next group
             __builtin_amdgcn_wave_barrier();
         }
+        __syncthreads();
+        // ---- phase C: thread per read — per-read histograms from the sums left in the records (QualityCheck.hpp:157-165)
+        if (parts & 1u)
+            for (uint32_t t = threadIdx.x; t < ch.count; t += blockDim.x) {
+                const uint32_t m0 = META[t * KS_MW];
+                if (!(m0 & KM_PRIM)) continue;
+                const uint32_t L = m0 >> 20, qs = META[t * KS_MW + 1], v2 = META[t * KS_MW + 2];
+                const uint32_t mate = (m0 & 0x40u) ? 0u : 1u;
+                atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + (v2 & 0xFFFFu)], 1u);
+                atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + (v2 >> 16)], 1u);
+                if (L > 0) { // round-half-away and ceil of qs/L in exact integer arithmetic
+                    atomicAdd(&lds[KS_AQ + mate * 256 + (((2u * qs + L) / (2u * L)) & 255u)], 1u);
+                    atomicAdd(&lds[KS_AC + mate * 256 + (((qs + L - 1u) / L) & 255u)], 1u);
+                }
+            }
         __syncthreads(); // META is rewritten by the next chunk
     }
 }
