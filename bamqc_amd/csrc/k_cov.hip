@@ -151,3 +151,23 @@ extern "C" void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n
 {
     if (n) hipLaunchKernelGGL(k_or_bytes, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
 }
+
+// ---- profiling aid: streams `n_dwords` with 4-byte-per-lane loads (the access width of k_short's staging) so that
+// the rocprofv3 FETCH_SIZE counter can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section)
+__global__ void k_calib_read4(const uint32_t* __restrict__ p, uint64_t n_dwords, uint32_t* __restrict__ out)
+{
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords; i += (uint64_t)gridDim.x * blockDim.x) acc ^= p[i];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+extern "C" int bqc_calib_read4(uint64_t bytes, int repeat)
+{
+    uint32_t* p = nullptr;
+    uint32_t* o = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMalloc(&o, 64) != hipSuccess) return 2;
+    (void)hipMemset(p, 1, bytes);
+    for (int r = 0; r < repeat; ++r) hipLaunchKernelGGL(k_calib_read4, dim3(256 * 8), dim3(256), 0, 0, p, bytes / 4, o);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p); (void)hipFree(o);
+    return 0;
+}

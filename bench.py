@@ -99,6 +99,14 @@ def main():
         dom = max(kavg, key=kavg.get)
         peak = 8000.0  # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
         ach = abytes / (kavg[dom] * 1e-3) / 1e9
+        # HBM traffic per launch comes from rocprofv3 PMC passes (profiles/collect_r1.sh): counters cannot be read in-process
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if tj.get("kernel") == dom and args.reads == 10_000_000 and args.read_len == 150:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "BAM records/sec (and GB/s vs HBM roofline), 150 bp PE, 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -108,7 +116,8 @@ def main():
                                    % (args.reads, args.read_len),
                        "reads_per_gpu_per_step": args.reads, "parallelism": "shard by read batch; RCCL reduce of state vector at end"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
-                         "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": None,
+                         "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": traffic,
+                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 calibrated)" if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_read": abytes / args.reads,
                          "kernel_ms": kavg},
             "host": {"generate_s": t_gen, "prepass_upload_s": t_up,

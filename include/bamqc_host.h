@@ -61,6 +61,10 @@ int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_b
 int bqc_fasta_load(const char* path, uint32_t* n_records, char*** names, uint8_t*** codes, uint64_t** lens);
 void bqc_fasta_free(uint32_t n_records, char** names, uint8_t** codes, uint64_t* lens);
 
+/* Profiling aid: stream `bytes` of device memory `repeat` times with 4-byte-per-lane loads (kernel k_calib_read4),
+ * used to calibrate the rocprofv3 FETCH_SIZE counter on a known byte count. */
+int bqc_calib_read4(uint64_t bytes, int repeat);
+
 /* ---- the program: drop-in for the reference's main() (bamqualcheck.cpp:239-457) ---- */
 int bqc_main(int argc, const char** argv);
 
