@@ -363,36 +363,61 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         P.perm.resize(n);
         for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
     }
-    { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> generic (chunks)
+    { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> generic (chunks).
+      // Fast reads are additionally grouped by mate inside windows of 2016 reads (stable), so that every fast chunk is
+      // mate-uniform (k_short then updates one register set per chunk) while both chunks of a window still share L2.
         uint32_t maxfast = 0;
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
         P.fast_w = std::max(10u, (maxfast + 7) / 8); // >= 10 keeps the per-wave staging tile within its LDS budget
         const uint32_t per_pass = 16u * (64u / P.fast_w);
         const uint32_t fast_reads = (1008u / per_pass) * per_pass; // <= KS_CHUNK (k_short keeps one record per read in LDS)
+        std::vector<uint32_t> np;
+        np.reserve(n);
+        std::vector<uint32_t> win[2];
+        uint32_t wlane = 0;
+        auto flush_window = [&]() {
+            for (uint32_t m = 0; m < 2; ++m) {
+                for (size_t o = 0; o < win[m].size(); o += fast_reads) {
+                    const uint32_t cnt = (uint32_t)std::min<size_t>(fast_reads, win[m].size() - o);
+                    P.chunks_fast.push_back(Chunk{(uint32_t)np.size(), cnt, wlane, m});
+                    np.insert(np.end(), win[m].begin() + o, win[m].begin() + o + cnt);
+                }
+                win[m].clear();
+            }
+        };
         uint32_t start = 0, count = 0, bases = 0, cl = 0;
-        bool cfast = false;
-        auto close = [&]() {
-            if (!count) return;
-            (cfast ? P.chunks_fast : P.chunks).push_back(Chunk{start, count, cl, 0});
+        auto close_slow = [&]() {
+            if (count) P.chunks.push_back(Chunk{start, count, cl, 0});
             count = 0; bases = 0;
         };
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t r = P.identity ? k : P.perm[k];
             const uint32_t L = b->l_seq[r], lane = b->lane[r];
             const bool fast = !c->no_fast && L <= BQC_FAST_MAXLEN;
+            if (fast) {
+                close_slow();
+                if ((win[0].size() + win[1].size()) && lane != wlane) flush_window();
+                wlane = lane;
+                win[(P.flag[r] & 0x40u) ? 0 : 1].push_back(r);
+                if (win[0].size() + win[1].size() == 2016) flush_window();
+                // fast-path triplets assume chromPos = pos + i: reads with several CIGAR operations take the generic walk
+                if ((P.flag[r] & BQC_FLAG_TRIPLET) && (b->n_cigar[r] != 1 || b->pos[r] < 0)) P.trip_list.push_back(r);
+                continue;
+            }
+            flush_window();
             const bool huge = L > BQC_CHUNK_BASES;
-            if (count && (lane != cl || fast != cfast || count == (cfast ? fast_reads : (uint32_t)BQC_CHUNK_READS) ||
-                          (!cfast && bases + L > BQC_CHUNK_BASES) || huge))
-                close();
-            if (!count) { start = k; cl = lane; cfast = fast; }
-            if (huge) { P.chunks.push_back(Chunk{k, 1, lane, 1}); continue; }
+            if (count && (lane != cl || count == (uint32_t)BQC_CHUNK_READS || bases + L > BQC_CHUNK_BASES || huge)) close_slow();
+            if (huge) { P.chunks.push_back(Chunk{(uint32_t)np.size(), 1, lane, 1}); np.push_back(r); continue; }
+            if (!count) { start = (uint32_t)np.size(); cl = lane; }
+            np.push_back(r);
             ++count; bases += L;
-            // fast-path triplets assume chromPos = pos + i: reads with several CIGAR operations take the generic walk
-            if (fast && (P.flag[r] & BQC_FLAG_TRIPLET) && (b->n_cigar[r] != 1 || b->pos[r] < 0)) P.trip_list.push_back(r);
         }
-        close();
-        // chunks over the triplet list (already grouped by lane because it follows perm order)
+        close_slow();
+        flush_window();
+        P.perm.swap(np);
+        P.identity = false;
+        // chunks over the triplet list (grouped by lane because it follows the lane-grouped order)
         uint32_t ts = 0, tc = 0, tl = 0, tb = 0;
         for (uint32_t k = 0; k < P.trip_list.size(); ++k) {
             const uint32_t r = P.trip_list[k], lane = b->lane[r], L = b->l_seq[r];
@@ -482,7 +507,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     const size_t o_flag = cv.take(2ull * n), o_mapq = cv.take(n), o_lane = cv.take(n), o_rid = cv.take(4ull * n), o_pos = cv.take(4ull * n),
                  o_tlen = cv.take(4ull * n), o_nm = cv.take(4ull * n), o_as = cv.take(4ull * n), o_lseq = cv.take(4ull * n),
                  o_ncig = cv.take(2ull * n), o_coff = cv.take(2ull * n), o_cwin = cv.take(4ull * n), o_soff = cv.take(4ull * n),
-                 o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 16), o_qual = cv.take(P.qual_bytes + 16),
+                 o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 512), o_qual = cv.take(P.qual_bytes + 512),
                  o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * n),
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
                  o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),

@@ -21,7 +21,8 @@
 #define BQC_DEVERR_MATE  4u      // neither first nor last flag
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
-    uint32_t first, count, lane, huge; // huge: single read longer than BQC_CHUNK_BASES
+    uint32_t first, count, lane;
+    uint32_t huge; // generic chunks: 1 = single read longer than BQC_CHUNK_BASES; fast chunks: mate (0 first, 1 second)
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane

@@ -30,7 +30,7 @@
 // LDS map (uint32 words)
 #define KS_T8    0                                 // 16384: 65536 u8 8-mer counters, four per dword
 #define KS_TRIP  (KS_T8 + 16384)                   // 1024
-#define KS_CYC   (KS_TRIP + 1024)                  // [2 sets: all reads, first-mate reads][6: A C G T other qual][KS_CT]
+#define KS_CYC   (KS_TRIP + 1024)                  // [2 mates][6: A C G T other qual][KS_CT]
 #define KS_NC    (KS_CYC + 2 * 6 * KS_CT)          // [2 mates][KS_CT + 1]
 #define KS_GC    (KS_NC + 2 * (KS_CT + 1))
 #define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
@@ -40,7 +40,7 @@
 #define KS_META  (KS_STAGE + KS_WAVES * KS_WS)      // per-read records of the current chunk
 #define KS_CHUNK 1008
 #define KS_MW    8                                 // flags|L<<20, pos, n0, ref limit | seq_off, qual_off, refn pointer (2)
-#define KS_WORDS (KS_META + KS_CHUNK * KS_MW)
+#define KS_WORDS (KS_META + (KS_CHUNK + 1) * KS_MW)  // + one dummy record for lanes past the end of a chunk
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
@@ -121,15 +121,12 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
         const uint32_t v = lds[KS_TRIP + i];
         if (v) { gadd(state + lb + sl.o_triplet + i, v); lds[KS_TRIP + i] = 0; }
     }
-    // per-cycle counters: set 0 = all reads, set 1 = first-mate reads; second mate = difference
-    for (uint32_t i = threadIdx.x; i < 6 * KS_CT; i += blockDim.x) {
-        const uint32_t all = lds[KS_CYC + i], m0 = lds[KS_CYC + 6 * KS_CT + i];
-        const uint32_t c = i / KS_CT, j = i % KS_CT;
-        lds[KS_CYC + i] = 0; lds[KS_CYC + 6 * KS_CT + i] = 0;
-        if (j >= sl.lcap) continue;
-        const uint32_t off = (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j;
-        if (m0) gadd(state + sl.mate_base(lane, 0) + off, m0);
-        if (all - m0) gadd(state + sl.mate_base(lane, 1) + off, all - m0);
+    for (uint32_t i = threadIdx.x; i < 2 * 6 * KS_CT; i += blockDim.x) { // per-cycle counters [2 mates][A C G T other qual][KS_CT]
+        const uint32_t v = lds[KS_CYC + i];
+        if (!v) continue;
+        lds[KS_CYC + i] = 0;
+        const uint32_t m = i / (6 * KS_CT), c = (i / KS_CT) % 6, j = i % KS_CT;
+        if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
     }
     for (uint32_t i = threadIdx.x; i < 2 * (KS_CT + 1); i += blockDim.x) {
         const uint32_t m = i / (KS_CT + 1), j = i % (KS_CT + 1);
@@ -152,71 +149,66 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
     }
 }
 
-// bit-sliced per-cycle counters of one lane (cycle group w of its slot)
+// bit-sliced per-cycle counters of one lane (cycle group w of its slot), for the reads of ONE mate
 struct CycAcc {
-    uint32_t l1[2][4];      // 4-bit vertical counters (nibble t <-> cycle 8w + 7 - t): [set][A C G T]
-    uint32_t l2[2][4][2];   // 8-bit: [..][0] nibbles 0,2,4,6  [..][1] nibbles 1,3,5,7
-    uint32_t q[2][4];       // quality sums, 16-bit fields: [set][e0 o0 e1 o1]
-    uint32_t n1, n2;        // groups since the last level-1 spill / level-2 flush
+    uint32_t l1[4];      // 4-bit vertical counters (nibble t <-> cycle 8w + 7 - t): A C G T
+    uint32_t l2[4][2];   // 8-bit: [..][0] nibbles 0,2,4,6  [..][1] nibbles 1,3,5,7
+    uint32_t q[4];       // quality sums, 16-bit fields: e0 o0 e1 o1
 };
 
 __device__ __forceinline__ void cyc_zero(CycAcc& A)
 {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { A.l1[s][p] = 0; A.l2[s][p][0] = 0; A.l2[s][p][1] = 0; A.q[s][p] = 0; }
-    A.n1 = 0; A.n2 = 0;
+    for (int p = 0; p < 4; ++p) { A.l1[p] = 0; A.l2[p][0] = 0; A.l2[p][1] = 0; A.q[p] = 0; }
 }
 
 __device__ __forceinline__ void cyc_spill(CycAcc& A)
 {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            A.l2[s][p][0] += A.l1[s][p] & 0x0F0F0F0Fu;
-            A.l2[s][p][1] += (A.l1[s][p] >> 4) & 0x0F0F0F0Fu;
-            A.l1[s][p] = 0;
-        }
-    A.n1 = 0;
+    for (int p = 0; p < 4; ++p) {
+        A.l2[p][0] += A.l1[p] & 0x0F0F0F0Fu;
+        A.l2[p][1] += (A.l1[p] >> 4) & 0x0F0F0F0Fu;
+        A.l1[p] = 0;
+    }
 }
 
 // Rare (every 255 groups / at a lane switch): the counters are copied to a small local array and handed to a real
 // function, so that the accumulators themselves never have their address taken (which would move them to scratch).
-__device__ __noinline__ void cyc_flush_arr(const uint32_t* v, uint32_t* lds, uint32_t w)
+__device__ __noinline__ void cyc_flush_arr(const uint32_t* v, uint32_t* base /* lds + KS_CYC + mate * 6 * KS_CT */, uint32_t w)
 {
     const uint32_t c0 = 8u * w;
-    for (int s = 0; s < 2; ++s) {
-        uint32_t* base = lds + KS_CYC + s * 6 * KS_CT;
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t a0 = v[(s * 4 + p) * 2], a1 = v[(s * 4 + p) * 2 + 1];
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t v0 = (a0 >> (8 * b)) & 0xFFu, v1 = (a1 >> (8 * b)) & 0xFFu;
-                const uint32_t cy0 = c0 + 7u - 2u * b, cy1 = c0 + 6u - 2u * b;
-                if (v0 && cy0 < KS_CT) atomicAdd(base + p * KS_CT + cy0, v0);
-                if (v1 && cy1 < KS_CT) atomicAdd(base + p * KS_CT + cy1, v1);
-            }
-        }
-        // quality: qa bytes = cycles c0..c0+3 (e0: +0,+2  o0: +1,+3), qb bytes = c0+4..c0+7
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ca = c0 + (k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5), cb = ca + 2;
-            const uint32_t x = v[16 + s * 4 + k], lo = x & 0xFFFFu, hi = x >> 16;
-            if (lo && ca < KS_CT) atomicAdd(base + 5 * KS_CT + ca, lo);
-            if (hi && cb < KS_CT) atomicAdd(base + 5 * KS_CT + cb, hi);
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t a0 = v[p * 2], a1 = v[p * 2 + 1];
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t v0 = (a0 >> (8 * b)) & 0xFFu, v1 = (a1 >> (8 * b)) & 0xFFu;
+            const uint32_t cy0 = c0 + 7u - 2u * b, cy1 = c0 + 6u - 2u * b;
+            if (v0 && cy0 < KS_CT) atomicAdd(base + p * KS_CT + cy0, v0);
+            if (v1 && cy1 < KS_CT) atomicAdd(base + p * KS_CT + cy1, v1);
         }
     }
+    // quality: qa bytes = cycles c0..c0+3 (e0: +0,+2  o0: +1,+3), qb bytes = c0+4..c0+7
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ca = c0 + (k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 4 : 5), cb = ca + 2;
+        const uint32_t x = v[8 + k], lo = x & 0xFFFFu, hi = x >> 16;
+        if (lo && ca < KS_CT) atomicAdd(base + 5 * KS_CT + ca, lo);
+        if (hi && cb < KS_CT) atomicAdd(base + 5 * KS_CT + cb, hi);
+    }
 }
-__device__ __forceinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t w)
+__device__ __forceinline__ void cyc_flush(CycAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
 {
     cyc_spill(A);
-    uint32_t v[24];
+    uint32_t v[12];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { v[(s * 4 + p) * 2] = A.l2[s][p][0]; v[(s * 4 + p) * 2 + 1] = A.l2[s][p][1]; v[16 + s * 4 + p] = A.q[s][p]; }
-    cyc_flush_arr(v, lds, w);
+    for (int p = 0; p < 4; ++p) { v[p * 2] = A.l2[p][0]; v[p * 2 + 1] = A.l2[p][1]; v[8 + p] = A.q[p]; }
+    cyc_flush_arr(v, lds + KS_CYC + mate * 6 * KS_CT, w);
     cyc_zero(A);
+}
+
+__device__ __forceinline__ void cyc_add(CycAcc& A, const uint32_t pa, const uint32_t pc, const uint32_t pg, const uint32_t pt,
+                                        const uint32_t qa, const uint32_t qb)
+{
+    A.l1[0] += pa; A.l1[1] += pc; A.l1[2] += pg; A.l1[3] += pt;
+    A.q[0] += qa & 0x00FF00FFu; A.q[1] += (qa >> 8) & 0x00FF00FFu; A.q[2] += qb & 0x00FF00FFu; A.q[3] += (qb >> 8) & 0x00FF00FFu;
 }
 
 // explicit global-address-space loads: pointers that were themselves loaded from memory (refs.refn[rid]) are generic to
@@ -226,7 +218,7 @@ typedef const __attribute__((address_space(1))) uint8_t* g_u8p;
 __device__ __forceinline__ uint32_t gld32(const uint32_t* p) { return *(g_u32p)(uintptr_t)p; }
 __device__ __forceinline__ uint32_t gld8(const uint8_t* p) { return *(g_u8p)(uintptr_t)p; }
 
-struct Pre { uint32_t sv, q0, q1, d0, d1, e0; }; // raw dwords of the NEXT group, in flight while the current one is computed
+struct Pre { uint32_t sv, q0, q1, d0, d1; }; // raw dwords of the NEXT group, in flight while the current one is computed
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-endian dword: one global_load_dword
@@ -237,33 +229,24 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-
 // record of one read in the chunk's LDS table (written by phase A)
 #define KM_PRIM   0x10000u   // primary record with first/last flag: reaches get_count / count8mers
 #define KM_TRIP   0x20000u   // triplet-eligible with a single CIGAR operation and a loaded reference
-// word 0: BAM flag (low 16 bits) | KM_* | L << 20, 1: pos, 2: n0, 3: contig length + 8 (saturated),
+// word 0: BAM flag (low 16 bits) | KM_* | L << 20 (L = 0 unless KM_PRIM), 1: pos, 2: n0, 3: index of the contig's first pad dword,
 // 4: seq_off, 5: qual_off, 6-7: pointer to the contig's nibble table
 
-// issue the global loads of group g for this lane (meta comes from the chunk's LDS records)
+// Issue the global loads of one group for this lane.  Branch-free: records of non-primary reads (and the dummy record
+// used by lanes past the end of the chunk) carry L = 0 and offsets / pointers that are safe to load from, and the
+// buffers are padded, so every lane always loads; what must not be used is masked when it is staged.
 __device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, bool in_chunk, uint32_t w, const uint8_t* seq,
                                            const uint8_t* qual)
 {
-    Pre P{0, 0, 0, 0, 0, 0};
-    if (!in_chunk) return P;
-    const uint4 ma = *(const uint4*)(META + k * KS_MW), mb = *(const uint4*)(META + k * KS_MW + 4);
-    const uint32_t m0 = ma.x, L = m0 >> 20;
-    if (!(m0 & KM_PRIM) || 8u * w >= L) return P;
+    const uint32_t kk = in_chunk ? k : (uint32_t)KS_CHUNK;
+    const uint4 ma = *(const uint4*)(META + kk * KS_MW), mb = *(const uint4*)(META + kk * KS_MW + 4);
+    Pre P;
     P.sv = ld32u(seq + mb.x + 4u * w);
-    if (!(m0 & BQC_FLAG_NO_QUAL)) {
-        const uint8_t* qp = qual + mb.y + 8u * w;
-        P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
-    }
-    if (m0 & KM_TRIP) {
-        const uint32_t pos = ma.y;
-        const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)mb.z | ((uint64_t)mb.w << 32));
-        const uint64_t p8 = (uint64_t)pos + 8u * w; // pos >= 0 for fast-path triplet reads (host)
-        if (p8 < (uint64_t)ma.w) {                   // else: past the contig -> zero nibbles, nothing matches
-            const uint64_t di = p8 >> 3;
-            P.d0 = gld32(rn + di); P.d1 = gld32(rn + di + 1);
-            if (w == 0) P.e0 = pos >= 8u ? gld32(rn + di - 1) : (pos > 0u ? gld32(rn) : 0u);
-        }
-    }
+    const uint8_t* qp = qual + mb.y + 8u * w;
+    P.q0 = ld32u(qp); P.q1 = ld32u(qp + 4);
+    const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)mb.z | ((uint64_t)mb.w << 32));
+    const uint32_t di = min((ma.y + 8u * w) >> 3, ma.w); // ma.w: index of the first of the two zero dwords behind the contig
+    P.d0 = gld32(rn + di); P.d1 = gld32(rn + di + 1);
     return P;
 }
 
@@ -284,9 +267,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     uint32_t* REFN = T + rpw * (3 * W + 6) + slot * (W + 2);
     uint32_t* REF2 = T + rpw * (4 * W + 8) + slot * (W + 2);
     uint32_t* META = lds + KS_META;
-    CycAcc A;
-    cyc_zero(A);
+    CycAcc A0, A1; // first-mate / second-mate reads (chunks are mate-uniform: Chunk::huge carries the mate)
+    cyc_zero(A0); cyc_zero(A1);
+    uint32_t n1[2] = {0, 0}, n2[2] = {0, 0}; // groups since the last level-1 spill / level-2 flush (wave-uniform)
     uint32_t cur_lane = 0xFFFFFFFFu;
+    if (threadIdx.x < KS_MW) // dummy record: L = 0, offsets 0, reference pointer -> any loadable memory
+        META[KS_CHUNK * KS_MW + threadIdx.x] = threadIdx.x == 6 ? (uint32_t)(uintptr_t)state : threadIdx.x == 7 ? (uint32_t)((uintptr_t)state >> 32) : 0u;
 
     const uint8_t* const g_seq = b.seq;
     const uint8_t* const g_qual = b.qual;
@@ -297,7 +283,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         if (!done) ch = b.chunks_fast[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
-                if (lane_used) cyc_flush(A, lds, w);
+                if (lane_used) { cyc_flush(A0, lds, 0, w); cyc_flush(A1, lds, 1, w); }
+                n1[0] = n1[1] = n2[0] = n2[1] = 0;
                 __syncthreads();
                 ks_flush(lds, sl, state, cur_lane);
                 __syncthreads();
@@ -312,23 +299,25 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             const uint32_t r = b.perm ? b.perm[ch.first + t] : ch.first + t;
             const uint32_t fl = b.flag[r], nc = b.n_cigar[r], L = b.l_seq[r];
             const int32_t rid = b.rid[r];
-            uint32_t m0 = fl & 0xFFFFu;
-            if (!(fl & 0x900u) && (fl & 0xC0u)) m0 |= KM_PRIM;
-            uint32_t n0 = 0, lim = 0;
-            uint64_t rn = 0;
-            if ((m0 & KM_PRIM) && (fl & BQC_FLAG_TRIPLET) && nc == 1 && L >= 3 && !(fl & BQC_FLAG_NO_QUAL) && rid >= 0 &&
-                (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr) {
-                m0 |= KM_TRIP;
-                n0 = b.cigar[b.cigar_off[r]] >> 4;
-                rn = (uint64_t)(uintptr_t)refs.refn[rid];
-                const uint64_t l8 = refs.len[rid] + 8u;
-                lim = l8 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l8;
+            uint32_t m0 = fl & 0xFFFFu, n0 = 0, maxd = 0, so = 0, qo = 0, Lr = 0;
+            uint64_t rn = (uint64_t)(uintptr_t)state; // any loadable address for reads without triplets
+            if (!(fl & 0x900u) && (fl & 0xC0u)) { // reaches get_count / count8mers
+                m0 |= KM_PRIM; Lr = L; so = b.seq_off[r]; qo = b.qual_off[r];
+                if ((fl & BQC_FLAG_TRIPLET) && nc == 1 && L >= 3 && !(fl & BQC_FLAG_NO_QUAL) && rid >= 0 && (uint32_t)rid < refs.n_refs &&
+                    refs.refn[rid] != nullptr) {
+                    m0 |= KM_TRIP;
+                    n0 = b.cigar[b.cigar_off[r]] >> 4;
+                    rn = (uint64_t)(uintptr_t)refs.refn[rid];
+                    const uint64_t md = (refs.len[rid] + 7u) >> 3; // first of the two zero dwords behind the contig
+                    maxd = md > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)md;
+                }
             }
             uint4* M = (uint4*)(META + t * KS_MW);
-            M[0] = make_uint4(m0 | (L << 20), (uint32_t)b.pos[r], n0, lim);
-            M[1] = make_uint4(b.seq_off[r], b.qual_off[r], (uint32_t)rn, (uint32_t)(rn >> 32));
+            M[0] = make_uint4(m0 | (Lr << 20), (m0 & KM_TRIP) ? (uint32_t)b.pos[r] : 0u, n0, maxd);
+            M[1] = make_uint4(so, (fl & BQC_FLAG_NO_QUAL) ? 0u : qo, (uint32_t)rn, (uint32_t)(rn >> 32));
         }
         __syncthreads();
+        const uint32_t cm8 = ch.huge & 1u; // mate of every read of this chunk
         // ---- phase B: groups of rpw reads per wave; the next group's data is loaded while this one is processed
         const uint32_t n_groups = (ch.count + rpw - 1) / rpw;
         Pre nxt = ks_prefetch(META, wave * rpw + slot, lane_used && wave * rpw + slot < ch.count, w, g_seq, g_qual);
@@ -340,22 +329,21 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             }
             const uint32_t k = g * rpw + slot;
             const bool have = lane_used && k < ch.count;
-            uint32_t flag = 0, L = 0, pos = 0, n0 = 0;
-            if (have) { const uint4 ma = *(const uint4*)(META + k * KS_MW); flag = ma.x; L = ma.x >> 20; pos = ma.y; n0 = ma.z; }
-            const bool prim = flag & KM_PRIM; // records that reach get_count / count8mers
-            if (!prim) L = 0;
+            const uint4 ma = *(const uint4*)(META + (have ? k : (uint32_t)KS_CHUNK) * KS_MW);
+            const uint32_t flag = ma.x, L = ma.x >> 20, pos = ma.y, n0 = ma.z; // L = 0 unless the record reaches get_count
+            const bool prim = flag & KM_PRIM;
             const bool rc = flag & 0x10u;
-            const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
+            const uint32_t mate = cm8;
             const uint32_t nd = (L + 7u) >> 3;           // dwords / cycle groups of this read
             const bool trip = (parts & 4u) && (flag & KM_TRIP);
             const uint32_t nv = (w < nd) ? min(8u, L - 8u * w) : 0u; // valid cycles of this lane
             // ---------------- staging (registers -> LDS tile of this wave), with the tails masked to zero
             if (lane_used) {
-                // the prefetch returns zeros for lanes without data; only the tail dword of a read needs masking:
                 // keep the top nv nibbles (also clears the pad nibble of an odd-length read) / the low nv quality bytes
                 const uint32_t sv = nv ? (bswap32(cur.sv) & (0xFFFFFFFFu << (4u * (8u - nv)))) : 0u; // big-endian: base 8w on top
                 const uint64_t qm = nv >= 8u ? ~0ull : ((1ull << (8u * nv)) - 1ull);
-                const uint32_t q0 = cur.q0 & (uint32_t)qm, q1 = cur.q1 & (uint32_t)(qm >> 32);
+                const bool hasq = !(flag & BQC_FLAG_NO_QUAL);
+                const uint32_t q0 = hasq ? cur.q0 & (uint32_t)qm : 0u, q1 = hasq ? cur.q1 & (uint32_t)(qm >> 32) : 0u;
                 if ((q0 | q1) & 0x80808080u) { // some Phred >= 128: check the 222 limit precisely
                     bool bad = false;
 #pragma unroll
@@ -365,21 +353,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 SEQ[1 + w] = sv;
                 QUAL[2 + 2 * w] = q0;
                 QUAL[3 + 2 * w] = q1;
-                if (trip) { // reference bases pos+8w .. pos+8w+7 (and pos-8 .. pos-1 by lane 0), one-hot nibbles
-                    const uint32_t sh = ((pos + 8u * w) & 7u) * 4u;
-                    const uint32_t v = sh ? alignbit(cur.d0, cur.d1, 32u - sh) : cur.d0;
-                    REFN[1 + w] = v;
-                    const uint32_t c = (((v >> 1) | (v >> 3)) & 0x11111111u) | ((((v >> 2) | (v >> 3)) & 0x11111111u) << 1);
-                    REF2[1 + w] = squeeze2(c);
-                    if (w == 0) {
-                        uint32_t pv = 0;
-                        if (pos >= 8u) pv = sh ? alignbit(cur.e0, cur.d0, 32u - sh) : cur.e0;
-                        else if (pos > 0u) pv = cur.e0 >> (4u * (8u - pos));
-                        REFN[0] = pv;
-                        const uint32_t pc = (((pv >> 1) | (pv >> 3)) & 0x11111111u) | ((((pv >> 2) | (pv >> 3)) & 0x11111111u) << 1);
-                        REF2[0] = squeeze2(pc);
-                    }
-                }
+                // reference bases pos+8w .. pos+8w+7 as one-hot nibbles and as 2-bit codes (garbage for reads without
+                // triplets: never read).  Position pos-1 is not needed: read position 0 is never evaluated.
+                const uint32_t sh = ((pos + 8u * w) & 7u) * 4u;
+                const uint32_t v = (uint32_t)((((uint64_t)cur.d0 << 32) | cur.d1) >> (32u - sh));
+                REFN[1 + w] = v;
+                REF2[1 + w] = squeeze2((((v >> 1) | (v >> 3)) & 0x11111111u) | ((((v >> 2) | (v >> 3)) & 0x11111111u) << 1));
             }
             // LDS operations of one wave execute in order, so other lanes' ds_writes above are visible to the ds_reads
             // below; only the COMPILER must not reorder them.  (A fence or volatile accesses would insert
@@ -387,46 +366,35 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 
-            // ---------------- sequencing-orientation dword X (cycles 8w .. 8w+7)
-            uint32_t X = 0, qa = 0, qb = 0;
-            if (nv) {
-                if (!rc) {
-                    X = SEQ[1 + w];
-                    qa = QUAL[2 + 2 * w]; qb = QUAL[3 + 2 * w];
-                } else {
-                    const int32_t o = (int32_t)L - 8 - 8 * (int32_t)w; // first base of the group, may be negative (> -8)
-                    const int32_t d0i = o >> 3;                          // floor: -1 addresses the zero pad
-                    const uint32_t shn = (uint32_t)(o - 8 * d0i) * 4u;
-                    const uint32_t hi = SEQ[1 + d0i], lo = SEQ[2 + d0i];
-                    const uint32_t Y = shn ? alignbit(hi, lo, 32u - shn) : hi;
-                    X = __brev(Y); // reversed base order, complemented one-hot codes (IUPAC masks complement the same way)
-                    const uint32_t bo = (uint32_t)(8 + o);              // byte offset into QUAL (data starts at byte 8)
-                    const uint32_t qd = bo >> 2, bs = bo & 3u;
-                    const uint32_t a0 = QUAL[qd], a1 = QUAL[qd + 1], a2 = QUAL[qd + 2];
-                    const uint32_t y0 = alignbyte(a1, a0, bs), y1 = alignbyte(a2, a1, bs);
-                    qa = bswap32(y1); qb = bswap32(y0);
-                }
+            // ---------------- sequencing-orientation dword X and qualities qa/qb (cycles 8w .. 8w+7), one code path for
+            //                  both strands: an unaligned 8-base / 8-byte window, bit- / byte-reversed for reverse reads
+            uint32_t X, qa, qb;
+            {
+                const int32_t o = nv ? (rc ? (int32_t)L - 8 - 8 * (int32_t)w : 8 * (int32_t)w) : 0; // first base, > -8
+                const int32_t d0i = o >> 3;                                                       // floor: -1 = zero pad
+                const uint32_t shn = ((uint32_t)o & 7u) * 4u;
+                const uint32_t hi = SEQ[1 + d0i], lo = SEQ[2 + d0i];
+                const uint32_t Y = (uint32_t)((((uint64_t)hi << 32) | lo) >> (32u - shn));
+                X = rc ? __brev(Y) : Y; // bit reversal = reversed base order and complemented one-hot codes (IUPAC too)
+                const uint32_t bo = (uint32_t)(8 + o);                                            // byte offset into QUAL
+                const uint32_t qd = bo >> 2, bs = bo & 3u;
+                const uint32_t a0 = QUAL[qd], a1 = QUAL[qd + 1], a2 = QUAL[qd + 2];
+                const uint32_t y0 = alignbyte(a1, a0, bs), y1 = alignbyte(a2, a1, bs);
+                qa = rc ? bswap32(y1) : y0; qb = rc ? bswap32(y0) : y1;
+                if (!nv) { X = 0; qa = 0; qb = 0; }
             }
             const Planes P = planes_of(X);
-            // ---- bit-sliced accumulation
+            // ---- bit-sliced accumulation (the chunk's mate selects the register set: wave-uniform branch)
             if (parts & 1u) {
-                const uint32_t m0 = mate == 0 ? 0xFFFFFFFFu : 0u;
-                A.l1[0][0] += P.a; A.l1[0][1] += P.c; A.l1[0][2] += P.g; A.l1[0][3] += P.t;
-                A.l1[1][0] += P.a & m0; A.l1[1][1] += P.c & m0; A.l1[1][2] += P.g & m0; A.l1[1][3] += P.t & m0;
-                const uint32_t e0 = qa & 0x00FF00FFu, o0 = (qa >> 8) & 0x00FF00FFu, e1 = qb & 0x00FF00FFu, o1 = (qb >> 8) & 0x00FF00FFu;
-                A.q[0][0] += e0; A.q[0][1] += o0; A.q[0][2] += e1; A.q[0][3] += o1;
-                A.q[1][0] += e0 & m0; A.q[1][1] += o0 & m0; A.q[1][2] += e1 & m0; A.q[1][3] += o1 & m0;
-                ++A.n1; ++A.n2;
-                if (A.n1 == 15u) cyc_spill(A);
-                if (A.n2 == 255u) cyc_flush(A, lds, w);
+                if (cm8 == 0) cyc_add(A0, P.a, P.c, P.g, P.t, qa, qb); else cyc_add(A1, P.a, P.c, P.g, P.t, qa, qb);
+                if (++n1[cm8] == 15u) { if (cm8 == 0) cyc_spill(A0); else cyc_spill(A1); n1[cm8] = 0; }
+                if (++n2[cm8] == 255u) { if (cm8 == 0) cyc_flush(A0, lds, 0, w); else cyc_flush(A1, lds, 1, w); n1[cm8] = 0; n2[cm8] = 0; }
                 // cycles holding anything but A/C/G/T (Dna5 'N' bin) are rare: counted directly
                 uint32_t other = nv ? (0x11111111u & (0xFFFFFFFFu << (4u * (8u - nv))) & ~P.oh) : 0u;
                 while (other) {
                     const uint32_t bit = (uint32_t)__ffs((int)other) - 1u;
                     other &= other - 1u;
-                    const uint32_t cy = 8u * w + 7u - (bit >> 2);
-                    atomicAdd(&lds[KS_CYC + 4 * KS_CT + cy], 1u);
-                    if (mate == 0) atomicAdd(&lds[KS_CYC + 6 * KS_CT + 4 * KS_CT + cy], 1u);
+                    atomicAdd(&lds[KS_CYC + (cm8 * 6 + 4) * KS_CT + 8u * w + 7u - (bit >> 2)], 1u);
                 }
             }
             // ---- per-read sums: N count, GC count, quality sum.  Wave-wide inclusive scans on the VALU; the total of a
