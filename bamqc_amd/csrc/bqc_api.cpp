@@ -237,10 +237,10 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
     uint8_t* p = nullptr;
     HIPCHK(c, hipMalloc(&p, len ? len : 1));
     HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
-    const uint64_t ndw = (len + 7) / 8 + 2; // two zero dwords behind the last base
+    const uint64_t nd8 = (len + 7) / 8; // nibble table: nd8 + 2 dwords; 2-bit table behind it: (nd8 + 1) / 2 + 2 dwords
     uint32_t* pn = nullptr;
-    HIPCHK(c, hipMalloc(&pn, ndw * 4));
-    bqc_launch_ref_nibbles(p, len, pn, ndw, c->stream);
+    HIPCHK(c, hipMalloc(&pn, (nd8 + 2 + (nd8 + 1) / 2 + 2) * 4));
+    bqc_launch_ref_nibbles(p, len, pn, nd8, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->d_ref[rid] = p;
     c->d_refn[rid] = pn;

@@ -13,77 +13,89 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
     __shared__ int32_t diff[BQC_COV_TILE + 8];
     __shared__ uint32_t hist[BQC_COVSIZE + 1];
     __shared__ uint32_t wsum[4];
-    const CovTile t = b.cov_tiles[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < BQC_COV_TILE + 8; i += blockDim.x) diff[i] = 0;
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE, hi = lo + BQC_COV_TILE;
-    for (uint32_t e = t.list_begin + threadIdx.x; e < t.list_end; e += blockDim.x) {
-        const uint32_t r = b.cov_list[e];
-        const uint32_t flag = b.flag[r];
-        const bool rc = flag & 0x10;
-        const int64_t base = (int64_t)b.cov_win[r] * BQC_VSIZE;
-        const int64_t limit = base + 2 * BQC_VSIZE; // DEFINED: increments at window offset >= 2000 are dropped
-        const int64_t p0 = base + b.cov_off[r];
-        const uint32_t ncig = b.n_cigar[r];
-        const uint32_t* cg = b.cigar + b.cigar_off[r];
-        uint32_t c = 0; // `int c` in the reference; wraps identically
-        for (uint32_t k = 0; k < ncig; ++k) { // seq-oriented CIGAR: reversed for RC reads (bamqualcheck.cpp:349)
-            const uint32_t w = cg[rc ? ncig - 1 - k : k], op = w & 15u, n = w >> 4;
-            if (op == 4u) c += n;                    // 'S'
-            if (op == 0u || op == 2u) {              // 'M' or 'D'
-                int64_t a = p0 + c, z = a + n;
-                if (z > limit) z = limit;
-                if (a < lo) a = lo;
-                if (z > hi) z = hi;
-                if (a < z) {
-                    atomicAdd(&diff[a - lo], 1);
-                    atomicAdd(&diff[z - lo], -1);
+    uint32_t cur_lane = 0xFFFFFFFFu;
+    // persistent workgroups: the depth histogram stays in LDS across tiles and is flushed once per lane
+    for (uint32_t ti = blockIdx.x;; ti += gridDim.x) {
+        const bool done = ti >= b.n_cov_tiles;
+        CovTile t{};
+        t.lane = 0xFFFFFFFFu;
+        if (!done) t = b.cov_tiles[ti];
+        if (t.lane != cur_lane) { // block-uniform
+            __syncthreads();
+            if (cur_lane != 0xFFFFFFFFu)
+                for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
+                    if (hist[i]) { gadd(state + sl.lane_base(cur_lane) + sl.o_poscov + i, hist[i]); hist[i] = 0; }
+            cur_lane = t.lane;
+        }
+        if (done) break;
+        for (uint32_t i = threadIdx.x; i < BQC_COV_TILE + 8; i += blockDim.x) diff[i] = 0;
+        __syncthreads();
+        const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE, hi = lo + BQC_COV_TILE;
+        for (uint32_t e = t.list_begin + threadIdx.x; e < t.list_end; e += blockDim.x) {
+            const uint32_t r = b.cov_list[e];
+            const uint32_t flag = b.flag[r];
+            const bool rc = flag & 0x10;
+            const int64_t base = (int64_t)b.cov_win[r] * BQC_VSIZE;
+            const int64_t limit = base + 2 * BQC_VSIZE; // DEFINED: increments at window offset >= 2000 are dropped
+            const int64_t p0 = base + b.cov_off[r];
+            const uint32_t ncig = b.n_cigar[r];
+            const uint32_t* cg = b.cigar + b.cigar_off[r];
+            uint32_t c = 0; // `int c` in the reference; wraps identically
+            for (uint32_t k = 0; k < ncig; ++k) { // seq-oriented CIGAR: reversed for RC reads (bamqualcheck.cpp:349)
+                const uint32_t w = cg[rc ? ncig - 1 - k : k], op = w & 15u, n = w >> 4;
+                if (op == 4u) c += n;                    // 'S'
+                if (op == 0u || op == 2u) {              // 'M' or 'D'
+                    int64_t a = p0 + c, z = a + n;
+                    if (z > limit) z = limit;
+                    if (a < lo) a = lo;
+                    if (z > hi) z = hi;
+                    if (a < z) {
+                        atomicAdd(&diff[a - lo], 1);
+                        atomicAdd(&diff[z - lo], -1);
+                    }
+                    c += n;
                 }
-                c += n;
             }
         }
-    }
-    __syncthreads();
-    // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16)
-    const uint32_t per = (BQC_COV_TILE + 255) / 256;
-    const uint32_t s0 = threadIdx.x * per;
-    int32_t loc = 0;
-    for (uint32_t j = 0; j < per; ++j) if (s0 + j < BQC_COV_TILE) loc += diff[s0 + j];
-    // inclusive wave scan of thread totals
-    int32_t inc = loc;
+        __syncthreads();
+        // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16)
+        const uint32_t per = (BQC_COV_TILE + 255) / 256;
+        const uint32_t s0 = threadIdx.x * per;
+        int32_t loc = 0;
+        for (uint32_t j = 0; j < per; ++j) if (s0 + j < BQC_COV_TILE) loc += diff[s0 + j];
+        int32_t inc = loc; // inclusive wave scan of thread totals
 #pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int32_t v = __shfl_up(inc, o);
-        if (lane_id() >= o) inc += v;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int32_t v = __shfl_up(inc, o);
+            if (lane_id() >= o) inc += v;
+        }
+        if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
+        __syncthreads();
+        int32_t off = inc - loc;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
+        const uint32_t par = parity[t.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
+        const uint32_t* cin = carry + ((uint64_t)t.lane * 2 + par) * 2000;
+        uint32_t* cout = carry + ((uint64_t)t.lane * 2 + (par ^ 1u)) * 2000;
+        int32_t run = off;
+        uint32_t run_bin = 0xFFFFFFFFu, run_n = 0; // consecutive positions mostly share a depth: one LDS atomic per run
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t p = s0 + j;
+            if (p >= BQC_COV_TILE) break;
+            run += diff[p];
+            const int64_t vp = lo + p;
+            uint32_t depth = (uint32_t)run;
+            if (vp < 2 * BQC_VSIZE) depth += cin[vp]; // partial windows carried over from the previous batch
+            const uint32_t win = t.win_lo + p / BQC_VSIZE;
+            if (win < t.win_final) { // update_coverage :66-77
+                const uint32_t bin = depth > BQC_COVSIZE ? BQC_COVSIZE : depth;
+                if (bin == run_bin) ++run_n;
+                else { if (run_n) atomicAdd(&hist[run_bin], run_n); run_bin = bin; run_n = 1; }
+            } else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
+        }
+        if (run_n) atomicAdd(&hist[run_bin], run_n);
+        __syncthreads(); // diff / wsum are reused by the next tile
     }
-    if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
-    __syncthreads();
-    int32_t off = inc - loc;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
-    const uint32_t par = parity[t.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
-    const uint32_t* cin = carry + ((uint64_t)t.lane * 2 + par) * 2000;
-    uint32_t* cout = carry + ((uint64_t)t.lane * 2 + (par ^ 1u)) * 2000;
-    int32_t run = off;
-    uint32_t run_bin = 0xFFFFFFFFu, run_n = 0; // consecutive positions mostly share a depth: one LDS atomic per run
-    for (uint32_t j = 0; j < per; ++j) {
-        const uint32_t p = s0 + j;
-        if (p >= BQC_COV_TILE) break;
-        run += diff[p];
-        const int64_t vp = lo + p;
-        uint32_t depth = (uint32_t)run;
-        if (vp < 2 * BQC_VSIZE) depth += cin[vp]; // partial windows carried over from the previous batch
-        const uint32_t win = t.win_lo + p / BQC_VSIZE;
-        if (win < t.win_final) { // update_coverage :66-77
-            const uint32_t bin = depth > BQC_COVSIZE ? BQC_COVSIZE : depth;
-            if (bin == run_bin) ++run_n;
-            else { if (run_n) atomicAdd(&hist[run_bin], run_n); run_bin = bin; run_n = 1; }
-        } else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
-    }
-    if (run_n) atomicAdd(&hist[run_bin], run_n);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
-        if (hist[i]) gadd(state + sl.lane_base(t.lane) + sl.o_poscov + i, hist[i]);
 }
 
 // end of stream: histogram the two live windows of every started lane (bamqualcheck.cpp:447-453)
@@ -128,7 +140,8 @@ extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_
                                hipStream_t s)
 {
     if (b.n_cov_tiles == 0) return;
-    hipLaunchKernelGGL(k_cov, dim3(b.n_cov_tiles), dim3(256), 0, s, b, sl, state, carry, parity);
+    const uint32_t grid = b.n_cov_tiles < 2048u ? b.n_cov_tiles : 2048u; // persistent workgroups, ~8 per CU
+    hipLaunchKernelGGL(k_cov, dim3(grid), dim3(256), 0, s, b, sl, state, carry, parity);
 }
 
 extern "C" void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t s)

@@ -218,7 +218,7 @@ typedef const __attribute__((address_space(1))) uint8_t* g_u8p;
 __device__ __forceinline__ uint32_t gld32(const uint32_t* p) { return *(g_u32p)(uintptr_t)p; }
 __device__ __forceinline__ uint32_t gld8(const uint8_t* p) { return *(g_u8p)(uintptr_t)p; }
 
-struct Pre { uint32_t sv, q0, q1, d0, d1; }; // raw dwords of the NEXT group, in flight while the current one is computed
+struct Pre { uint32_t sv, q0, q1, d0, d1, c0, c1; }; // raw dwords of the NEXT group, in flight while the current one is computed
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) // unaligned little-endian dword: one global_load_dword
@@ -247,6 +247,10 @@ __device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, boo
     const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)mb.z | ((uint64_t)mb.w << 32));
     const uint32_t di = min((ma.y + 8u * w) >> 3, ma.w); // ma.w: index of the first of the two zero dwords behind the contig
     P.d0 = gld32(rn + di); P.d1 = gld32(rn + di + 1);
+    // the same bases as 2-bit codes (16 per dword) live right behind the nibble table: offset in record word 2's top bits
+    const uint32_t* r2 = rn + ma.w + 2u;
+    const uint32_t dj = min((ma.y + 8u * w) >> 4, (ma.w + 1u) >> 1);
+    P.c0 = gld32(r2 + dj); P.c1 = gld32(r2 + dj + 1);
     return P;
 }
 
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t sh = ((pos + 8u * w) & 7u) * 4u;
                 const uint32_t v = (uint32_t)((((uint64_t)cur.d0 << 32) | cur.d1) >> (32u - sh));
                 REFN[1 + w] = v;
-                REF2[1 + w] = squeeze2((((v >> 1) | (v >> 3)) & 0x11111111u) | ((((v >> 2) | (v >> 3)) & 0x11111111u) << 1));
+                REF2[1 + w] = (uint32_t)((((uint64_t)cur.c0 << 32) | cur.c1) >> (48u - ((pos + 8u * w) & 15u) * 2u)) & 0xFFFFu;
             }
             // LDS operations of one wave execute in order, so other lanes' ds_writes above are visible to the ds_reads
             // below; only the COMPILER must not reorder them.  (A fence or volatile accesses would insert
@@ -429,10 +433,15 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                             old[kw] = atomicAdd(&lds[KS_T8 + (h >> 2)], 1u << (8u * (h & 3u)));
                         }
                     }
+                    uint32_t hot = 0;
 #pragma unroll
-                    for (int kw = 0; kw < 8; ++kw) {
-                        const uint32_t h = bfe(c32, 16 - 2 * kw, 16);
-                        ovf |= (((old[kw] >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) ? (1u << kw) : 0u; // old == 0 for skipped windows
+                    for (int kw = 0; kw < 8; ++kw) hot |= old[kw];
+                    if (hot & 0x80808080u) { // some counter of a touched dword is >= 128: look precisely (rare)
+#pragma unroll
+                        for (int kw = 0; kw < 8; ++kw) {
+                            const uint32_t h = bfe(c32, 16 - 2 * kw, 16);
+                            ovf |= (((old[kw] >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) ? (1u << kw) : 0u; // old == 0 for skipped windows
+                        }
                     }
                     if (ovf) { // rare: some packed u8 counter wrapped
 #pragma unroll
@@ -506,22 +515,34 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     }
 }
 
-// Dna5 bytes -> one-hot nibbles, 8 bases per dword, first base in the top nibble; N (4) -> A like Dna5 -> Dna
-__global__ void k_ref_nibbles(const uint8_t* __restrict__ dna5, uint64_t len, uint32_t* __restrict__ out, uint64_t n_dwords)
+// Dna5 bytes -> (a) one-hot nibbles, 8 bases per dword, first base in the top nibble, followed by two zero dwords;
+//               (b) right behind: 2-bit codes, 16 bases per dword, first base in the top bits, followed by two zero dwords.
+// N (4) -> A like Dna5 -> Dna.  nd8 = ceil(len / 8): table (a) has nd8 + 2 dwords, table (b) starts at out + nd8 + 2.
+__global__ void k_ref_nibbles(const uint8_t* __restrict__ dna5, uint64_t len, uint32_t* __restrict__ out, uint64_t nd8)
 {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n_dwords) return;
-    uint32_t v = 0;
-    for (uint32_t t = 0; t < 8; ++t) {
-        const uint64_t p = d * 8 + t;
-        if (p < len) v |= (1u << (dna5[p] & 3u)) << (28u - 4u * t);
+    const uint64_t nd16 = (nd8 + 1) / 2;
+    if (d < nd8 + 2) {
+        uint32_t v = 0;
+        for (uint32_t t = 0; t < 8; ++t) {
+            const uint64_t p = d * 8 + t;
+            if (p < len) v |= (1u << (dna5[p] & 3u)) << (28u - 4u * t);
+        }
+        out[d] = v;
     }
-    out[d] = v;
+    if (d < nd16 + 2) {
+        uint32_t v = 0;
+        for (uint32_t t = 0; t < 16; ++t) {
+            const uint64_t p = d * 16 + t;
+            if (p < len) v |= (uint32_t)(dna5[p] & 3u) << (30u - 2u * t);
+        }
+        out[nd8 + 2 + d] = v;
+    }
 }
 
-extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t s)
+extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t nd8, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((n_dwords + 255) / 256)), dim3(256), 0, s, dna5, len, out, n_dwords);
+    hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((nd8 + 2 + 255) / 256)), dim3(256), 0, s, dna5, len, out, nd8);
 }
 
 extern "C" hipError_t bqc_short_init()
