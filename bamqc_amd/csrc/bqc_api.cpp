@@ -364,27 +364,37 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
     }
     { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> generic (chunks).
-      // Fast reads are additionally grouped by mate inside windows of 2016 reads (stable), so that every fast chunk is
-      // mate-uniform (k_short then updates one register set per chunk) while both chunks of a window still share L2.
+      // Inside a fast chunk the reads are grouped by mate (stable), so that every group of reads a wave handles at once is
+      // mate-uniform (k_short then updates one register set per group) while all the loads of a chunk stay together.
         uint32_t maxfast = 0;
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
         P.fast_w = std::max(10u, (maxfast + 7) / 8); // >= 10 keeps the per-wave staging tile within its LDS budget
         const uint32_t per_pass = 16u * (64u / P.fast_w);
-        const uint32_t fast_reads = (1008u / per_pass) * per_pass; // <= KS_CHUNK (k_short keeps one record per read in LDS)
+        const uint32_t fast_reads = 960u - 960u % per_pass; // + padding entries stays <= KS_CHUNK (one LDS record per entry)
         std::vector<uint32_t> np;
         np.reserve(n);
-        std::vector<uint32_t> win[2];
+        const uint32_t rpw = 64u / P.fast_w;
+        std::vector<uint32_t> win; // reads of the current fast chunk, in stream order
         uint32_t wlane = 0;
         auto flush_window = [&]() {
-            for (uint32_t m = 0; m < 2; ++m) {
-                for (size_t o = 0; o < win[m].size(); o += fast_reads) {
-                    const uint32_t cnt = (uint32_t)std::min<size_t>(fast_reads, win[m].size() - o);
-                    P.chunks_fast.push_back(Chunk{(uint32_t)np.size(), cnt, wlane, m});
-                    np.insert(np.end(), win[m].begin() + o, win[m].begin() + o + cnt);
+            // Inside a chunk the reads are regrouped in slices of 192: first-mate reads, then second-mate reads, each run
+            // padded with null entries (0xFFFFFFFF) to a multiple of the reads a wave handles at once -> every group of
+            // rpw consecutive records is mate-uniform, and the two runs of a slice are touched close together in time
+            // (their 128-byte lines are shared, so the second touch hits L2).
+            if (win.empty()) return;
+            const uint32_t first = (uint32_t)np.size();
+            for (size_t o = 0; o < win.size(); o += 192) {
+                const size_t e = std::min(win.size(), o + 192);
+                for (uint32_t m = 0; m < 2; ++m) {
+                    uint32_t cnt = 0;
+                    for (size_t i = o; i < e; ++i)
+                        if (((P.flag[win[i]] & 0x40u) ? 0u : 1u) == m) { np.push_back(win[i]); ++cnt; }
+                    while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
                 }
-                win[m].clear();
             }
+            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, 0});
+            win.clear();
         };
         uint32_t start = 0, count = 0, bases = 0, cl = 0;
         auto close_slow = [&]() {
@@ -397,10 +407,10 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             const bool fast = !c->no_fast && L <= BQC_FAST_MAXLEN;
             if (fast) {
                 close_slow();
-                if ((win[0].size() + win[1].size()) && lane != wlane) flush_window();
+                if (!win.empty() && lane != wlane) flush_window();
                 wlane = lane;
-                win[(P.flag[r] & 0x40u) ? 0 : 1].push_back(r);
-                if (win[0].size() + win[1].size() == 2016) flush_window();
+                win.push_back(r);
+                if (win.size() == fast_reads) flush_window();
                 // fast-path triplets assume chromPos = pos + i: reads with several CIGAR operations take the generic walk
                 if ((P.flag[r] & BQC_FLAG_TRIPLET) && (b->n_cigar[r] != 1 || b->pos[r] < 0)) P.trip_list.push_back(r);
                 continue;
@@ -508,7 +518,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_tlen = cv.take(4ull * n), o_nm = cv.take(4ull * n), o_as = cv.take(4ull * n), o_lseq = cv.take(4ull * n),
                  o_ncig = cv.take(2ull * n), o_coff = cv.take(2ull * n), o_cwin = cv.take(4ull * n), o_soff = cv.take(4ull * n),
                  o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 512), o_qual = cv.take(P.qual_bytes + 512),
-                 o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * n),
+                 o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * P.perm.size()),
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
                  o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
                  o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
@@ -530,7 +540,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     UP(o_cwin, P.cov_win.data(), 4ull * n); UP(o_soff, P.seq_off.data(), 4ull * n); UP(o_qoff, P.qual_off.data(), 4ull * n);
     UP(o_cgoff, P.cigar_off.data(), 4ull * n); UP(o_seq, b->seq, P.seq_bytes); UP(o_qual, b->qual, P.qual_bytes);
     UP(o_cig, b->cigar, 4 * P.cigar_words);
-    if (!P.identity) UP(o_perm, P.perm.data(), 4ull * n);
+    if (!P.identity) UP(o_perm, P.perm.data(), 4ull * P.perm.size());
     UP(o_chunks, P.chunks.data(), sizeof(Chunk) * P.chunks.size());
     UP(o_chf, P.chunks_fast.data(), sizeof(Chunk) * P.chunks_fast.size());
     UP(o_tl, P.trip_list.data(), 4ull * P.trip_list.size());
@@ -553,6 +563,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.seq_off = (const uint32_t*)(base + o_soff); d.qual_off = (const uint32_t*)(base + o_qoff); d.cigar_off = (const uint32_t*)(base + o_cgoff);
     d.seq = (const uint8_t*)(base + o_seq); d.qual = (const uint8_t*)(base + o_qual); d.cigar = (const uint32_t*)(base + o_cig);
     d.perm = P.identity ? nullptr : (const uint32_t*)(base + o_perm);
+    d.n_perm = P.identity ? n : (uint32_t)P.perm.size();
     d.chunks = (const Chunk*)(base + o_chunks); d.n_chunks = (uint32_t)P.chunks.size();
     d.chunks_fast = (const Chunk*)(base + o_chf); d.n_chunks_fast = (uint32_t)P.chunks_fast.size(); d.fast_w = P.fast_w;
     d.trip_list = (const uint32_t*)(base + o_tl); d.trip_chunks = (const Chunk*)(base + o_tch); d.n_trip_chunks = (uint32_t)P.trip_chunks.size();

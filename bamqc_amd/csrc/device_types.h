@@ -22,7 +22,7 @@
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;
-    uint32_t huge; // generic chunks: 1 = single read longer than BQC_CHUNK_BASES; fast chunks: mate (0 first, 1 second)
+    uint32_t huge; // generic chunks: 1 = single read longer than BQC_CHUNK_BASES; fast chunks: unused
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
@@ -57,7 +57,9 @@ struct DevBatch {
     const uint8_t* qual;   // raw Phred
     const uint32_t* cigar; // len<<4|op
     // work decomposition (host pre-pass)
-    const uint32_t* perm;  // reads grouped by lane (stable); nullptr = identity
+    const uint32_t* perm;  // processing order: reads grouped by lane (and by mate inside fast chunks); entries
+                           // 0xFFFFFFFF are padding; nullptr = identity
+    uint32_t n_perm;       // entries in perm (>= n_reads because of padding), n_reads when perm == nullptr
     const Chunk* chunks;
     uint32_t n_chunks;
     const uint32_t* nm_extra_read;

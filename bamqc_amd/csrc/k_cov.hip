@@ -173,6 +173,12 @@ __global__ void k_calib_read4(const uint32_t* __restrict__ p, uint64_t n_dwords,
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords; i += (uint64_t)gridDim.x * blockDim.x) acc ^= p[i];
     if (acc == 0x12345678u) out[0] = acc;
 }
+__global__ void k_calib_read8(const uint2* __restrict__ p, uint64_t n, uint32_t* __restrict__ out)
+{
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { const uint2 v = p[i]; acc ^= v.x ^ v.y; }
+    if (acc == 0x12345678u) out[0] = acc;
+}
 extern "C" int bqc_calib_read4(uint64_t bytes, int repeat)
 {
     uint32_t* p = nullptr;
@@ -180,6 +186,7 @@ extern "C" int bqc_calib_read4(uint64_t bytes, int repeat)
     if (hipMalloc(&p, bytes) != hipSuccess || hipMalloc(&o, 64) != hipSuccess) return 2;
     (void)hipMemset(p, 1, bytes);
     for (int r = 0; r < repeat; ++r) hipLaunchKernelGGL(k_calib_read4, dim3(256 * 8), dim3(256), 0, 0, p, bytes / 4, o);
+    for (int r = 0; r < repeat; ++r) hipLaunchKernelGGL(k_calib_read8, dim3(256 * 8), dim3(256), 0, 0, (const uint2*)p, bytes / 8, o);
     (void)hipDeviceSynchronize();
     (void)hipFree(p); (void)hipFree(o);
     return 0;

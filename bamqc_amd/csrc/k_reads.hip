@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint6
         }
         for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
             const uint32_t t = t0 + threadIdx.x;
-            const bool live = t < ch.count;
-            const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            bool live = t < ch.count;
+            uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            if (r == 0xFFFFFFFFu) { live = false; r = 0; } // padding entry of a fast chunk
             if (__ballot(live)) read_stats(b, sl, state, refs, err, lds, r, live, live);
         }
     }

@@ -301,6 +301,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         // ---- phase A: thread per read — the read's record for phase B into LDS
         for (uint32_t t = threadIdx.x; t < ch.count; t += blockDim.x) {
             const uint32_t r = b.perm ? b.perm[ch.first + t] : ch.first + t;
+            if (r == 0xFFFFFFFFu) { // padding entry
+                uint4* M = (uint4*)(META + t * KS_MW);
+                M[0] = make_uint4(0, 0, 0, 0);
+                M[1] = make_uint4(0, 0, (uint32_t)(uintptr_t)state, (uint32_t)((uintptr_t)state >> 32));
+                continue;
+            }
             const uint32_t fl = b.flag[r], nc = b.n_cigar[r], L = b.l_seq[r];
             const int32_t rid = b.rid[r];
             uint32_t m0 = fl & 0xFFFFu, n0 = 0, maxd = 0, so = 0, qo = 0, Lr = 0;
@@ -321,9 +327,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             M[1] = make_uint4(so, (fl & BQC_FLAG_NO_QUAL) ? 0u : qo, (uint32_t)rn, (uint32_t)(rn >> 32));
         }
         __syncthreads();
-        const uint32_t cm8 = ch.huge & 1u; // mate of every read of this chunk
         // ---- phase B: groups of rpw reads per wave; the next group's data is loaded while this one is processed
-        const uint32_t n_groups = (ch.count + rpw - 1) / rpw;
+        const uint32_t n_groups = (ch.count + rpw - 1) / rpw; // host: every group of rpw consecutive records is mate-uniform
         Pre nxt = ks_prefetch(META, wave * rpw + slot, lane_used && wave * rpw + slot < ch.count, w, g_seq, g_qual);
         for (uint32_t g = wave; g < n_groups; g += KS_WAVES) {
             const Pre cur = nxt;
@@ -333,6 +338,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             }
             const uint32_t k = g * rpw + slot;
             const bool have = lane_used && k < ch.count;
+            // mate of every read of this group: the record of slot 0 (padding entries sit at the end of a run)
+            const uint32_t cm8 = (META[g * rpw * KS_MW] & 0x40u) ? 0u : 1u;
             const uint4 ma = *(const uint4*)(META + (have ? k : (uint32_t)KS_CHUNK) * KS_MW);
             const uint32_t flag = ma.x, L = ma.x >> 20, pos = ma.y, n0 = ma.z; // L = 0 unless the record reaches get_count
             const bool prim = flag & KM_PRIM;
