@@ -7,19 +7,21 @@ O=gpurun_out/prof_r1b; rm -rf $O; mkdir -p $O
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 10 --warmup 2 --no-cpu > $O/bench_under_rocprof.json 2> $O/kt.err
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 3 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 3 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_tcc -- python bench.py --steps 3 --warmup 0 --no-cpu > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $O/cal_dram -- python -c "from bamqc_amd import _lib; _lib.load().bqc_calib_read4(1<<30, 3)" > /dev/null 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- python -c "from bamqc_amd import _lib; _lib.load().bqc_calib_read4(1<<30, 3)" > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, collections, json
 O = "gpurun_out/prof_r1b"
 out = {}
-for name in ("pmc_fetch", "pmc_write", "cal_fetch"):
+for name in ("pmc_fetch", "pmc_write", "pmc_tcc", "cal_fetch", "cal_dram"):
     for f in glob.glob(O + "/" + name + "/*/*counter_collection.csv"):
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             agg[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in agg.items():
             if k.startswith("k_") or "k_" in k:
-                out["%s:%s:%s" % (name, k, c)] = {"dispatches": len(v), "avg_KB": sum(v) / len(v)}
+                out["%s:%s:%s" % (name, k, c)] = {"dispatches": len(v), "avg": sum(v) / len(v)}
 json.dump(out, open(O + "/pmc_summary.json", "w"), indent=1)
 for k, v in out.items():
     print(k, v)
