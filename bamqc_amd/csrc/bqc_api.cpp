@@ -20,7 +20,7 @@
 extern "C" {
 void bqc_launch_reads_chunks(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t n_cu, hipStream_t);
 void bqc_launch_nm_extra(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
-void bqc_launch_bases(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, int variant, hipStream_t);
+void bqc_launch_long(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t* rsum, uint32_t max_len, uint32_t n_cu, hipStream_t);
 void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, const uint32_t* parity, hipStream_t);
 void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
@@ -28,7 +28,7 @@ void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* 
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
 void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, hipStream_t);
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
-hipError_t bqc_kernels_init();
+hipError_t bqc_long_init();
 hipError_t bqc_short_init();
 void bqc_launch_trip_list(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t n_cu, hipStream_t);
 }
@@ -57,6 +57,8 @@ struct bqc_dbatch {
     std::vector<LaneCov> cov_after;
     int32_t fasta_cursor_after = -1;
     uint64_t seq = 0;
+    uint32_t* d_rsum = nullptr; // [n_reads][3] per-read sums of the long-read kernel (present when the batch has generic chunks)
+    uint32_t long_max_len = 0;
 };
 
 struct bqc_ctx {
@@ -102,7 +104,6 @@ struct bqc_ctx {
     std::vector<bqc_lane_counts> lanes;
     std::vector<std::vector<bqc_sketch_counts>> sk_out;
     bqc_counts counts{};
-    int bases_variant = 0; // 0 fused, 1 split (BQC_BASES_SPLIT=1)
     std::string err;
 };
 
@@ -161,9 +162,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     c->d_ref.assign(nr, nullptr);
     c->d_refn.assign(nr, nullptr);
     c->ref_len.assign(nr, 0);
-    const char* v = getenv("BQC_BASES_SPLIT");
-    c->bases_variant = (v && v[0] == '1') ? 1 : 0;
-    v = getenv("BQC_NO_FAST");
+    const char* v = getenv("BQC_NO_FAST");
     c->no_fast = v && v[0] == '1';
 #define CCHK(call)                                                                                            \
     do {                                                                                                      \
@@ -179,7 +178,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipGetDeviceProperties(&prop, c->device));
     c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
     CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CCHK(bqc_kernels_init());
+    CCHK(bqc_long_init());
     CCHK(bqc_short_init());
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err, 64));
@@ -263,6 +262,7 @@ struct Prep {
     std::vector<uint64_t> add_idx, add_val;
     uint64_t seq_bytes = 0, qual_bytes = 0, cigar_words = 0;
     bool identity = true;
+    uint32_t long_max_len = 0;
 };
 }
 
@@ -396,7 +396,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, 0});
             win.clear();
         };
-        uint32_t start = 0, count = 0, bases = 0, cl = 0;
+        uint32_t start = 0, count = 0, cl = 0;
+        uint64_t bases = 0;
         auto close_slow = [&]() {
             if (count) P.chunks.push_back(Chunk{start, count, cl, 0});
             count = 0; bases = 0;
@@ -416,9 +417,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
                 continue;
             }
             flush_window();
-            const bool huge = L > BQC_CHUNK_BASES;
-            if (count && (lane != cl || count == (uint32_t)BQC_CHUNK_READS || bases + L > BQC_CHUNK_BASES || huge)) close_slow();
-            if (huge) { P.chunks.push_back(Chunk{(uint32_t)np.size(), 1, lane, 1}); np.push_back(r); continue; }
+            if (count && (lane != cl || count == (uint32_t)BQC_CHUNK_READS || bases + (uint64_t)L > BQC_CHUNK_BASES)) close_slow();
+            P.long_max_len = std::max(P.long_max_len, L);
             if (!count) { start = (uint32_t)np.size(); cl = lane; }
             np.push_back(r);
             ++count; bases += L;
@@ -522,7 +522,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
                  o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
                  o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
-                 o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
+                 o_rsum = cv.take(P.chunks.empty() ? 0 : 12ull * n), o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
     hipError_t he = hipMalloc(&db->dmem, db->dbytes);
     if (he != hipSuccess) { delete db; c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", db->dbytes, hipGetErrorString(he)); }
@@ -570,6 +570,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.nm_extra_read = (const uint32_t*)(base + o_xr); d.nm_extra_val = (const int32_t*)(base + o_xv); d.n_nm_extra = b->n_nm_extra;
     d.cov_list = (const uint32_t*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
     db->d_lane_mask = (uint8_t*)(base + o_mask);
+    db->d_rsum = (uint32_t*)(base + o_rsum); db->long_max_len = P.long_max_len;
     db->d_add_idx = (uint64_t*)(base + o_aidx); db->d_add_val = (uint64_t*)(base + o_aval);
     db->add_idx = P.add_idx; db->add_val = P.add_val;
     db->algo_bytes = 48ull * n + P.seq_bytes + P.qual_bytes + 4 * P.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
@@ -632,17 +633,9 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     if (slow.n_chunks) {
         bqc_launch_reads_chunks(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
         tick(c, "k_reads(generic)");
-        if (c->bases_variant == 0) {
-            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 0, c->stream);
-            tick(c, "k_bases");
-        } else {
-            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 1, c->stream);
-            tick(c, "k_bases<cyc>");
-            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 2, c->stream);
-            tick(c, "k_bases<8mer>");
-            bqc_launch_bases(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, 3, c->stream);
-            tick(c, "k_bases<trip>");
-        }
+        HIPCHK(c, hipMemsetAsync(db->d_rsum, 0, 12ull * db->d.n_reads, c->stream));
+        bqc_launch_long(slow, c->sl, c->d_state, refs, c->d_err, db->d_rsum, db->long_max_len, c->n_cu, c->stream);
+        tick(c, "k_long");
     }
     if (db->d.n_nm_extra) bqc_launch_nm_extra(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
     if (db->d.n_cov_tiles) {

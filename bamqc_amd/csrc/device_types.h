@@ -10,7 +10,7 @@
 #define BQC_TILE_STRIDE 56       // positions owned per wave tile (64 loaded: 8 look-ahead for 8-mers)
 #define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
 #define BQC_CHUNK_READS 128      // max reads per chunk
-#define BQC_CHUNK_BASES 24576    // max bases per chunk (bounds the u16 8-mer counters, see k_bases)
+#define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_MAXLEN 256      // reads up to this length take the short-read fast path (k_short)
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
@@ -22,7 +22,7 @@
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;
-    uint32_t huge; // generic chunks: 1 = single read longer than BQC_CHUNK_BASES; fast chunks: unused
+    uint32_t huge; // unused (kept for the 16-byte layout)
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
