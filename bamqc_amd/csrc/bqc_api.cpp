@@ -236,9 +236,9 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
     uint8_t* p = nullptr;
     HIPCHK(c, hipMalloc(&p, len ? len : 1));
     HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
-    const uint64_t nd8 = (len + 7) / 8; // nibble table: nd8 + 2 dwords; 2-bit table behind it: (nd8 + 1) / 2 + 2 dwords
+    const uint64_t nd8 = (len + 7) / 8; // nibble table of the fast path: 2 pad dwords + nd8 + 2 pad dwords
     uint32_t* pn = nullptr;
-    HIPCHK(c, hipMalloc(&pn, (nd8 + 2 + (nd8 + 1) / 2 + 2) * 4));
+    HIPCHK(c, hipMalloc(&pn, (nd8 + 4) * 4));
     bqc_launch_ref_nibbles(p, len, pn, nd8, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->d_ref[rid] = p;
@@ -363,37 +363,34 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         P.perm.resize(n);
         for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
     }
-    { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> generic (chunks).
-      // Inside a fast chunk the reads are grouped by mate (stable), so that every group of reads a wave handles at once is
-      // mate-uniform (k_short then updates one register set per group) while all the loads of a chunk stay together.
+    { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> k_long (chunks).
+      // A fast chunk is [first-mate reads | second-mate reads] of one stretch of the stream (stable), each part padded with
+      // null entries (0xFFFFFFFF) to a multiple of the reads a wave handles at once: half of k_short's waves walk the first
+      // part, half the second, at the same pace, so both mates of a stretch are touched close together in time (their
+      // 128-byte lines are shared: the second touch hits L2) and a wave accumulates per-cycle counts of one mate only.
         uint32_t maxfast = 0;
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
-        P.fast_w = std::max(10u, (maxfast + 7) / 8); // >= 10 keeps the per-wave staging tile within its LDS budget
-        const uint32_t per_pass = 16u * (64u / P.fast_w);
-        const uint32_t fast_reads = 960u - 960u % per_pass; // + padding entries stays <= KS_CHUNK (one LDS record per entry)
+        P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
+        const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
+        const uint32_t per_pass = 16u * rpw;
+        const uint32_t fast_reads = std::max(per_pass, (BQC_FAST_CHUNK - 2u * (rpw - 1u)) / per_pass * per_pass); // reads + padding <= BQC_FAST_CHUNK
         std::vector<uint32_t> np;
         np.reserve(n);
-        const uint32_t rpw = 64u / P.fast_w;
         std::vector<uint32_t> win; // reads of the current fast chunk, in stream order
         uint32_t wlane = 0;
         auto flush_window = [&]() {
-            // Inside a chunk the reads are regrouped in slices of 192: first-mate reads, then second-mate reads, each run
-            // padded with null entries (0xFFFFFFFF) to a multiple of the reads a wave handles at once -> every group of
-            // rpw consecutive records is mate-uniform, and the two runs of a slice are touched close together in time
-            // (their 128-byte lines are shared, so the second touch hits L2).
             if (win.empty()) return;
             const uint32_t first = (uint32_t)np.size();
-            for (size_t o = 0; o < win.size(); o += 192) {
-                const size_t e = std::min(win.size(), o + 192);
-                for (uint32_t m = 0; m < 2; ++m) {
-                    uint32_t cnt = 0;
-                    for (size_t i = o; i < e; ++i)
-                        if (((P.flag[win[i]] & 0x40u) ? 0u : 1u) == m) { np.push_back(win[i]); ++cnt; }
-                    while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
-                }
+            uint32_t part0 = 0;
+            for (uint32_t m = 0; m < 2; ++m) {
+                uint32_t cnt = 0;
+                for (uint32_t r : win)
+                    if (((P.flag[r] & 0x40u) ? 0u : 1u) == m) { np.push_back(r); ++cnt; }
+                while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
+                if (m == 0) part0 = cnt;
             }
-            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, 0});
+            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, part0});
             win.clear();
         };
         uint32_t start = 0, count = 0, cl = 0;

@@ -11,7 +11,8 @@
 #define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
 #define BQC_CHUNK_READS 128      // max reads per chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
-#define BQC_FAST_MAXLEN 256      // reads up to this length take the short-read fast path (k_short)
+#define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
+#define BQC_FAST_CHUNK 1152      // max entries (reads + padding) of a fast chunk = per-read records k_short holds in LDS
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
 
@@ -22,7 +23,7 @@
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;
-    uint32_t huge; // unused (kept for the 16-byte layout)
+    uint32_t aux;  // fast chunks: entries of the first-mate part (the chunk is [first-mate | second-mate], each padded); else unused
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
@@ -68,10 +69,10 @@ struct DevBatch {
     const uint32_t* cov_list;
     const CovTile* cov_tiles;
     uint32_t n_cov_tiles;
-    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 8 * fast_w
+    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 16 * fast_w
     const Chunk* chunks_fast;
     uint32_t n_chunks_fast;
-    uint32_t fast_w;           // lanes per read = ceil(max fast read length / 8)
+    uint32_t fast_w;           // lanes per read = ceil(max fast read length / 16)
     // triplet-eligible fast reads whose CIGAR has more than one operation: generic triplet walk
     const uint32_t* trip_list; // read ids, grouped like perm
     const Chunk* trip_chunks;  // `first` indexes trip_list
@@ -83,7 +84,7 @@ struct DevRefs {
     const uint64_t* len;
     const uint8_t* main_chrom; // [n_refs]
     uint32_t n_refs;
-    // same contigs as one-hot nibbles (A=1 C=2 G=4 T=8, N -> A as Dna5->Dna does), 8 bases per dword,
-    // first base in the top nibble; two zero dwords of padding behind the last base
+    // same contigs as nibbles r1 r0 ~r0 ~r1 (r = code & 3, N -> A as Dna5 -> Dna does), 8 bases per dword, first base in
+    // the top nibble, two zero dwords in front and at least two behind (see k_ref_nibbles)
     const uint32_t* const* refn;
 };
