@@ -374,7 +374,9 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
         const uint32_t per_pass = 16u * rpw;
-        const uint32_t fast_reads = std::max(per_pass, (BQC_FAST_CHUNK - 2u * (rpw - 1u)) / per_pass * per_pass); // reads + padding <= BQC_FAST_CHUNK
+        uint32_t chunk_cap = BQC_FAST_CHUNK;
+        if (const char* e = getenv("BQC_FAST_CHUNK_CAP")) chunk_cap = std::min<uint32_t>(BQC_FAST_CHUNK, std::max(128, atoi(e))); // tuning knob
+        const uint32_t fast_reads = std::max(per_pass, (chunk_cap - 2u * (rpw - 1u)) / per_pass * per_pass); // reads + padding <= BQC_FAST_CHUNK
         std::vector<uint32_t> np;
         np.reserve(n);
         std::vector<uint32_t> win; // reads of the current fast chunk, in stream order

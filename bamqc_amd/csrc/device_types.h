@@ -12,7 +12,7 @@
 #define BQC_CHUNK_READS 128      // max reads per chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
-#define BQC_FAST_CHUNK 1152      // max entries (reads + padding) of a fast chunk = per-read records k_short holds in LDS
+#define BQC_FAST_CHUNK 1024      // max entries (reads + padding) of a fast chunk = per-read records k_short holds in LDS (one per thread)
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
 

@@ -30,7 +30,8 @@
 // LDS map (uint32 words)
 #define KS_T8    0                                 // 16384: 65536 u8 8-mer counters, four per dword
 #define KS_TRIP  (KS_T8 + 16384)                   // [4 groups][256]
-#define KS_CYC   (KS_TRIP + 1024)                  // [2 mates][6: A C G T other qual][KS_CT]
+#define KS_CYC   (KS_TRIP + 1024)                  // [2 mates][6: A C G T other qual][KS_CT], cycle c at (c & 15) * 16 + (c >> 4):
+                                                   // the lanes of a read (c >> 4 = w) hit different banks when they add the same c & 15
 #define KS_NC    (KS_CYC + 2 * 6 * KS_CT)          // [2 mates][KS_CT + 1]
 #define KS_GC    (KS_NC + 2 * (KS_CT + 1))
 #define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
@@ -130,7 +131,7 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
         const uint32_t v = lds[KS_CYC + i];
         if (!v) continue;
         lds[KS_CYC + i] = 0;
-        const uint32_t m = i / (6 * KS_CT), c = (i / KS_CT) % 6, j = i % KS_CT;
+        const uint32_t m = i / (6 * KS_CT), c = (i / KS_CT) % 6, jj = i % KS_CT, j = (jj & 15u) * 16u + (jj >> 4);
         if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
     }
     for (uint32_t i = threadIdx.x; i < 2 * (KS_CT + 1); i += blockDim.x) {
@@ -166,7 +167,7 @@ __device__ __forceinline__ void cyc_zero(CycAcc& A)
 }
 // The counters go to the LDS cycle tile through real functions with by-value arguments (registers, no scratch): rare.
 __device__ __noinline__ void cyc_spill_lds(uint32_t a0, uint32_t a1, uint32_t c0, uint32_t c1, uint32_t g0, uint32_t g1, uint32_t t0, uint32_t t1,
-                                           uint32_t* base /* lds + KS_CYC + mate * 6 * KS_CT + 16 w */)
+                                           uint32_t* base /* lds + KS_CYC + mate * 6 * KS_CT + w */)
 {
     const uint32_t v[8] = {a0, a1, c0, c1, g0, g1, t0, t1};
 #pragma unroll
@@ -174,29 +175,29 @@ __device__ __noinline__ void cyc_spill_lds(uint32_t a0, uint32_t a1, uint32_t c0
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) atomicAdd(base + p * KS_CT + 8 * h + 7 - t, (v[2 * p + h] >> (4 * t)) & 15u);
+            for (int t = 0; t < 8; ++t) atomicAdd(base + p * KS_CT + 16 * (8 * h + 7 - t), (v[2 * p + h] >> (4 * t)) & 15u);
 }
 __device__ __noinline__ void cyc_qflush_lds(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t o2, uint32_t e2, uint32_t o3, uint32_t e3,
-                                            uint32_t* base /* lds + KS_CYC + (mate * 6 + 5) * KS_CT + 16 w */)
+                                            uint32_t* base /* lds + KS_CYC + (mate * 6 + 5) * KS_CT + w */)
 {
     const uint32_t vo[4] = {o0, o1, o2, o3}, ve[4] = {e0, e1, e2, e3};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        atomicAdd(base + 4 * d + 0, vo[d] >> 16);
-        atomicAdd(base + 4 * d + 1, ve[d] >> 16);
-        atomicAdd(base + 4 * d + 2, vo[d] & 0xFFFFu);
-        atomicAdd(base + 4 * d + 3, ve[d] & 0xFFFFu);
+        atomicAdd(base + 16 * (4 * d + 0), vo[d] >> 16);
+        atomicAdd(base + 16 * (4 * d + 1), ve[d] >> 16);
+        atomicAdd(base + 16 * (4 * d + 2), vo[d] & 0xFFFFu);
+        atomicAdd(base + 16 * (4 * d + 3), ve[d] & 0xFFFFu);
     }
 }
 __device__ __forceinline__ void cyc_spill(CycAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
 {
-    cyc_spill_lds(A.l1[0][0], A.l1[1][0], A.l1[0][1], A.l1[1][1], A.l1[0][2], A.l1[1][2], A.l1[0][3], A.l1[1][3], lds + KS_CYC + mate * 6 * KS_CT + 16 * w);
+    cyc_spill_lds(A.l1[0][0], A.l1[1][0], A.l1[0][1], A.l1[1][1], A.l1[0][2], A.l1[1][2], A.l1[0][3], A.l1[1][3], lds + KS_CYC + mate * 6 * KS_CT + w);
 #pragma unroll
     for (int p = 0; p < 4; ++p) { A.l1[0][p] = 0; A.l1[1][p] = 0; }
 }
 __device__ __forceinline__ void cyc_qflush(CycAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
 {
-    cyc_qflush_lds(A.qo[0], A.qe[0], A.qo[1], A.qe[1], A.qo[2], A.qe[2], A.qo[3], A.qe[3], lds + KS_CYC + (mate * 6 + 5) * KS_CT + 16 * w);
+    cyc_qflush_lds(A.qo[0], A.qe[0], A.qo[1], A.qe[1], A.qo[2], A.qe[2], A.qo[3], A.qe[3], lds + KS_CYC + (mate * 6 + 5) * KS_CT + w);
 #pragma unroll
     for (int p = 0; p < 4; ++p) { A.qo[p] = 0; A.qe[p] = 0; }
 }
@@ -420,9 +421,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 // cycles holding anything but A/C/G/T (Dna5 'N' bin) are rare: counted directly
                 uint32_t o0 = xm.x & M & ~P0.oh, o1 = xm.y & M & ~P1.oh;
                 if (o0 | o1) {
-                    uint32_t* ob = lds + KS_CYC + (mate * 6 + 4) * KS_CT + w16;
-                    while (o0) { const uint32_t bit = (uint32_t)__ffs((int)o0) - 1u; o0 &= o0 - 1u; atomicAdd(ob + 7u - (bit >> 2), 1u); }
-                    while (o1) { const uint32_t bit = (uint32_t)__ffs((int)o1) - 1u; o1 &= o1 - 1u; atomicAdd(ob + 15u - (bit >> 2), 1u); }
+                    uint32_t* ob = lds + KS_CYC + (mate * 6 + 4) * KS_CT + w;
+                    while (o0) { const uint32_t bit = (uint32_t)__ffs((int)o0) - 1u; o0 &= o0 - 1u; atomicAdd(ob + 16u * (7u - (bit >> 2)), 1u); }
+                    while (o1) { const uint32_t bit = (uint32_t)__ffs((int)o1) - 1u; o1 &= o1 - 1u; atomicAdd(ob + 16u * (15u - (bit >> 2)), 1u); }
                 }
                 // per-read sums: quality | N << 16 | GC << 24 (L <= 255), one wave-wide prefix scan; the lane at the start of
                 // a slot leaves the running sum before its read in record word 1 and, for the previous slot, after it in word 2
