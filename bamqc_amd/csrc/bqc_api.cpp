@@ -30,6 +30,7 @@ void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevR
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
+uint32_t bqc_short_parts();
 void bqc_launch_trip_list(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t n_cu, hipStream_t);
 }
 
@@ -392,13 +393,20 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
                 while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
                 if (m == 0) part0 = cnt;
             }
-            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, part0});
+            Chunk fc{first, (uint32_t)np.size() - first, wlane, part0, 0, 0, 0, 0};
+            if (win.back() - win.front() + 1 == win.size()) { // consecutive records (always, unless the batch mixes read groups)
+                const uint32_t lastr = win.back();
+                fc.src_first = win.front(); fc.src_count = (uint32_t)win.size();
+                fc.cig_first = P.cigar_off[win.front()];
+                fc.cig_words = P.cigar_off[lastr] + b->n_cigar[lastr] - fc.cig_first;
+            }
+            P.chunks_fast.push_back(fc);
             win.clear();
         };
         uint32_t start = 0, count = 0, cl = 0;
         uint64_t bases = 0;
         auto close_slow = [&]() {
-            if (count) P.chunks.push_back(Chunk{start, count, cl, 0});
+            if (count) P.chunks.push_back(Chunk{start, count, cl, 0, 0, 0, 0, 0});
             count = 0; bases = 0;
         };
         for (uint32_t k = 0; k < n; ++k) {
@@ -430,11 +438,11 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         uint32_t ts = 0, tc = 0, tl = 0, tb = 0;
         for (uint32_t k = 0; k < P.trip_list.size(); ++k) {
             const uint32_t r = P.trip_list[k], lane = b->lane[r], L = b->l_seq[r];
-            if (tc && (lane != tl || tc == 32u || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0}); tc = 0; tb = 0; }
+            if (tc && (lane != tl || tc == 32u || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0, 0, 0, 0, 0}); tc = 0; tb = 0; }
             if (!tc) { ts = k; tl = lane; }
             ++tc; tb += L;
         }
-        if (tc) P.trip_chunks.push_back(Chunk{ts, tc, tl, 0});
+        if (tc) P.trip_chunks.push_back(Chunk{ts, tc, tl, 0, 0, 0, 0, 0});
     }
     // ---- coverage tiles
     for (uint32_t l = 0; l < nl; ++l) {
@@ -618,10 +626,12 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
     DevBatch slow = db->d; // generic kernels see only the reads that are not on the fast path
     if (db->d.n_chunks_fast) {
-        DevBatch fr = db->d; // per-read statistics of the fast chunks
-        fr.chunks = db->d.chunks_fast; fr.n_chunks = db->d.n_chunks_fast;
-        bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
-        tick(c, "k_reads");
+        if (!(bqc_short_parts() & 8u)) { // (profiling only: per-read statistics of the fast chunks as a separate kernel)
+            DevBatch fr = db->d;
+            fr.chunks = db->d.chunks_fast; fr.n_chunks = db->d.n_chunks_fast;
+            bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
+            tick(c, "k_reads");
+        }
         bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
         tick(c, "k_short");
         if (db->d.n_trip_chunks) {

@@ -24,6 +24,9 @@
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;
     uint32_t aux;  // fast chunks: entries of the first-mate part (the chunk is [first-mate | second-mate], each padded); else unused
+    // fast chunks whose reads are consecutive records of the batch: where their columns / CIGAR words live, so that k_short
+    // can pull the next chunk towards L2 while it computes the current one (src_count = 0: unknown)
+    uint32_t src_first, src_count, cig_first, cig_words;
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane

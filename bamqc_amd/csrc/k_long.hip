@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
     uint32_t cur_lane = 0xFFFFFFFFu;
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane
         const bool done = ci >= b.n_chunks;
-        Chunk ch{0, 0, 0xFFFFFFFFu, 0};
+        Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {

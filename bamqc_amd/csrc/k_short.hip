@@ -21,8 +21,10 @@
 //                c(j-1) r(j) c(j) r(j+1) is ONE bit-field extract; ks_flush maps the bins (reverse-strand groups:
 //                complemented and mirrored) to the reference's layout (TripletCounting.hpp:195-236).  Reads whose
 //                CIGAR has more than one operation go to k_trip_list (k_trip.hip).
-//   per-read     flag cascade / histograms stay in k_reads (k_reads.hip), launched over the same chunks.
+//   per-read     flag cascade / scalars / per-read histograms (read_stats.h, the body of k_reads) run thread-per-read in
+//                phase A, where the read's columns are loaded anyway (bamqualcheck.cpp:318-434).
 #include "kernels_common.h"
+#include "read_stats.h"
 
 #define KS_THREADS 1024
 #define KS_WAVES (KS_THREADS / 64)
@@ -37,10 +39,10 @@
 #define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
 #define KS_AC    (KS_AQ + 512)
 #define KS_LUT   (KS_AC + 512)                     // [17][8] masks for "the first n of 16 cycles": nibbles (2), pad (2), bytes (4)
-#define KS_META  (KS_LUT + 17 * 8)                 // per-read records of the current chunk
-#define KS_CHUNK BQC_FAST_CHUNK
+#define KS_META  (KS_LUT + 17 * 8)                 // per-read records: 64 per wave (the reads the wave is working on)
 #define KS_MW    8
-#define KS_WORDS (KS_META + (KS_CHUNK + 1) * KS_MW)  // + one dummy record for lanes past the end of a chunk
+#define KS_RS    (KS_META + (KS_WAVES * 64 + 1) * KS_MW)  // (16 waves x 64 records + one dummy record); per-read statistics (read_stats.h)
+#define KS_WORDS (KS_RS + RS_WORDS)
 #define KS_BIAS  512u                              // seq / qual offsets in the records are biased so that they stay non-negative
 
 static_assert((KS_LUT % 4) == 0 && (KS_META % 4) == 0, "16-byte alignment of the LDS tables");
@@ -234,10 +236,9 @@ struct Pre { u32x3 s; u32x4 q; u32x3 e; uint32_t m0, pp, w5; }; // raw data of t
 // Issue the global loads of one group for this lane.  Branch-free: records of non-primary reads, padding entries and the
 // dummy record used by lanes past the end of the chunk carry L = 0 and offsets / pointers that are safe to load from
 // (the buffers are padded on both sides), so every lane always loads; what must not be used is masked when consumed.
-__device__ __forceinline__ Pre ks_prefetch(const uint32_t* META, uint32_t k, bool in_chunk, uint32_t w, g_u8p seqb, g_u8p qualb)
+__device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, g_u8p seqb, g_u8p qualb)
 {
-    const uint32_t kk = in_chunk ? k : (uint32_t)KS_CHUNK;
-    const uint4 ma = *(const uint4*)(META + kk * KS_MW), mb = *(const uint4*)(META + kk * KS_MW + 4);
+    const uint4 ma = *(const uint4*)rec, mb = *(const uint4*)(rec + 4);
     const int32_t sw = (ma.x & 0x10u) ? -(int32_t)w : (int32_t)w;
     Pre P;
     P.m0 = ma.x;
@@ -263,7 +264,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     const uint32_t slot = ln / W, w = ln % W, w16 = 16u * w;
     const bool lane_used = slot < rpw;
     const bool last_w = (w + 1u >= W) || ln == 63u;   // the next lane belongs to another read
-    uint32_t* META = lds + KS_META;
+    const uint32_t tile_cap = rpw * (64u / rpw);        // reads a wave takes at a time: one record per lane, whole groups
+    uint32_t* WM = lds + KS_META + wave * 64u * KS_MW;   // this wave's records
+    const uint32_t* DUMMY = lds + KS_META + KS_WAVES * 64u * KS_MW; // record for lanes behind the last slot
     const uint32_t* LUT = lds + KS_LUT;
     if (threadIdx.x < 17u) { // masks for "the first n of the lane's 16 cycles"
         const uint32_t n = threadIdx.x, n0 = n < 8u ? n : 8u, n1 = n - n0;
@@ -277,9 +280,10 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     }
     if (threadIdx.x < KS_MW) { // dummy record: L = 0, loadable offsets / pointer
         const uint32_t t = threadIdx.x;
-        META[KS_CHUNK * KS_MW + t] = t == 1 || t == 2 ? KS_BIAS : t == 3 ? 15u : t == 5 ? (24u << 16) : t == 6 ? (uint32_t)(uintptr_t)state
+        lds[KS_META + KS_WAVES * 64u * KS_MW + t] = t == 1 || t == 2 ? KS_BIAS : t == 3 ? 15u : t == 5 ? (24u << 16) : t == 6 ? (uint32_t)(uintptr_t)state
                                    : t == 7 ? (uint32_t)((uintptr_t)state >> 32) : 0u;
     }
+    __syncthreads();
     CycAcc A; // per-cycle accumulators of this wave: reads of ONE mate (a wave only takes groups of `acc_mate`, see below)
     cyc_zero(A);
     uint32_t acc_mate = wave >> 3;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     const uint32_t n_chunks = b.n_chunks_fast;
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane (single call site)
         const bool done = ci >= n_chunks;
-        Chunk ch{0, 0, 0xFFFFFFFFu, 0};
+        Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.chunks_fast[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
@@ -299,19 +303,36 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 n1 = n2 = 0;
                 __syncthreads();
                 ks_flush(lds, sl, state, cur_lane);
-                __syncthreads();
+                rs_flush(lds + KS_RS, sl, state, cur_lane);
             }
             cur_lane = ch.lane;
         }
         if (done) break;
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
-        // ---- phase A: thread per read — the read's record for phase B into LDS
-        for (uint32_t t = threadIdx.x; t < ch.count; t += blockDim.x) {
-            const uint32_t r = b.perm ? b.perm[ch.first + t] : ch.first + t;
+        // The chunk is [first-mate reads | second-mate reads] (each part padded to a multiple of rpw): waves 0-7 take tiles of the
+        // first part, waves 8-15 of the second, so a wave accumulates per-cycle counts of one mate only.
+        uint32_t p_first = 0, p_n = ch.count, tw = wave, tstride = KS_WAVES, mate = ch.aux ? 0u : 1u;
+        if (ch.aux != 0u && ch.aux != ch.count) {
+            mate = wave >> 3; tw = wave & 7u; tstride = KS_WAVES / 2;
+            p_first = mate ? ch.aux : 0u; p_n = mate ? ch.count - ch.aux : ch.aux;
+        }
+        if (mate != acc_mate) { // only when a chunk holds reads of a single mate
+            if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
+            n1 = n2 = 0;
+            acc_mate = mate;
+        }
+        for (uint32_t tb = tw * tile_cap; tb < p_n; tb += tstride * tile_cap) {
+        const uint32_t tn = min(tile_cap, p_n - tb); // entries of this wave's tile (a multiple of rpw)
+        // ---- phase A: lane per read — per-read statistics, and the read's record for phase B into LDS
+        {
+            const uint32_t t = ch.first + p_first + tb + ln;
+            const uint32_t r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
+            const bool live = r != 0xFFFFFFFFu; // not a padding entry
+            if ((parts & 8u) && __ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, live ? r : 0u, live, live);
             uint4 R0 = make_uint4(0u, KS_BIAS, KS_BIAS, 15u);
             uint4 R1 = make_uint4(0u, 24u << 16, (uint32_t)(uintptr_t)state, (uint32_t)((uintptr_t)state >> 32));
-            if (r != 0xFFFFFFFFu) { // not a padding entry
+            if (live) {
                 const uint32_t fl = b.flag[r];
                 R0.x = fl & 0xFFFFu;
                 if (!(fl & 0x900u) && (fl & 0xC0u)) { // reaches get_count / count8mers
@@ -346,27 +367,18 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     }
                 }
             }
-            uint4* Mr = (uint4*)(META + t * KS_MW);
+            uint4* Mr = (uint4*)(WM + ln * KS_MW);
             Mr[0] = R0; Mr[1] = R1;
         }
-        __syncthreads();
-        // ---- phase B: groups of rpw reads per wave.  The chunk is [first-mate reads | second-mate reads] (each part padded to
-        //      a multiple of rpw): waves 0-7 take the groups of the first part, waves 8-15 those of the second, so a wave
-        //      accumulates per-cycle counts of one mate only; both halves advance through the stream at the same pace.
-        uint32_t p_first = 0, p_n = ch.count, g0 = wave, gstride = KS_WAVES, mate = ch.aux ? 0u : 1u;
-        if (ch.aux != 0u && ch.aux != ch.count) {
-            mate = wave >> 3; g0 = wave & 7u; gstride = KS_WAVES / 2;
-            p_first = mate ? ch.aux : 0u; p_n = mate ? ch.count - ch.aux : ch.aux;
-        }
-        if (mate != acc_mate) { // only when a chunk holds reads of a single mate
-            if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
-            n1 = n2 = 0;
-            acc_mate = mate;
-        }
-        const uint32_t n_groups = (p_n + rpw - 1) / rpw;
-        Pre cur = ks_prefetch(META, p_first + g0 * rpw + slot, lane_used && g0 * rpw + slot < p_n, w, g_seq, g_qual);
-        for (uint32_t g = g0; g < n_groups; g += gstride) {
-            const uint32_t k = p_first + g * rpw + slot;
+        // LDS operations of one wave execute in order, so the records are visible to the reads below; only the COMPILER must not
+        // reorder them
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B: groups of rpw reads; the next group's data is loaded while this one is processed
+        const uint32_t n_groups = tn / rpw;
+        Pre cur = ks_prefetch(lane_used ? WM + slot * KS_MW : DUMMY, w, g_seq, g_qual);
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            const uint32_t k = g * rpw + slot; // this lane's record (lanes behind the last slot: unused)
             const uint32_t m0 = cur.m0, w5 = cur.w5, L = (m0 >> 20) & 0xFFu; // L = 0 unless the record reaches get_count
             const bool rc = m0 & 0x10u;
             const uint32_t nv = (uint32_t)min(max((int32_t)L - (int32_t)w16, 0), 16);   // valid cycles of this lane
@@ -409,8 +421,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 E1 = rc ? __brev(F0) : F1;
             }
             { // the raw registers are free again: issue the loads of this wave's next group
-                const uint32_t kn = (g + gstride) * rpw + slot;
-                cur = ks_prefetch(META, p_first + kn, lane_used && kn < p_n, w, g_seq, g_qual);
+                cur = ks_prefetch(lane_used && g + 1u < n_groups ? WM + (k + rpw) * KS_MW : DUMMY, w, g_seq, g_qual);
             }
             const Planes P0 = planes_of(X0), P1 = planes_of(X1);
             // ---- per-cycle counters (the group's mate selects the register set: wave-uniform branch)
@@ -435,9 +446,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t bs = lane_prev(si);
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)si, 63);
                 if (lane_used && w == 0u) {
-                    META[k * KS_MW + 1] = bs;
-                    if (slot) META[(k - 1u) * KS_MW + 2] = bs;
-                    if (slot + 1u == rpw) META[k * KS_MW + 2] = tot; // lanes behind the last slot hold only zeros
+                    WM[k * KS_MW + 1] = bs;
+                    if (slot) WM[(k - 1u) * KS_MW + 2] = bs;
+                    if (slot + 1u == rpw) WM[k * KS_MW + 2] = tot; // lanes behind the last slot hold only zeros
                 }
             }
             // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
@@ -521,15 +532,14 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 }
             }
         }
-        __syncthreads();
-        // ---- phase C: thread per read — per-read histograms from the sums left in the records (QualityCheck.hpp:157-165)
-        if (parts & 1u)
-            for (uint32_t t = threadIdx.x; t < ch.count; t += blockDim.x) {
-                const uint32_t m0 = META[t * KS_MW];
-                if (!(m0 & KM_PRIM)) continue;
-                const uint32_t L = (m0 >> 20) & 0xFFu, sum = META[t * KS_MW + 2] - META[t * KS_MW + 1];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase C: lane per read — per-read histograms from the sums left in the records (QualityCheck.hpp:157-165)
+        if ((parts & 1u) && ln < tn) {
+            const uint32_t m0 = WM[ln * KS_MW];
+            if (m0 & KM_PRIM) {
+                const uint32_t L = (m0 >> 20) & 0xFFu, sum = WM[ln * KS_MW + 2] - WM[ln * KS_MW + 1];
                 const uint32_t qs = sum & 0xFFFFu, nN = (sum >> 16) & 0xFFu, nGC = sum >> 24;
-                const uint32_t mate = (m0 & 0x40u) ? 0u : 1u;
                 atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + nN], 1u);
                 atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + nGC], 1u);
                 if (L > 0) { // round-half-away and ceil of qs/L in exact integer arithmetic
@@ -537,9 +547,13 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     atomicAdd(&lds[KS_AC + mate * 256 + (((qs + L - 1u) / L) & 255u)], 1u);
                 }
             }
-        __syncthreads(); // META is rewritten by the next chunk
+        }
+        asm volatile("" ::: "memory"); // the records are rewritten by the next tile
+        __builtin_amdgcn_wave_barrier();
+        } // tiles
     }
 }
+
 
 // Dna5 bytes -> reference table of the fast path: one nibble  r1 r0 ~r0 ~r1  per base (r = Dna5 code & 3, i.e. N -> A like
 // Dna5 -> Dna), 8 bases per dword, first base in the top nibble; bases 0.. start at dword 2 (two zero dwords in front, at
@@ -565,6 +579,15 @@ extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32
     hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((nd8 + 4 + 255) / 256)), dim3(256), 0, s, dna5, len, out, nd8);
 }
 
+// BQC_SHORT_PARTS: ablation switch for profiling (1 cycles + per-read sums, 2 8-mers, 4 triplets, 8 per-read statistics;
+// without 8 the caller runs k_reads over the fast chunks instead)
+extern "C" uint32_t bqc_short_parts()
+{
+    static uint32_t parts = 0xFFFFFFFFu;
+    if (parts == 0xFFFFFFFFu) { const char* e = getenv("BQC_SHORT_PARTS"); parts = e ? (uint32_t)atoi(e) : 15u; }
+    return parts;
+}
+
 extern "C" hipError_t bqc_short_init()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_short), hipFuncAttributeMaxDynamicSharedMemorySize, KS_WORDS * 4);
@@ -575,7 +598,5 @@ extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint6
 {
     if (b.n_chunks_fast == 0) return;
     if (grid > b.n_chunks_fast) grid = b.n_chunks_fast;
-    static uint32_t parts = 0xFFFFFFFFu; // BQC_SHORT_PARTS: ablation switch for profiling (1 cycles + per-read sums, 2 8-mers, 4 triplets)
-    if (parts == 0xFFFFFFFFu) { const char* e = getenv("BQC_SHORT_PARTS"); parts = e ? (uint32_t)atoi(e) : 15u; }
-    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, parts);
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts());
 }

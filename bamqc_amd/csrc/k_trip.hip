@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void k_trip_list(DevBatch b, StateLayout sl, u
     uint32_t cur_lane = 0xFFFFFFFFu;
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) {
         const bool done = ci >= b.n_trip_chunks;
-        Chunk ch{0, 0, 0xFFFFFFFFu, 0};
+        Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.trip_chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform: flush
             __syncthreads();
