@@ -26,7 +26,7 @@ void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
-void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, hipStream_t);
+void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t t8_lane, hipStream_t);
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
@@ -60,6 +60,7 @@ struct bqc_dbatch {
     uint64_t seq = 0;
     uint32_t* d_rsum = nullptr; // [n_reads][3] per-read sums of the long-read kernel (present when the batch has generic chunks)
     uint32_t long_max_len = 0;
+    uint32_t t8_lane = 0; // read group with the most fast chunks: its 8-mer counts go through the scratch rows
 };
 
 struct bqc_ctx {
@@ -72,6 +73,7 @@ struct bqc_ctx {
     uint32_t n_cu = 256;
     uint64_t* d_state = nullptr;
     uint32_t* d_err = nullptr;
+    uint32_t* d_t8rows = nullptr; // [n_cu][65536] per-workgroup 8-mer rows of k_short (zero between launches)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
     uint32_t* d_parity = nullptr; // [lane]
     uint8_t* d_started = nullptr; // [lane]
@@ -183,6 +185,8 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(bqc_short_init());
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err, 64));
+    CCHK(hipMalloc(&c->d_t8rows, (size_t)c->n_cu * 65536 * 4));
+    CCHK(hipMemsetAsync(c->d_t8rows, 0, (size_t)c->n_cu * 65536 * 4, c->stream));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
     CCHK(hipMalloc(&c->d_parity, (size_t)opt->n_lanes * 4));
     CCHK(hipMalloc(&c->d_started, opt->n_lanes));
@@ -221,7 +225,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     for (auto p : c->d_refn) if (p) (void)hipFree(p);
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
-    (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
+    (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
     (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -578,6 +582,10 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.cov_list = (const uint32_t*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
     db->d_lane_mask = (uint8_t*)(base + o_mask);
     db->d_rsum = (uint32_t*)(base + o_rsum); db->long_max_len = P.long_max_len;
+    { // the read group with the most fast chunks
+        std::vector<uint32_t> cnt(c->opt.n_lanes, 0);
+        for (const Chunk& fc : P.chunks_fast) if (++cnt[fc.lane] > cnt[db->t8_lane]) db->t8_lane = fc.lane;
+    }
     db->d_add_idx = (uint64_t*)(base + o_aidx); db->d_add_val = (uint64_t*)(base + o_aval);
     db->add_idx = P.add_idx; db->add_val = P.add_val;
     db->algo_bytes = 48ull * n + P.seq_bytes + P.qual_bytes + 4 * P.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
@@ -597,6 +605,7 @@ static int check_device_error(bqc_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!e) return 0;
     c->poisoned = true;
+    if (e & BQC_DEVERR_INTERNAL) return fail(c, BQC_ERR_DEVICE, "internal error: kernel layout assumption violated");
     if (e & BQC_DEVERR_MATE) return fail(c, BQC_ERR_NO_MATE_FLAG, "ERROR: No first or second flag in read");
     if (e & BQC_DEVERR_RANGE) return fail(c, BQC_ERR_RANGE, "mismatch/deletion/insertion count exceeds hist_cap (or NM < D+I)");
     return fail(c, BQC_ERR_RANGE, "base quality above 222 cannot be represented by the reference (q+33 wraps)");
@@ -632,7 +641,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
             bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
             tick(c, "k_reads");
         }
-        bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
+        bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->d_t8rows, db->t8_lane, c->stream);
         tick(c, "k_short");
         if (db->d.n_trip_chunks) {
             bqc_launch_trip_list(db->d, c->sl, c->d_state, refs, c->n_cu, c->stream);

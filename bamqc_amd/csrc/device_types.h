@@ -20,6 +20,7 @@
 #define BQC_DEVERR_QUAL  1u      // Phred byte > 222 (q+33 wraps in the reference's char arithmetic)
 #define BQC_DEVERR_RANGE 2u      // mismatch / deletion / insertion count >= hist_cap
 #define BQC_DEVERR_MATE  4u      // neither first nor last flag
+#define BQC_DEVERR_INTERNAL 8u   // a kernel found its own layout assumptions violated (never expected)
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;

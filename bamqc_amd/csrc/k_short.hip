@@ -43,6 +43,7 @@
 #define KS_MW    8
 #define KS_RS    (KS_META + (KS_WAVES * 64 + 1) * KS_MW)  // (16 waves x 64 records + one dummy record); per-read statistics (read_stats.h)
 #define KS_WORDS (KS_RS + RS_WORDS)
+#define KS_T8_PERIOD 16                            // chunks between two flushes of the 8-mer counters (~35 counts per bin)
 #define KS_BIAS  512u                              // seq / qual offsets in the records are biased so that they stay non-negative
 
 static_assert((KS_LUT % 4) == 0 && (KS_META % 4) == 0, "16-byte alignment of the LDS tables");
@@ -110,15 +111,47 @@ __device__ __noinline__ void t8_wrap(uint64_t* __restrict__ em, uint32_t h, uint
     }
 }
 
-__device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
+// Rare: some old value of a batch of 8 window atomics has a byte >= 128.  A real function (by-value arguments) that recomputes
+// the windows, so that the hot loop does not keep them in registers.  HB = first window of the batch, f = its count flags.
+template <int HB>
+__device__ __noinline__ void t8_check(uint64_t* __restrict__ em, uint32_t c32, uint32_t cx, uint32_t f, uint32_t o0, uint32_t o1, uint32_t o2,
+                                      uint32_t o3, uint32_t o4, uint32_t o5, uint32_t o6, uint32_t o7)
+{
+    const uint32_t old[8] = {o0, o1, o2, o3, o4, o5, o6, o7};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int kw = HB + kk;
+        const uint32_t h = (kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : __builtin_amdgcn_alignbit(c32, cx, 48 - 2 * kw)) & 0xFFFFu;
+        const bool counted = (f >> (28 - 4 * kk)) & 1u; // a blocked window added 0
+        if (counted && ((old[kk] >> (8u * t8_byte(h))) & 0xFFu) == 0xFFu) t8_wrap(em, h, old[kk]);
+    }
+}
+
+// The packed 8-mer counters of this workgroup go to its own row of a global scratch table (plain read-modify-write of 16 B
+// per thread, no atomics; k_t8_reduce folds the rows into the state vector), or with global atomics when the read group is
+// not the one the scratch table is collecting in this launch.  Called workgroup-uniformly between barriers.
+__device__ __forceinline__ void t8_flush(uint32_t* lds, uint64_t* __restrict__ em, uint4* __restrict__ row /* nullptr: atomics */)
+{
+    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) {
+        const uint32_t v = lds[KS_T8 + i];
+        if (!v) continue;
+        lds[KS_T8 + i] = 0;
+        if (row) { // row[i] = counts of the dword's bytes 0..3, i.e. of bins 4i + (0, 3, 2, 1)
+            uint4 x = row[i];
+            x.x += v & 0xFFu; x.y += (v >> 8) & 0xFFu; x.z += (v >> 16) & 0xFFu; x.w += v >> 24;
+            row[i] = x;
+        } else {
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b)
+                if ((v >> (8u * b)) & 0xFFu) gadd(em + 4u * i + ((4u - b) & 3u), (v >> (8u * b)) & 0xFFu);
+        }
+    }
+}
+
+__device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint4* __restrict__ row)
 {
     const uint64_t lb = sl.lane_base(lane);
-    for (uint32_t i = threadIdx.x; i < 65536; i += blockDim.x) {
-        const uint32_t v = (lds[KS_T8 + (i >> 2)] >> (8u * t8_byte(i))) & 0xFFu;
-        if (v) gadd(state + lb + sl.o_eightmer + i, v);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) lds[KS_T8 + i] = 0;
+    t8_flush(lds, state + lb + sl.o_eightmer, row);
     for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) { // bin = c(j-1) r(j) c(j) r(j+1) of group i >> 8, in cycle space
         const uint32_t v = lds[KS_TRIP + i];
         if (!v) continue;
@@ -219,6 +252,8 @@ typedef u32x3 __attribute__((aligned(1))) u32x3_u;
 typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 typedef u32x3 __attribute__((aligned(4))) u32x3_a;
 typedef const __attribute__((address_space(1))) uint8_t* g_u8p;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ lds_u32* lds_at(uint32_t byte_addr) { return (lds_u32*)(uintptr_t)byte_addr; }
 
 // record of one read in the chunk's LDS table (written by phase A)
 #define KM_PRIM   0x10000u   // primary record with first/last flag: reaches get_count / count8mers
@@ -253,9 +288,14 @@ __device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, g_u8
 }
 
 __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                         uint32_t* __restrict__ err, uint32_t parts)
+                                                         uint32_t* __restrict__ err, uint32_t parts, uint4* __restrict__ t8rows,
+                                                         uint32_t t8_lane, uint32_t t8_period)
 {
     extern __shared__ uint32_t lds[];
+    if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KS_T8 at LDS address 0)
+        if (threadIdx.x == 0) atomicOr(err, BQC_DEVERR_INTERNAL);
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     const uint32_t M = 0x11111111u;
@@ -288,7 +328,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     cyc_zero(A);
     uint32_t acc_mate = wave >> 3;
     uint32_t n1 = 0, n2 = 0; // groups since the last counter spill / quality flush (wave-uniform)
-    uint32_t cur_lane = 0xFFFFFFFFu;
+    uint32_t cur_lane = 0xFFFFFFFFu, since_t8 = 0;
 
     const g_u8p g_seq = (g_u8p)(uintptr_t)(b.seq - KS_BIAS);
     const g_u8p g_qual = (g_u8p)(uintptr_t)(b.qual - KS_BIAS);
@@ -302,12 +342,19 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
                 n1 = n2 = 0;
                 __syncthreads();
-                ks_flush(lds, sl, state, cur_lane);
+                ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
                 rs_flush(lds + KS_RS, sl, state, cur_lane);
             }
             cur_lane = ch.lane;
+            since_t8 = 0;
         }
         if (done) break;
+        if (++since_t8 > t8_period) { // keep the packed u8 counters small, so that the wrap check below stays on its fast path
+            since_t8 = 1;
+            __syncthreads();
+            t8_flush(lds, state + sl.lane_base(cur_lane) + sl.o_eightmer, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
+            __syncthreads();
+        }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
         // The chunk is [first-mate reads | second-mate reads] (each part padded to a multiple of rpw): waves 0-7 take tiles of the
@@ -461,29 +508,34 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t cx = lane_next(c32);
                 uint32_t nbx = lane_next(nb0);
                 if (last_w) nbx = M;
-                if (nv) {
+                // a window is blocked when any of its 8 cycles is: OR-smear over the next 7 positions of the flag stream nb0 nb1 nbx
+                uint32_t f0, f1;
+                {
+                    const uint32_t a0 = nb0 | alignbit(nb0, nb1, 28), a1 = nb1 | alignbit(nb1, nbx, 28), ax = nbx | (nbx << 4);
+                    const uint32_t b0 = a0 | alignbit(a0, a1, 24), b1 = a1 | alignbit(a1, ax, 24), bx = ax | (ax << 8);
+                    f0 = ~(b0 | alignbit(b0, b1, 16)); // nibble LSB set <=> the window starting there is counted
+                    f1 = ~(b1 | alignbit(b1, bx, 16));
+                }
+                // Branch-free: every lane issues all 16 returning atomics; a blocked window (and every window of a lane without
+                // valid cycles) adds 0.  The address is the LDS byte address itself: KS_T8 = 0 and the dynamic LDS block starts
+                // at 0 (checked at kernel entry), which saves the base addition per window.
+                if (nv)
 #pragma unroll
-                    for (int hb = 0; hb < 16; hb += 8) { // two batches of 8 windows: issue the returning atomics, then look at the old values
-                        uint32_t old[8];
+                for (int hb = 0; hb < 16; hb += 8) { // two batches of 8 windows: issue the atomics, then look at the old values
+                    uint32_t old[8];
 #pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) {
-                            const int kw = hb + kk;
-                            const uint32_t blocked = kw == 0 ? nb0 : kw < 8 ? alignbit(nb0, nb1, 32 - 4 * kw) : kw == 8 ? nb1 : alignbit(nb1, nbx, 64 - 4 * kw);
-                            const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw); // window in the low 16 bits
-                            old[kk] = 0;
-                            if (blocked == 0u) old[kk] = atomicAdd(&lds[KS_T8 + ((h & 0xFFFCu) >> 2)], alignbyte(1u, 1u, h));
-                        }
-                        uint32_t hot = 0;
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int kw = hb + kk;
+                        const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw); // window in the low 16 bits
+                        const uint32_t one = bfe(kw < 8 ? f0 : f1, 28 - 4 * (kw & 7), 1);
+                        old[kk] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    uint32_t hot = 0;
 #pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) hot |= old[kk];
-                        if (hot & 0x80808080u) { // some counter of a touched dword is >= 128: look precisely (rare)
-#pragma unroll
-                            for (int kk = 0; kk < 8; ++kk) {
-                                const int kw = hb + kk;
-                                const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw);
-                                if (((old[kk] >> (8u * t8_byte(h))) & 0xFFu) == 0xFFu) t8_wrap(em, h & 0xFFFFu, old[kk]); // old == 0 for skipped windows
-                            }
-                        }
+                    for (int kk = 0; kk < 8; ++kk) hot |= old[kk];
+                    if (hot & 0x80808080u) { // some counter of a touched dword is >= 128: look precisely (rare)
+                        if (hb == 0) t8_check<0>(em, c32, cx, f0, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
+                        else t8_check<8>(em, c32, cx, f1, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
                     }
                 }
             }
@@ -593,10 +645,30 @@ extern "C" hipError_t bqc_short_init()
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_short), hipFuncAttributeMaxDynamicSharedMemorySize, KS_WORDS * 4);
 }
 
+// Fold the per-workgroup 8-mer rows into the state vector and clear them: thread per LDS dword (4 bins).
+__global__ __launch_bounds__(256) void k_t8_reduce(uint4* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ em)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 16384u) return;
+    uint64_t a = 0, b = 0, c = 0, d = 0;
+    for (uint32_t r = 0; r < n_rows; ++r) {
+        const uint4 x = rows[(size_t)r * 16384u + i];
+        if (x.x | x.y | x.z | x.w) rows[(size_t)r * 16384u + i] = make_uint4(0, 0, 0, 0);
+        a += x.x; b += x.y; c += x.z; d += x.w;
+    }
+    if (a) gadd(em + 4u * i + 0u, a);
+    if (b) gadd(em + 4u * i + 3u, b);
+    if (c) gadd(em + 4u * i + 2u, c);
+    if (d) gadd(em + 4u * i + 1u, d);
+}
+
 extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                 uint32_t grid, hipStream_t s)
+                                 uint32_t grid, uint32_t* t8rows, uint32_t t8_lane, hipStream_t s)
 {
     if (b.n_chunks_fast == 0) return;
     if (grid > b.n_chunks_fast) grid = b.n_chunks_fast;
-    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts());
+    static uint32_t period = 0;
+    if (!period) { const char* e = getenv("BQC_T8_PERIOD"); period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : KS_T8_PERIOD; } // tuning knob
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_lane, period);
+    hipLaunchKernelGGL(k_t8_reduce, dim3(64), dim3(256), 0, s, (uint4*)t8rows, grid, state + sl.lane_base(t8_lane) + sl.o_eightmer);
 }
