@@ -257,8 +257,9 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
 // ---------------------------------------------------------------------------------------------------
 namespace {
 struct Prep {
-    std::vector<uint16_t> flag, cov_off;
-    std::vector<uint32_t> cov_win, seq_off, qual_off, cigar_off, perm, cov_list;
+    std::vector<uint16_t> flag;
+    std::vector<uint32_t> seq_off, qual_off, cigar_off, perm;
+    std::vector<CovEntry> cov_list;
     std::vector<Chunk> chunks, chunks_fast, trip_chunks;
     std::vector<uint32_t> trip_list;
     uint32_t fast_w = 10;
@@ -290,11 +291,12 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
 {
     const uint32_t n = b->n_reads;
     const uint32_t nl = c->opt.n_lanes;
-    P.flag.resize(n); P.cov_off.assign(n, 0); P.cov_win.assign(n, 0);
+    P.flag.resize(n);
     P.seq_off.resize(n); P.qual_off.resize(n); P.cigar_off.resize(n);
     P.lane_mask.assign(nl, 0);
     uint64_t so = 0, qo = 0, co = 0;
-    std::vector<std::vector<uint32_t>> lane_list(nl), lane_win(nl);
+    std::vector<std::vector<CovEntry>> lane_list(nl); // covered intervals, in stream order (windows never decrease)
+    std::vector<std::vector<uint32_t>> lane_win(nl), lane_ewin(nl); // first live window per coverage read / per interval
     std::vector<uint8_t> started_before(nl);
     for (uint32_t l = 0; l < nl; ++l) {
         started_before[l] = !c->cov[l].first;
@@ -345,11 +347,35 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
                 }
                 const uint64_t rel = s.win - s.batch_base;
                 if (rel > 0xFFFFFFF0ull) return fail(c, BQC_ERR_ARG, "batch spans too many coverage windows (split the batch)");
-                P.cov_win[i] = (uint32_t)rel;
-                P.cov_off[i] = (uint16_t)pos; // 0..2000
                 flag |= BQC_FLAG_COV;
-                lane_list[lane].push_back(i);
                 lane_win[lane].push_back((uint32_t)rel);
+                // The read's covered interval(s) relative to its first live window (OverallNumbers.hpp:112-131): `c` runs over the
+                // seq-oriented CIGAR (reversed for reverse reads, bamqualcheck.cpp:349) and advances on S, M and D; M and D add
+                // coverage.  DEFINED: increments at window offset >= 2000 are dropped.  One interval unless a clip sits between
+                // two match operations.
+                {
+                    const bool rc = flag & 0x10;
+                    uint32_t cc = 0; // `int c` in the reference; wraps identically
+                    int64_t run_a = -1, run_z = -1;
+                    auto emit = [&]() {
+                        int64_t a = run_a, z = std::min<int64_t>(run_z, 2 * BQC_VSIZE);
+                        if (a >= 0 && a < z) {
+                            lane_list[lane].push_back(CovEntry{(uint32_t)rel, (uint32_t)a | ((uint32_t)(z - a) << 16)});
+                            lane_ewin[lane].push_back((uint32_t)rel);
+                        }
+                    };
+                    for (uint32_t k = 0; k < nc; ++k) {
+                        const uint32_t w = cg[rc ? nc - 1 - k : k], op = w & 15u, nn = w >> 4;
+                        if (op == 4u) cc += nn;
+                        if (op == 0u || op == 2u) {
+                            const int64_t a = (int64_t)pos + cc, z = a + nn;
+                            if (run_z == a) run_z = z;
+                            else { emit(); run_a = a; run_z = z; }
+                            cc += nn;
+                        }
+                    }
+                    emit();
+                }
             }
         }
         P.flag[i] = (uint16_t)flag;
@@ -452,7 +478,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
     for (uint32_t l = 0; l < nl; ++l) {
         const auto& list = lane_list[l];
         const auto& win = lane_win[l];
-        if (list.empty()) continue;
+        const auto& ewin = lane_ewin[l];
+        if (win.empty()) continue;
         P.lane_mask[l] = 1;
         const uint32_t W1 = win.back(); // windows < W1 are complete after this batch
         const uint32_t base_off = (uint32_t)P.cov_list.size();
@@ -476,8 +503,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         for (uint32_t t : need) {
             const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
             const uint32_t lo_key = wlo == 0 ? 0 : wlo - 1;
-            const uint32_t b0 = (uint32_t)(std::lower_bound(win.begin(), win.end(), lo_key) - win.begin());
-            const uint32_t b1 = (uint32_t)(std::lower_bound(win.begin(), win.end(), wlo + BQC_COV_TILE_WINDOWS) - win.begin());
+            const uint32_t b0 = (uint32_t)(std::lower_bound(ewin.begin(), ewin.end(), lo_key) - ewin.begin());
+            const uint32_t b1 = (uint32_t)(std::lower_bound(ewin.begin(), ewin.end(), wlo + BQC_COV_TILE_WINDOWS) - ewin.begin());
             CovTile ct{};
             ct.lane = l; ct.win_lo = wlo; ct.list_begin = base_off + b0; ct.list_end = base_off + b1; ct.win_final = W1;
             P.tiles.push_back(ct);
@@ -527,12 +554,12 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     Carver cv;
     const size_t o_flag = cv.take(2ull * n), o_mapq = cv.take(n), o_lane = cv.take(n), o_rid = cv.take(4ull * n), o_pos = cv.take(4ull * n),
                  o_tlen = cv.take(4ull * n), o_nm = cv.take(4ull * n), o_as = cv.take(4ull * n), o_lseq = cv.take(4ull * n),
-                 o_ncig = cv.take(2ull * n), o_coff = cv.take(2ull * n), o_cwin = cv.take(4ull * n), o_soff = cv.take(4ull * n),
+                 o_ncig = cv.take(2ull * n), o_soff = cv.take(4ull * n),
                  o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 512), o_qual = cv.take(P.qual_bytes + 512),
                  o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * P.perm.size()),
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
                  o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
-                 o_clist = cv.take(4ull * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
+                 o_clist = cv.take(sizeof(CovEntry) * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
                  o_rsum = cv.take(P.chunks.empty() ? 0 : 12ull * n), o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
     hipError_t he = hipMalloc(&db->dmem, db->dbytes);
@@ -547,8 +574,8 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     } while (0)
     UP(o_flag, P.flag.data(), 2ull * n); UP(o_mapq, b->mapq, n); UP(o_lane, b->lane, n); UP(o_rid, b->rid, 4ull * n);
     UP(o_pos, b->pos, 4ull * n); UP(o_tlen, b->tlen, 4ull * n); UP(o_nm, b->nm, 4ull * n); UP(o_as, b->as, 4ull * n);
-    UP(o_lseq, b->l_seq, 4ull * n); UP(o_ncig, b->n_cigar, 2ull * n); UP(o_coff, P.cov_off.data(), 2ull * n);
-    UP(o_cwin, P.cov_win.data(), 4ull * n); UP(o_soff, P.seq_off.data(), 4ull * n); UP(o_qoff, P.qual_off.data(), 4ull * n);
+    UP(o_lseq, b->l_seq, 4ull * n); UP(o_ncig, b->n_cigar, 2ull * n);
+    UP(o_soff, P.seq_off.data(), 4ull * n); UP(o_qoff, P.qual_off.data(), 4ull * n);
     UP(o_cgoff, P.cigar_off.data(), 4ull * n); UP(o_seq, b->seq, P.seq_bytes); UP(o_qual, b->qual, P.qual_bytes);
     UP(o_cig, b->cigar, 4 * P.cigar_words);
     if (!P.identity) UP(o_perm, P.perm.data(), 4ull * P.perm.size());
@@ -557,7 +584,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     UP(o_tl, P.trip_list.data(), 4ull * P.trip_list.size());
     UP(o_tch, P.trip_chunks.data(), sizeof(Chunk) * P.trip_chunks.size());
     UP(o_xr, b->nm_extra_read, 4ull * b->n_nm_extra); UP(o_xv, b->nm_extra_val, 4ull * b->n_nm_extra);
-    UP(o_clist, P.cov_list.data(), 4ull * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
+    UP(o_clist, P.cov_list.data(), sizeof(CovEntry) * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
     UP(o_mask, P.lane_mask.data(), c->opt.n_lanes);
     std::vector<uint8_t> st(c->opt.n_lanes);
     for (uint32_t l = 0; l < c->opt.n_lanes; ++l) st[l] = !c->cov[l].first; // lanes that have seen a coverage read so far
@@ -570,7 +597,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.flag = (const uint16_t*)(base + o_flag); d.mapq = (const uint8_t*)(base + o_mapq); d.lane = (const uint8_t*)(base + o_lane);
     d.rid = (const int32_t*)(base + o_rid); d.pos = (const int32_t*)(base + o_pos); d.tlen = (const int32_t*)(base + o_tlen);
     d.nm = (const int32_t*)(base + o_nm); d.as_ = (const int32_t*)(base + o_as); d.l_seq = (const uint32_t*)(base + o_lseq);
-    d.n_cigar = (const uint16_t*)(base + o_ncig); d.cov_off = (const uint16_t*)(base + o_coff); d.cov_win = (const uint32_t*)(base + o_cwin);
+    d.n_cigar = (const uint16_t*)(base + o_ncig);
     d.seq_off = (const uint32_t*)(base + o_soff); d.qual_off = (const uint32_t*)(base + o_qoff); d.cigar_off = (const uint32_t*)(base + o_cgoff);
     d.seq = (const uint8_t*)(base + o_seq); d.qual = (const uint8_t*)(base + o_qual); d.cigar = (const uint32_t*)(base + o_cig);
     d.perm = P.identity ? nullptr : (const uint32_t*)(base + o_perm);
@@ -579,7 +606,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.chunks_fast = (const Chunk*)(base + o_chf); d.n_chunks_fast = (uint32_t)P.chunks_fast.size(); d.fast_w = P.fast_w;
     d.trip_list = (const uint32_t*)(base + o_tl); d.trip_chunks = (const Chunk*)(base + o_tch); d.n_trip_chunks = (uint32_t)P.trip_chunks.size();
     d.nm_extra_read = (const uint32_t*)(base + o_xr); d.nm_extra_val = (const int32_t*)(base + o_xv); d.n_nm_extra = b->n_nm_extra;
-    d.cov_list = (const uint32_t*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
+    d.cov_list = (const CovEntry*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
     db->d_lane_mask = (uint8_t*)(base + o_mask);
     db->d_rsum = (uint32_t*)(base + o_rsum); db->long_max_len = P.long_max_len;
     { // the read group with the most fast chunks

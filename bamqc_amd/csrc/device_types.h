@@ -30,10 +30,15 @@ struct Chunk {        // lane-uniform run of reads (indices into perm, or read i
     uint32_t src_first, src_count, cig_first, cig_words;
 };
 
+struct CovEntry {     // one covered interval: positions [win * 1000 + off, + len) in window coordinates, off + len <= 2000
+    uint32_t win;     // batch-relative index of the read's first live window
+    uint32_t off_len; // off | len << 16
+};
+
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
     uint32_t lane;
     uint32_t win_lo;      // first window (batch-relative index)
-    uint32_t list_begin;  // candidate reads: cov_list[list_begin, list_end)
+    uint32_t list_begin;  // candidate intervals: cov_list[list_begin, list_end)
     uint32_t list_end;
     uint32_t win_final;   // windows < win_final are complete -> histogram; win_final, win_final+1 -> carry out
     uint32_t pad0, pad1, pad2;
@@ -52,8 +57,6 @@ struct DevBatch {
     const int32_t* as_;
     const uint32_t* l_seq;
     const uint16_t* n_cigar;
-    const uint16_t* cov_off;  // pos - anchor of the read's first live window (0..2000)
-    const uint32_t* cov_win;  // batch-relative index of the read's first live window
     const uint32_t* seq_off;
     const uint32_t* qual_off;
     const uint32_t* cigar_off;
@@ -70,7 +73,7 @@ struct DevBatch {
     const uint32_t* nm_extra_read;
     const int32_t* nm_extra_val;
     uint32_t n_nm_extra;
-    const uint32_t* cov_list;
+    const CovEntry* cov_list; // covered intervals per read group, in stream order (host pre-pass)
     const CovTile* cov_tiles;
     uint32_t n_cov_tiles;
     // short-read fast path (k_short): lane-uniform chunks of reads with L <= 16 * fast_w

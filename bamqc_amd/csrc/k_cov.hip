@@ -4,23 +4,33 @@
 // ---------------------------------------------------------------------------------------------------
 // k_cov — coverage depth histogram
 // ---------------------------------------------------------------------------------------------------
-// Virtual coordinates: the host runs the order-dependent anchor recurrence (OverallNumbers.hpp:84-110)
-// and numbers every 1000-position window in flush order; a read contributes to
-// [win*1000 + off + c, ...) truncated at (win+2)*1000.  Depth is then order-free.
+// Virtual coordinates: the host runs the order-dependent anchor recurrence (OverallNumbers.hpp:84-110), numbers every
+// 1000-position window in flush order and turns every read into its covered interval(s) [win*1000 + off, + len), already
+// truncated at (win+2)*1000 (CovEntry, 8 B).  Depth is then order-free: +1 / -1 into an LDS difference array per interval,
+// prefix scan, clamp-100 histogram.  One workgroup per tile of 4 windows; the intervals of the NEXT tile are loaded (two
+// per thread, coalesced) while the current tile is scanned.
 __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_t* __restrict__ state,
                                                 uint32_t* __restrict__ carry /* [lane][2][2000] */, const uint32_t* __restrict__ parity)
 {
-    __shared__ int32_t diff[BQC_COV_TILE + 8];
+    __shared__ __attribute__((aligned(16))) int32_t diff[4096]; // 256 threads x 16 positions >= BQC_COV_TILE + 1
     __shared__ uint32_t hist[BQC_COVSIZE + 1];
     __shared__ uint32_t wsum[4];
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) diff[i] = 0;
     uint32_t cur_lane = 0xFFFFFFFFu;
+    CovTile t{};
+    t.lane = 0xFFFFFFFFu;
+    CovEntry e0{0, 0}, e1{0, 0}; // len = 0: nothing
+    if (blockIdx.x < b.n_cov_tiles) {
+        t = b.cov_tiles[blockIdx.x];
+        const uint32_t i0 = t.list_begin + threadIdx.x, i1 = i0 + blockDim.x;
+        if (i0 < t.list_end) e0 = b.cov_list[i0];
+        if (i1 < t.list_end) e1 = b.cov_list[i1];
+    }
     // persistent workgroups: the depth histogram stays in LDS across tiles and is flushed once per lane
     for (uint32_t ti = blockIdx.x;; ti += gridDim.x) {
         const bool done = ti >= b.n_cov_tiles;
-        CovTile t{};
-        t.lane = 0xFFFFFFFFu;
-        if (!done) t = b.cov_tiles[ti];
+        if (done) t.lane = 0xFFFFFFFFu;
         if (t.lane != cur_lane) { // block-uniform
             __syncthreads();
             if (cur_lane != 0xFFFFFFFFu)
@@ -29,41 +39,41 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
             cur_lane = t.lane;
         }
         if (done) break;
-        for (uint32_t i = threadIdx.x; i < BQC_COV_TILE + 8; i += blockDim.x) diff[i] = 0;
-        __syncthreads();
-        const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE, hi = lo + BQC_COV_TILE;
-        for (uint32_t e = t.list_begin + threadIdx.x; e < t.list_end; e += blockDim.x) {
-            const uint32_t r = b.cov_list[e];
-            const uint32_t flag = b.flag[r];
-            const bool rc = flag & 0x10;
-            const int64_t base = (int64_t)b.cov_win[r] * BQC_VSIZE;
-            const int64_t limit = base + 2 * BQC_VSIZE; // DEFINED: increments at window offset >= 2000 are dropped
-            const int64_t p0 = base + b.cov_off[r];
-            const uint32_t ncig = b.n_cigar[r];
-            const uint32_t* cg = b.cigar + b.cigar_off[r];
-            uint32_t c = 0; // `int c` in the reference; wraps identically
-            for (uint32_t k = 0; k < ncig; ++k) { // seq-oriented CIGAR: reversed for RC reads (bamqualcheck.cpp:349)
-                const uint32_t w = cg[rc ? ncig - 1 - k : k], op = w & 15u, n = w >> 4;
-                if (op == 4u) c += n;                    // 'S'
-                if (op == 0u || op == 2u) {              // 'M' or 'D'
-                    int64_t a = p0 + c, z = a + n;
-                    if (z > limit) z = limit;
-                    if (a < lo) a = lo;
-                    if (z > hi) z = hi;
-                    if (a < z) {
-                        atomicAdd(&diff[a - lo], 1);
-                        atomicAdd(&diff[z - lo], -1);
-                    }
-                    c += n;
-                }
+        __syncthreads(); // diff is zero (initially / re-zeroed by the second pass of the previous tile)
+        const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE;
+        auto add = [&](const CovEntry& e) {
+            const uint32_t len = e.off_len >> 16;
+            if (!len) return;
+            int64_t a = (int64_t)e.win * BQC_VSIZE + (e.off_len & 0xFFFFu) - lo, z = a + len;
+            if (a < 0) a = 0;
+            if (z > BQC_COV_TILE) z = BQC_COV_TILE;
+            if (a < z) { atomicAdd(&diff[a], 1); atomicAdd(&diff[z], -1); }
+        };
+        add(e0); add(e1);
+        for (uint32_t e = t.list_begin + 2 * blockDim.x + threadIdx.x; e < t.list_end; e += blockDim.x) add(b.cov_list[e]); // (rare: > 512 intervals)
+        const CovTile tc = t;
+        { // next tile of this workgroup: descriptor and first intervals
+            const uint32_t tn = ti + gridDim.x;
+            e0 = CovEntry{0, 0}; e1 = CovEntry{0, 0};
+            if (tn < b.n_cov_tiles) {
+                t = b.cov_tiles[tn];
+                const uint32_t i0 = t.list_begin + threadIdx.x, i1 = i0 + blockDim.x;
+                if (i0 < t.list_end) e0 = b.cov_list[i0];
+                if (i1 < t.list_end) e1 = b.cov_list[i1];
             }
         }
         __syncthreads();
-        // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16)
-        const uint32_t per = (BQC_COV_TILE + 255) / 256;
-        const uint32_t s0 = threadIdx.x * per;
+        // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16), read as 4 x int4
+        const uint32_t s0 = threadIdx.x * 16u;
+        int32_t d[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 v = *(const int4*)&diff[s0 + 4 * q];
+            d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+        }
         int32_t loc = 0;
-        for (uint32_t j = 0; j < per; ++j) if (s0 + j < BQC_COV_TILE) loc += diff[s0 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) loc += (s0 + j < BQC_COV_TILE) ? d[j] : 0;
         int32_t inc = loc; // inclusive wave scan of thread totals
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
@@ -72,29 +82,32 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         }
         if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
         __syncthreads();
+        // this thread's 16 entries are in registers: zero them for the next tile (its atomics come after the barrier on top)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(int4*)&diff[s0 + 4 * q] = make_int4(0, 0, 0, 0);
         int32_t off = inc - loc;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
-        const uint32_t par = parity[t.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
-        const uint32_t* cin = carry + ((uint64_t)t.lane * 2 + par) * 2000;
-        uint32_t* cout = carry + ((uint64_t)t.lane * 2 + (par ^ 1u)) * 2000;
+        const uint32_t par = parity[tc.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
+        const uint32_t* cin = carry + ((uint64_t)tc.lane * 2 + par) * 2000;
+        uint32_t* cout = carry + ((uint64_t)tc.lane * 2 + (par ^ 1u)) * 2000;
         int32_t run = off;
         uint32_t run_bin = 0xFFFFFFFFu, run_n = 0; // consecutive positions mostly share a depth: one LDS atomic per run
-        for (uint32_t j = 0; j < per; ++j) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
             const uint32_t p = s0 + j;
-            if (p >= BQC_COV_TILE) break;
-            run += diff[p];
+            if (p >= BQC_COV_TILE) continue;
+            run += d[j];
             const int64_t vp = lo + p;
             uint32_t depth = (uint32_t)run;
             if (vp < 2 * BQC_VSIZE) depth += cin[vp]; // partial windows carried over from the previous batch
-            const uint32_t win = t.win_lo + p / BQC_VSIZE;
-            if (win < t.win_final) { // update_coverage :66-77
+            const uint32_t win = tc.win_lo + p / BQC_VSIZE;
+            if (win < tc.win_final) { // update_coverage :66-77
                 const uint32_t bin = depth > BQC_COVSIZE ? BQC_COVSIZE : depth;
                 if (bin == run_bin) ++run_n;
                 else { if (run_n) atomicAdd(&hist[run_bin], run_n); run_bin = bin; run_n = 1; }
-            } else if (win < t.win_final + 2) cout[(win - t.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
+            } else if (win < tc.win_final + 2) cout[(win - tc.win_final) * BQC_VSIZE + p % BQC_VSIZE] = depth;
         }
         if (run_n) atomicAdd(&hist[run_bin], run_n);
-        __syncthreads(); // diff / wsum are reused by the next tile
     }
 }
 
