@@ -31,7 +31,6 @@ void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, ui
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
 uint32_t bqc_short_parts();
-void bqc_launch_trip_list(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t n_cu, hipStream_t);
 }
 
 static thread_local char g_create_err[512];
@@ -260,8 +259,8 @@ struct Prep {
     std::vector<uint16_t> flag;
     std::vector<uint32_t> seq_off, qual_off, cigar_off, perm;
     std::vector<CovEntry> cov_list;
-    std::vector<Chunk> chunks, chunks_fast, trip_chunks;
-    std::vector<uint32_t> trip_list;
+    std::vector<Chunk> chunks, chunks_fast;
+    std::vector<TripSeg> segs;
     uint32_t fast_w = 10;
     std::vector<CovTile> tiles;
     std::vector<uint8_t> lane_mask;
@@ -404,14 +403,13 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
         P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
-        const uint32_t per_pass = 16u * rpw;
-        uint32_t chunk_cap = BQC_FAST_CHUNK;
-        if (const char* e = getenv("BQC_FAST_CHUNK_CAP")) chunk_cap = std::min<uint32_t>(BQC_FAST_CHUNK, std::max(128, atoi(e))); // tuning knob
-        const uint32_t fast_reads = std::max(per_pass, (chunk_cap - 2u * (rpw - 1u)) / per_pass * per_pass); // reads + padding <= BQC_FAST_CHUNK
+        const uint32_t part_cap = 8u * rpw * (64u / rpw); // entries per mate part: 8 waves x one tile of whole groups (see k_short)
         std::vector<uint32_t> np;
-        np.reserve(n);
-        std::vector<uint32_t> win; // reads of the current fast chunk, in stream order
-        uint32_t wlane = 0;
+        np.reserve(n + n / 8);
+        std::vector<uint32_t> win;     // reads of the current fast chunk, in stream order
+        std::vector<uint32_t> win_seg; // their triplet segments (indices into P.segs), in the same order
+        uint32_t wlane = 0, nr[2] = {0, 0}, ns[2] = {0, 0}; // per mate part: reads / segments so far
+        auto padded = [&](uint32_t x) { return (x + rpw - 1) / rpw * rpw; };
         auto flush_window = [&]() {
             if (win.empty()) return;
             const uint32_t first = (uint32_t)np.size();
@@ -421,17 +419,14 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
                 for (uint32_t r : win)
                     if (((P.flag[r] & 0x40u) ? 0u : 1u) == m) { np.push_back(r); ++cnt; }
                 while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
+                for (uint32_t k : win_seg)
+                    if (((P.flag[P.segs[k].r] & 0x40u) ? 0u : 1u) == m) { np.push_back(BQC_ENTRY_SEG | k); ++cnt; }
+                while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
                 if (m == 0) part0 = cnt;
             }
-            Chunk fc{first, (uint32_t)np.size() - first, wlane, part0, 0, 0, 0, 0};
-            if (win.back() - win.front() + 1 == win.size()) { // consecutive records (always, unless the batch mixes read groups)
-                const uint32_t lastr = win.back();
-                fc.src_first = win.front(); fc.src_count = (uint32_t)win.size();
-                fc.cig_first = P.cigar_off[win.front()];
-                fc.cig_words = P.cigar_off[lastr] + b->n_cigar[lastr] - fc.cig_first;
-            }
-            P.chunks_fast.push_back(fc);
-            win.clear();
+            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, part0, 0, 0, 0, 0});
+            win.clear(); win_seg.clear();
+            nr[0] = nr[1] = ns[0] = ns[1] = 0;
         };
         uint32_t start = 0, count = 0, cl = 0;
         uint64_t bases = 0;
@@ -446,11 +441,35 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             if (fast) {
                 close_slow();
                 if (!win.empty() && lane != wlane) flush_window();
+                // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
+                // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
+                const uint32_t seg0 = (uint32_t)P.segs.size();
+                if ((P.flag[r] & BQC_FLAG_TRIPLET) && b->n_cigar[r] > 1 && L >= 3) {
+                    const uint32_t* cg = b->cigar + P.cigar_off[r];
+                    const uint32_t n0 = cg[0] >> 4;
+                    if (n0 != 0) { // (n0 == 0: every position counts as inside the first operation, no walk)
+                        uint64_t rp = n0;
+                        int64_t cpos = (int64_t)b->pos[r] + n0;
+                        for (uint32_t k2 = 1; k2 < b->n_cigar[r] && rp < L; ++k2) {
+                            const uint32_t op = cg[k2] & 15u, nn = cg[k2] >> 4;
+                            if (op == 2u || op == 3u || op == 5u || op == 6u) cpos += nn;   // D N H P
+                            else if (op == 4u || op == 1u) rp += nn;                          // S I
+                            else {                                                            // M = X (and unknown)
+                                const uint64_t ia = std::max<uint64_t>(rp, 1), ib = std::min<uint64_t>(rp + nn, (uint64_t)L - 1);
+                                const int64_t posv = cpos - (int64_t)rp;
+                                if (ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2)
+                                    P.segs.push_back(TripSeg{r, (int32_t)posv, (uint32_t)ia | ((uint32_t)ib << 8), 0});
+                                rp += nn; cpos += nn;
+                            }
+                        }
+                    }
+                }
+                const uint32_t m = (P.flag[r] & 0x40u) ? 0u : 1u, add = (uint32_t)P.segs.size() - seg0;
+                if (!win.empty() && padded(nr[m] + 1) + padded(ns[m] + add) > part_cap) flush_window(); // this read opens the next chunk
                 wlane = lane;
                 win.push_back(r);
-                if (win.size() == fast_reads) flush_window();
-                // fast-path triplets assume chromPos = pos + i: reads with several CIGAR operations take the generic walk
-                if ((P.flag[r] & BQC_FLAG_TRIPLET) && (b->n_cigar[r] != 1 || b->pos[r] < 0)) P.trip_list.push_back(r);
+                nr[m] += 1; ns[m] += add;
+                for (uint32_t k = seg0; k < P.segs.size(); ++k) win_seg.push_back(k);
                 continue;
             }
             flush_window();
@@ -464,15 +483,6 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         flush_window();
         P.perm.swap(np);
         P.identity = false;
-        // chunks over the triplet list (grouped by lane because it follows the lane-grouped order)
-        uint32_t ts = 0, tc = 0, tl = 0, tb = 0;
-        for (uint32_t k = 0; k < P.trip_list.size(); ++k) {
-            const uint32_t r = P.trip_list[k], lane = b->lane[r], L = b->l_seq[r];
-            if (tc && (lane != tl || tc == 32u || tb + L > BQC_CHUNK_BASES)) { P.trip_chunks.push_back(Chunk{ts, tc, tl, 0, 0, 0, 0, 0}); tc = 0; tb = 0; }
-            if (!tc) { ts = k; tl = lane; }
-            ++tc; tb += L;
-        }
-        if (tc) P.trip_chunks.push_back(Chunk{ts, tc, tl, 0, 0, 0, 0, 0});
     }
     // ---- coverage tiles
     for (uint32_t l = 0; l < nl; ++l) {
@@ -558,7 +568,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_qoff = cv.take(4ull * n), o_cgoff = cv.take(4ull * n), o_seq = cv.take(P.seq_bytes + 512), o_qual = cv.take(P.qual_bytes + 512),
                  o_cig = cv.take(4 * P.cigar_words + 16), o_perm = cv.take(P.identity ? 0 : 4ull * P.perm.size()),
                  o_chunks = cv.take(sizeof(Chunk) * P.chunks.size()), o_chf = cv.take(sizeof(Chunk) * P.chunks_fast.size()),
-                 o_tl = cv.take(4ull * P.trip_list.size()), o_tch = cv.take(sizeof(Chunk) * P.trip_chunks.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
+                 o_segs = cv.take(sizeof(TripSeg) * P.segs.size()), o_xr = cv.take(4ull * b->n_nm_extra), o_xv = cv.take(4ull * b->n_nm_extra),
                  o_clist = cv.take(sizeof(CovEntry) * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
                  o_rsum = cv.take(P.chunks.empty() ? 0 : 12ull * n), o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
@@ -581,8 +591,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     if (!P.identity) UP(o_perm, P.perm.data(), 4ull * P.perm.size());
     UP(o_chunks, P.chunks.data(), sizeof(Chunk) * P.chunks.size());
     UP(o_chf, P.chunks_fast.data(), sizeof(Chunk) * P.chunks_fast.size());
-    UP(o_tl, P.trip_list.data(), 4ull * P.trip_list.size());
-    UP(o_tch, P.trip_chunks.data(), sizeof(Chunk) * P.trip_chunks.size());
+    UP(o_segs, P.segs.data(), sizeof(TripSeg) * P.segs.size());
     UP(o_xr, b->nm_extra_read, 4ull * b->n_nm_extra); UP(o_xv, b->nm_extra_val, 4ull * b->n_nm_extra);
     UP(o_clist, P.cov_list.data(), sizeof(CovEntry) * P.cov_list.size()); UP(o_tiles, P.tiles.data(), sizeof(CovTile) * P.tiles.size());
     UP(o_mask, P.lane_mask.data(), c->opt.n_lanes);
@@ -604,7 +613,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     d.n_perm = P.identity ? n : (uint32_t)P.perm.size();
     d.chunks = (const Chunk*)(base + o_chunks); d.n_chunks = (uint32_t)P.chunks.size();
     d.chunks_fast = (const Chunk*)(base + o_chf); d.n_chunks_fast = (uint32_t)P.chunks_fast.size(); d.fast_w = P.fast_w;
-    d.trip_list = (const uint32_t*)(base + o_tl); d.trip_chunks = (const Chunk*)(base + o_tch); d.n_trip_chunks = (uint32_t)P.trip_chunks.size();
+    d.segs = (const TripSeg*)(base + o_segs);
     d.nm_extra_read = (const uint32_t*)(base + o_xr); d.nm_extra_val = (const int32_t*)(base + o_xv); d.n_nm_extra = b->n_nm_extra;
     d.cov_list = (const CovEntry*)(base + o_clist); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)P.tiles.size();
     db->d_lane_mask = (uint8_t*)(base + o_mask);
@@ -670,10 +679,6 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
         }
         bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->d_t8rows, db->t8_lane, c->stream);
         tick(c, "k_short");
-        if (db->d.n_trip_chunks) {
-            bqc_launch_trip_list(db->d, c->sl, c->d_state, refs, c->n_cu, c->stream);
-            tick(c, "k_trip_list");
-        }
     }
     if (slow.n_chunks) {
         bqc_launch_reads_chunks(slow, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);

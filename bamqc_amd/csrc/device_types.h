@@ -12,7 +12,6 @@
 #define BQC_CHUNK_READS 128      // max reads per chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
-#define BQC_FAST_CHUNK 1024      // max entries (reads + padding) of a fast chunk = per-read records k_short holds in LDS (one per thread)
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
 
@@ -24,11 +23,20 @@
 
 struct Chunk {        // lane-uniform run of reads (indices into perm, or read ids when perm == nullptr)
     uint32_t first, count, lane;
-    uint32_t aux;  // fast chunks: entries of the first-mate part (the chunk is [first-mate | second-mate], each padded); else unused
-    // fast chunks whose reads are consecutive records of the batch: where their columns / CIGAR words live, so that k_short
-    // can pull the next chunk towards L2 while it computes the current one (src_count = 0: unknown)
-    uint32_t src_first, src_count, cig_first, cig_words;
+    uint32_t aux;  // fast chunks: entries of the first-mate part (the chunk is [first-mate part | second-mate part]); else unused
+    uint32_t pad0, pad1, pad2, pad3;
 };
+
+// Triplet segment of a short read whose CIGAR has several operations: read positions [ia, ib) are one match-like operation
+// (other than the first, which the read's own record covers) aligned at chromPos = posv + i (TripletCounting.hpp:203-232).
+// A mate part of a fast chunk lists them as entries 0x80000000 | index behind its reads: k_short evaluates triplets only for them.
+struct TripSeg {
+    uint32_t r;     // read
+    int32_t posv;   // virtual alignment start: segment's reference start - its first read position
+    uint32_t range; // ia | ib << 8
+    uint32_t pad;
+};
+#define BQC_ENTRY_SEG 0x80000000u // perm entry: TripSeg index (0xFFFFFFFF = padding)
 
 struct CovEntry {     // one covered interval: positions [win * 1000 + off, + len) in window coordinates, off + len <= 2000
     uint32_t win;     // batch-relative index of the read's first live window
@@ -65,8 +73,8 @@ struct DevBatch {
     const uint8_t* qual;   // raw Phred
     const uint32_t* cigar; // len<<4|op
     // work decomposition (host pre-pass)
-    const uint32_t* perm;  // processing order: reads grouped by lane (and by mate inside fast chunks); entries
-                           // 0xFFFFFFFF are padding; nullptr = identity
+    const uint32_t* perm;  // processing order: reads grouped by lane (and by mate inside fast chunks); entries with
+                           // the top bit set are not reads (0xFFFFFFFF padding, else TripSeg index); nullptr = identity
     uint32_t n_perm;       // entries in perm (>= n_reads because of padding), n_reads when perm == nullptr
     const Chunk* chunks;
     uint32_t n_chunks;
@@ -80,10 +88,7 @@ struct DevBatch {
     const Chunk* chunks_fast;
     uint32_t n_chunks_fast;
     uint32_t fast_w;           // lanes per read = ceil(max fast read length / 16)
-    // triplet-eligible fast reads whose CIGAR has more than one operation: generic triplet walk
-    const uint32_t* trip_list; // read ids, grouped like perm
-    const Chunk* trip_chunks;  // `first` indexes trip_list
-    uint32_t n_trip_chunks;
+    const TripSeg* segs;       // triplet segments of fast reads with several CIGAR operations
 };
 
 struct DevRefs {

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint6
             const uint32_t t = t0 + threadIdx.x;
             bool live = t < ch.count;
             uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
-            if (r == 0xFFFFFFFFu) { live = false; r = 0; } // padding entry of a fast chunk
+            if (r & BQC_ENTRY_SEG) { live = false; r = 0; } // padding / triplet-segment entry of a fast chunk
             if (__ballot(live)) read_stats(b, sl, state, refs, err, lds, r, live, live);
         }
     }

@@ -257,7 +257,8 @@ __device__ __forceinline__ lds_u32* lds_at(uint32_t byte_addr) { return (lds_u32
 
 // record of one read in the chunk's LDS table (written by phase A)
 #define KM_PRIM   0x10000u   // primary record with first/last flag: reaches get_count / count8mers
-#define KM_TRIP   0x20000u   // triplet-eligible with a single CIGAR operation, a loaded reference and a non-empty position range
+#define KM_TRIP   0x20000u   // triplets are evaluated for the position range in word 5 (needs a loaded reference)
+#define KM_SEG    0x40000u   // triplet-segment entry: the read's bases / qualities for triplets only (no KM_PRIM)
 // word 0: BAM flag (low 16 bits) | KM_* | L << 20 (L = 0 unless KM_PRIM)
 //      1: seq byte offset of the window of lane w = 0 (+ KS_BIAS)      -> after the group was computed: packed sums before the read
 //      2: qual byte offset of the window of lane w = 0 (+ KS_BIAS)     ->                               packed sums after the read
@@ -357,8 +358,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
-        // The chunk is [first-mate reads | second-mate reads] (each part padded to a multiple of rpw): waves 0-7 take tiles of the
-        // first part, waves 8-15 of the second, so a wave accumulates per-cycle counts of one mate only.
+        // The chunk is [first-mate part | second-mate part]; a part is its reads followed by the triplet segments of those reads,
+        // both padded to a multiple of rpw, and holds at most 8 tiles: waves 0-7 take the tiles of the first part, waves 8-15 of
+        // the second, so a wave accumulates per-cycle counts of one mate only.
         uint32_t p_first = 0, p_n = ch.count, tw = wave, tstride = KS_WAVES, mate = ch.aux ? 0u : 1u;
         if (ch.aux != 0u && ch.aux != ch.count) {
             mate = wave >> 3; tw = wave & 7u; tstride = KS_WAVES / 2;
@@ -374,9 +376,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         // ---- phase A: lane per read — per-read statistics, and the read's record for phase B into LDS
         {
             const uint32_t t = ch.first + p_first + tb + ln;
-            const uint32_t r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
-            const bool live = r != 0xFFFFFFFFu; // not a padding entry
-            if ((parts & 8u) && __ballot(live)) read_stats(b, sl, state, refs, err, lds + KS_RS, live ? r : 0u, live, live);
+            uint32_t r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
+            const bool live = r != 0xFFFFFFFFu;                // not a padding entry
+            const bool seg = live && (r & BQC_ENTRY_SEG);      // triplet segment of a read (the read itself is another entry)
+            TripSeg sg{0, 0, 0, 0};
+            if (seg) { sg = b.segs[r & ~BQC_ENTRY_SEG]; r = sg.r; }
+            if ((parts & 8u) && __ballot(live && !seg)) read_stats(b, sl, state, refs, err, lds + KS_RS, live && !seg ? r : 0u, live && !seg, live && !seg);
             uint4 R0 = make_uint4(0u, KS_BIAS, KS_BIAS, 15u);
             uint4 R1 = make_uint4(0u, 24u << 16, (uint32_t)(uintptr_t)state, (uint32_t)((uintptr_t)state >> 32));
             if (live) {
@@ -386,23 +391,27 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                     const uint32_t L = b.l_seq[r];
                     const bool rc = fl & 0x10u, noq = fl & BQC_FLAG_NO_QUAL;
                     const int32_t o0 = rc ? (int32_t)L - 16 : 0;
-                    R0.x |= KM_PRIM | (L << 20);
+                    R0.x |= (seg ? KM_SEG : KM_PRIM) | (L << 20);
                     R0.y = b.seq_off[r] + (uint32_t)((o0 - 1) >> 1) + KS_BIAS; // the window is loaded from one byte (odd o0: one nibble) earlier
                     R0.z = (noq ? 0u : b.qual_off[r]) + (uint32_t)o0 + KS_BIAS;
                     R1.y = ((o0 & 1) ? 28u : 24u) << 16;
                     const int32_t rid = b.rid[r];
-                    const int64_t pos = b.pos[r];
-                    if ((fl & BQC_FLAG_TRIPLET) && b.n_cigar[r] == 1 && L >= 3 && !noq && rid >= 0 && (uint32_t)rid < refs.n_refs && pos >= 0 &&
+                    if ((fl & BQC_FLAG_TRIPLET) && b.n_cigar[r] >= 1 && L >= 3 && !noq && rid >= 0 && (uint32_t)rid < refs.n_refs &&
                         refs.refn[rid] != nullptr) {
-                        // read positions 1 <= i < ib: inside the read, inside the single CIGAR operation (first operation
-                        // assumed match-like, TripletCounting.hpp:203), context pos+i-1 .. pos+i+1 inside the contig
-                        const uint32_t n0 = b.cigar[b.cigar_off[r]] >> 4;
+                        // read positions ia <= i < ib with chromPos = pos + i: inside the read (1 .. L-2), inside the first CIGAR
+                        // operation (assumed match-like, TripletCounting.hpp:203) or the segment, context pos+i-1 .. pos+i+1 inside the contig
+                        const int64_t pos = seg ? (int64_t)sg.posv : (int64_t)b.pos[r];
                         const int64_t reflen = (int64_t)refs.len[rid];
-                        int64_t ib = (int64_t)L - 1;
-                        if (n0 != 0u && (int64_t)n0 < ib) ib = n0;
+                        int64_t ia = 1, ib = (int64_t)L - 1;
+                        if (seg) { ia = sg.range & 0xFFu; ib = (sg.range >> 8) & 0xFFu; }
+                        else {
+                            const uint32_t n0 = b.cigar[b.cigar_off[r]] >> 4;
+                            if (n0 != 0u && (int64_t)n0 < ib) ib = n0;
+                        }
+                        if (1 - pos > ia) ia = 1 - pos;
                         if (reflen - 1 - pos < ib) ib = reflen - 1 - pos;
-                        if (ib > 1) {
-                            const uint32_t ja = rc ? L - (uint32_t)ib : 1u, jb = rc ? L - 1u : (uint32_t)ib; // the same range in cycles
+                        if (ib > ia && pos > -(1 << 30) && pos < (1 << 30)) {
+                            const uint32_t ja = rc ? L - (uint32_t)ib : (uint32_t)ia, jb = rc ? L - (uint32_t)ia : (uint32_t)ib; // the same range in cycles
                             const uint64_t nd8 = (uint64_t)(reflen + 7) >> 3;
                             R0.x |= KM_TRIP;
                             R0.w = (uint32_t)((int32_t)pos + o0 + 15);
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             const uint32_t k = g * rpw + slot; // this lane's record (lanes behind the last slot: unused)
             const uint32_t m0 = cur.m0, w5 = cur.w5, L = (m0 >> 20) & 0xFFu; // L = 0 unless the record reaches get_count
             const bool rc = m0 & 0x10u;
+            const bool segg = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0) & KM_SEG; // a group of triplet segments: triplets only
             const uint32_t nv = (uint32_t)min(max((int32_t)L - (int32_t)w16, 0), 16);   // valid cycles of this lane
             const uint32_t nvq = (m0 & BQC_FLAG_NO_QUAL) ? 0u : nv;
             const uint2 xm = *(const uint2*)(LUT + 8u * nv);
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             }
             const Planes P0 = planes_of(X0), P1 = planes_of(X1);
             // ---- per-cycle counters (the group's mate selects the register set: wave-uniform branch)
-            if (parts & 1u) {
+            if ((parts & 1u) && !segg) {
                 cyc_add(A, P0, P1, Q);
                 if (++n1 == 15u) { if (lane_used) cyc_spill(A, lds, mate, w); n1 = 0; }
                 if (++n2 == 255u) { if (lane_used) cyc_qflush(A, lds, mate, w); n2 = 0; }
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             // literal N or past the end of the read: blocks 8-mer windows and triplet flanks
             const uint32_t nb0 = P0.n | (~xm.x & M), nb1 = P1.n | (~xm.y & M);
             // ---- 8-mers: windows starting at the lane's 16 cycles
-            if (parts & 2u) {
+            if ((parts & 2u) && !segg) {
                 const uint32_t c32 = vperm(squeeze2(cn0), squeeze2(cn1), 0x05040100u); // cycle 16w in the top two bits
                 const uint32_t cx = lane_next(c32);
                 uint32_t nbx = lane_next(nb0);
@@ -569,17 +579,17 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t ok1 = P1.oh & ~fl1 & pb.y & ~pa.y & vperm(qf[2], qf[3], 0x07060302u);
                 const uint32_t Ip = lane_prev(I1), In = lane_next(I0); // (cross-lane: outside the divergent branch)
                 if (ok0 | ok1) {
-                    uint32_t* tb = lds + KS_TRIP + ((rc ? 2u : 0u) + mate) * 256u;
+                    uint32_t* tbin = lds + KS_TRIP + ((rc ? 2u : 0u) + ((m0 & 0x40u) ? 0u : 1u)) * 256u; // fwd1st fwd2nd rev1st rev2nd
                     const uint32_t SA0 = alignbit(Ip, I0, 6), SB0 = alignbit(I0, I1, 22), SA1 = alignbit(I0, I1, 6), SB1 = alignbit(I1, In, 22);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) { // bin = c(j-1) r(j) c(j) r(j+1): 8 contiguous bits of the [r c] stream
                         const uint32_t i0 = t < 6 ? bfe(SA0, 20 - 4 * t, 8) : bfe(SB0, 12 - 4 * (t - 6), 8);
-                        if (ok0 & (1u << (28 - 4 * t))) atomicAdd(tb + i0, 1u);
+                        if (ok0 & (1u << (28 - 4 * t))) atomicAdd(tbin + i0, 1u);
                     }
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const uint32_t i1 = t < 6 ? bfe(SA1, 20 - 4 * t, 8) : bfe(SB1, 12 - 4 * (t - 6), 8);
-                        if (ok1 & (1u << (28 - 4 * t))) atomicAdd(tb + i1, 1u);
+                        if (ok1 & (1u << (28 - 4 * t))) atomicAdd(tbin + i1, 1u);
                     }
                 }
             }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
         const uint32_t kk = base + threadIdx.x;
         bool live = kk < hi_r;
         uint32_t r = live ? (b.perm ? b.perm[kk] : kk) : 0;
-        if (r == 0xFFFFFFFFu) { live = false; r = 0; } // padding entry
+        if (r & BQC_ENTRY_SEG) { live = false; r = 0; } // padding / triplet-segment entry
         const uint32_t lane = live ? b.lane[r] : 0;
         if (threadIdx.x == 0) s_lane = lane;
         __syncthreads();
