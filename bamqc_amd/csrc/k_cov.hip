@@ -32,14 +32,14 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         const bool done = ti >= b.n_cov_tiles;
         if (done) t.lane = 0xFFFFFFFFu;
         if (t.lane != cur_lane) { // block-uniform
-            __syncthreads();
+            block_sync();
             if (cur_lane != 0xFFFFFFFFu)
                 for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
                     if (hist[i]) { gadd(state + sl.lane_base(cur_lane) + sl.o_poscov + i, hist[i]); hist[i] = 0; }
             cur_lane = t.lane;
         }
         if (done) break;
-        __syncthreads(); // diff is zero (initially / re-zeroed by the second pass of the previous tile)
+        block_sync(); // diff is zero (initially / re-zeroed by the second pass of the previous tile)
         const int64_t lo = (int64_t)t.win_lo * BQC_VSIZE;
         auto add = [&](const CovEntry& e) {
             const uint32_t len = e.off_len >> 16;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
                 if (i1 < t.list_end) e1 = b.cov_list[i1];
             }
         }
-        __syncthreads();
+        block_sync();
         // block scan of diff: 16 consecutive entries per thread (4000 <= 256 * 16), read as 4 x int4
         const uint32_t s0 = threadIdx.x * 16u;
         int32_t d[16];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
             if (lane_id() >= o) inc += v;
         }
         if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
-        __syncthreads();
+        block_sync();
         // this thread's 16 entries are in registers: zero them for the next tile (its atomics come after the barrier on top)
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(int4*)&diff[s0 + 4 * q] = make_int4(0, 0, 0, 0);
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void k_cov_final(StateLayout sl, uint64_t* __r
     const uint32_t lane = blockIdx.x;
     if (!started[lane]) return;
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
+    block_sync();
     const uint32_t* c = carry + ((uint64_t)lane * 2 + (parity[lane] & 1u)) * 2000;
     for (uint32_t i = threadIdx.x; i < 2000; i += blockDim.x) {
         const uint32_t d = c[i];
         atomicAdd(&hist[d > BQC_COVSIZE ? BQC_COVSIZE : d], 1u);
     }
-    __syncthreads();
+    block_sync();
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
         if (hist[i]) gadd(state + sl.lane_base(lane) + sl.o_poscov + i, hist[i]);
     if (threadIdx.x == 0) gadd(state + sl.lane_base(lane) + sl.o_covstart, 1);

@@ -36,7 +36,7 @@ __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, u
         const uint32_t v = (lds[KL_T8 + (i >> 2)] >> (8u * (i & 3u))) & 0xFFu;
         if (v) gadd(state + lb + sl.o_eightmer + i, v);
     }
-    __syncthreads();
+    block_sync();
     for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) lds[KL_T8 + i] = 0;
     for (uint32_t i = threadIdx.x; i < 2 * 6 * KL_CT; i += blockDim.x) {
         const uint32_t v = lds[KL_CYC + i];
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
 {
     extern __shared__ uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < KL_WORDS; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
+    block_sync();
     const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t cyc0 = blockIdx.y * KL_CT;
     uint32_t cur_lane = 0xFFFFFFFFu;
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
         if (!done) ch = b.chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
-                __syncthreads();
+                block_sync();
                 kl_flush(lds, sl, state, cur_lane, cyc0);
-                __syncthreads();
+                block_sync();
             }
             cur_lane = ch.lane;
         }

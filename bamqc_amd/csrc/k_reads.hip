@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint6
     __shared__ uint32_t lds[RS_WORDS];
     for (uint32_t i = threadIdx.x; i < RS_WORDS; i += blockDim.x) lds[i] = 0;
     uint32_t blane = 0xFFFFFFFFu;
-    __syncthreads();
+    block_sync();
     for (uint32_t ci = blockIdx.x; ci < b.n_chunks; ci += gridDim.x) { // lane-uniform chunks (generic-path reads only)
         const Chunk ch = b.chunks[ci];
         if (ch.lane != blane) { // block-uniform

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         return;
     }
     for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
+    block_sync();
     const uint32_t M = 0x11111111u;
     const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t W = b.fast_w, rpw = 64u / W;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         lds[KS_META + KS_WAVES * 64u * KS_MW + t] = t == 1 || t == 2 ? KS_BIAS : t == 3 ? 15u : t == 5 ? (24u << 16) : t == 6 ? (uint32_t)(uintptr_t)state
                                    : t == 7 ? (uint32_t)((uintptr_t)state >> 32) : 0u;
     }
-    __syncthreads();
+    block_sync();
     CycAcc A; // per-cycle accumulators of this wave: reads of ONE mate (a wave only takes groups of `acc_mate`, see below)
     cyc_zero(A);
     uint32_t acc_mate = wave >> 3;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             if (cur_lane != 0xFFFFFFFFu) {
                 if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
                 n1 = n2 = 0;
-                __syncthreads();
+                block_sync();
                 ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
                 rs_flush(lds + KS_RS, sl, state, cur_lane);
             }
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         if (done) break;
         if (++since_t8 > t8_period) { // keep the packed u8 counters small, so that the wrap check below stays on its fast path
             since_t8 = 1;
-            __syncthreads();
+            block_sync();
             t8_flush(lds, state + sl.lane_base(cur_lane) + sl.o_eightmer, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
-            __syncthreads();
+            block_sync();
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;

@@ -12,6 +12,17 @@
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// Workgroup barrier that first drains this wave's outstanding LDS operations (s_waitcnt lgkmcnt(0)).  With this toolchain a
+// plain __syncthreads() reached through a loop back-edge was observed WITHOUT that wait in front of its s_barrier, so that
+// LDS atomics issued just before it (non-returning ds_add) could land after another wave had already read the counters
+// behind the barrier (k_cov lost histogram counts that way, about once per 25 000 tiles).  Use this instead of
+// __syncthreads() in every kernel.
+__device__ __forceinline__ void block_sync()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F); // vmcnt / expcnt: no wait, lgkmcnt(0)
+    __syncthreads();
+}
+
 __device__ __forceinline__ void gadd(uint64_t* p, uint64_t v)
 {
     atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);

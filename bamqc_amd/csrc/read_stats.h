@@ -158,7 +158,7 @@ __device__ __forceinline__ void read_stats(const DevBatch& b, const StateLayout&
 // preceded and followed by __syncthreads by the caller as needed)
 __device__ __forceinline__ void rs_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane)
 {
-    __syncthreads();
+    block_sync();
     const uint64_t lb = sl.lane_base(lane);
     for (uint32_t i = threadIdx.x; i < RS_WORDS; i += blockDim.x) {
         const uint32_t v = lds[i];
@@ -183,5 +183,5 @@ __device__ __forceinline__ void rs_flush(uint32_t* lds, const StateLayout& sl, u
             gadd(state + sl.mate_base(lane, 0) + sl.m_insert + (i - RS_INSERT), v);
         }
     }
-    __syncthreads();
+    block_sync();
 }

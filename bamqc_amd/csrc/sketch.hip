@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) hv[i] = hv_all[pair * 128 + i];
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) lm[i] = 0;
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) ix[i] = idx_tab[i];
-    __syncthreads();
+    block_sync();
     const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_perm, lo_r + per_block);
     uint32_t blane = 0xFFFFFFFFu;
     uint32_t& s_lane = lm[63]; // (no static __shared__: it would mis-align the dynamic LDS base)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
         if (r & BQC_ENTRY_SEG) { live = false; r = 0; } // padding / triplet-segment entry
         const uint32_t lane = live ? b.lane[r] : 0;
         if (threadIdx.x == 0) s_lane = lane;
-        __syncthreads();
+        block_sync();
         const uint32_t fl = s_lane;
         if (fl != blane) { // block-uniform: flush the privatised F2 / M counters of the previous lane
             if (blane != 0xFFFFFFFFu) {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
             }
             blane = fl;
             sat_mask = dsk[blane * n_pairs + pair].misc[40];
-            __syncthreads();
+            block_sync();
         }
         const DevSketch D = dsk[lane * n_pairs + pair];
         const bool mine = live && lane == blane; // reads of another lane inside a mixed block use global memory only
@@ -224,11 +224,11 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
             }
             if (mine) atomicAdd(&lm[32], n_hash); else if (n_hash) gadd(D.misc, n_hash);
         }
-        __syncthreads();
+        block_sync();
     }
     if (blane != 0xFFFFFFFFu) {
         const DevSketch D = dsk[blane * n_pairs + pair];
-        __syncthreads();
+        block_sync();
         for (uint32_t i = threadIdx.x; i < SK_F2; i += blockDim.x) { const uint32_t v = f2[i]; if (v) gadd(D.f2 + i, v); }
         if (threadIdx.x < 33) { const uint32_t v = lm[threadIdx.x]; if (v) gadd(D.misc + (threadIdx.x == 32 ? 0 : 1 + threadIdx.x), v); }
     }
