@@ -394,39 +394,38 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         for (uint32_t i = 0; i < n; ++i) P.perm[cnt[b->lane[i]]++] = i;
     }
     { // chunk tables: reads of up to BQC_FAST_MAXLEN bases -> k_short (chunks_fast), everything else -> k_long (chunks).
-      // A fast chunk is [first-mate reads | second-mate reads] of one stretch of the stream (stable), each part padded with
-      // null entries (0xFFFFFFFF) to a multiple of the reads a wave handles at once: half of k_short's waves walk the first
-      // part, half the second, at the same pace, so both mates of a stretch are touched close together in time (their
-      // 128-byte lines are shared: the second touch hits L2) and a wave accumulates per-cycle counts of one mate only.
+      // A fast chunk is a sequence of groups of rpw entries (what a wave of k_short handles at once): the first h0 slots of a
+      // group hold first-mate reads, the other h1 second-mate reads, both taken in stream order, so that a group covers one
+      // short stretch of the stream (its 128-byte lines hold reads of both mates) while every lane of k_short still sees reads
+      // of one mate only and can keep that mate's per-cycle counters in registers.  Missing reads of a mate are null entries
+      // (0xFFFFFFFF).  Behind the read groups: the triplet segments of those reads, as groups of their own.
         uint32_t maxfast = 0;
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
         P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
-        const uint32_t part_cap = 8u * rpw * (64u / rpw); // entries per mate part: 8 waves x one tile of whole groups (see k_short)
+        const uint32_t h0 = (rpw + 1) / 2, h1 = rpw / 2; // slots per mate
+        const uint32_t groups_cap = 16u * (64u / rpw);  // groups per chunk: 16 waves x one tile of whole groups (see k_short)
         std::vector<uint32_t> np;
-        np.reserve(n + n / 8);
-        std::vector<uint32_t> win;     // reads of the current fast chunk, in stream order
-        std::vector<uint32_t> win_seg; // their triplet segments (indices into P.segs), in the same order
-        uint32_t wlane = 0, nr[2] = {0, 0}, ns[2] = {0, 0}; // per mate part: reads / segments so far
-        auto padded = [&](uint32_t x) { return (x + rpw - 1) / rpw * rpw; };
+        np.reserve(n + n / 4);
+        std::vector<uint32_t> q[2];    // reads of the current fast chunk per mate, in stream order
+        std::vector<uint32_t> win_seg; // their triplet segments (indices into P.segs)
+        uint32_t wlane = 0;
+        auto groups_of = [&](size_t n0, size_t n1) { return (uint32_t)std::max((n0 + h0 - 1) / h0, h1 ? (n1 + h1 - 1) / h1 : (n1 ? (size_t)1 << 30 : 0)); };
         auto flush_window = [&]() {
-            if (win.empty()) return;
+            if (q[0].empty() && q[1].empty()) return;
             const uint32_t first = (uint32_t)np.size();
-            uint32_t part0 = 0;
-            for (uint32_t m = 0; m < 2; ++m) {
-                uint32_t cnt = 0;
-                for (uint32_t r : win)
-                    if (((P.flag[r] & 0x40u) ? 0u : 1u) == m) { np.push_back(r); ++cnt; }
-                while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
-                for (uint32_t k : win_seg)
-                    if (((P.flag[P.segs[k].r] & 0x40u) ? 0u : 1u) == m) { np.push_back(BQC_ENTRY_SEG | k); ++cnt; }
-                while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
-                if (m == 0) part0 = cnt;
+            const uint32_t ng = groups_of(q[0].size(), q[1].size());
+            for (uint32_t g = 0; g < ng; ++g) {
+                for (uint32_t k = 0; k < h0; ++k) { const size_t i = (size_t)g * h0 + k; np.push_back(i < q[0].size() ? q[0][i] : 0xFFFFFFFFu); }
+                for (uint32_t k = 0; k < h1; ++k) { const size_t i = (size_t)g * h1 + k; np.push_back(i < q[1].size() ? q[1][i] : 0xFFFFFFFFu); }
             }
-            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, part0, 0, 0, 0, 0});
-            win.clear(); win_seg.clear();
-            nr[0] = nr[1] = ns[0] = ns[1] = 0;
+            const uint32_t n_read_entries = (uint32_t)np.size() - first;
+            uint32_t cnt = 0;
+            for (uint32_t k : win_seg) { np.push_back(BQC_ENTRY_SEG | k); ++cnt; }
+            while (cnt % rpw) { np.push_back(0xFFFFFFFFu); ++cnt; }
+            P.chunks_fast.push_back(Chunk{first, (uint32_t)np.size() - first, wlane, n_read_entries, 0, 0, 0, 0});
+            q[0].clear(); q[1].clear(); win_seg.clear();
         };
         uint32_t start = 0, count = 0, cl = 0;
         uint64_t bases = 0;
@@ -440,7 +439,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             const bool fast = !c->no_fast && L <= BQC_FAST_MAXLEN;
             if (fast) {
                 close_slow();
-                if (!win.empty() && lane != wlane) flush_window();
+                if (lane != wlane) flush_window();
                 // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
                 // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
                 const uint32_t seg0 = (uint32_t)P.segs.size();
@@ -464,11 +463,11 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
                         }
                     }
                 }
-                const uint32_t m = (P.flag[r] & 0x40u) ? 0u : 1u, add = (uint32_t)P.segs.size() - seg0;
-                if (!win.empty() && padded(nr[m] + 1) + padded(ns[m] + add) > part_cap) flush_window(); // this read opens the next chunk
+                const uint32_t m = (P.flag[r] & 0x40u) ? 0u : 1u;
+                if (m == 1 && h1 == 0) return fail(c, BQC_ERR_RANGE, "internal: no slot for second-mate reads"); // (rpw >= 4 always)
+                if (groups_of(q[0].size() + (m == 0), q[1].size() + (m == 1)) > groups_cap) flush_window(); // this read opens the next chunk
                 wlane = lane;
-                win.push_back(r);
-                nr[m] += 1; ns[m] += add;
+                q[m].push_back(r);
                 for (uint32_t k = seg0; k < P.segs.size(); ++k) win_seg.push_back(k);
                 continue;
             }

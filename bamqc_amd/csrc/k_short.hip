@@ -325,9 +325,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                                    : t == 7 ? (uint32_t)((uintptr_t)state >> 32) : 0u;
     }
     block_sync();
-    CycAcc A; // per-cycle accumulators of this wave: reads of ONE mate (a wave only takes groups of `acc_mate`, see below)
+    CycAcc A; // per-cycle accumulators of this lane: reads of ONE mate (fixed per slot, see the chunk layout below)
     cyc_zero(A);
-    uint32_t acc_mate = wave >> 3;
+    const uint32_t mate = slot < (rpw + 1u) / 2u ? 0u : 1u;
     uint32_t n1 = 0, n2 = 0; // groups since the last counter spill / quality flush (wave-uniform)
     uint32_t cur_lane = 0xFFFFFFFFu, since_t8 = 0;
 
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         if (!done) ch = b.chunks_fast[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
-                if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
+                if (lane_used) { cyc_spill(A, lds, mate, w); cyc_qflush(A, lds, mate, w); }
                 n1 = n2 = 0;
                 block_sync();
                 ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
@@ -358,20 +358,18 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
-        // The chunk is [first-mate part | second-mate part]; a part is its reads followed by the triplet segments of those reads,
-        // both padded to a multiple of rpw, and holds at most 8 tiles: waves 0-7 take the tiles of the first part, waves 8-15 of
-        // the second, so a wave accumulates per-cycle counts of one mate only.
-        uint32_t p_first = 0, p_n = ch.count, tw = wave, tstride = KS_WAVES, mate = ch.aux ? 0u : 1u;
-        if (ch.aux != 0u && ch.aux != ch.count) {
-            mate = wave >> 3; tw = wave & 7u; tstride = KS_WAVES / 2;
-            p_first = mate ? ch.aux : 0u; p_n = mate ? ch.count - ch.aux : ch.aux;
-        }
-        if (mate != acc_mate) { // only when a chunk holds reads of a single mate
-            if (lane_used) { cyc_spill(A, lds, acc_mate, w); cyc_qflush(A, lds, acc_mate, w); }
-            n1 = n2 = 0;
-            acc_mate = mate;
-        }
-        for (uint32_t tb = tw * tile_cap; tb < p_n; tb += tstride * tile_cap) {
+        // The chunk is [read groups | triplet-segment groups]; in a read group the first h0 slots hold first-mate reads and the
+        // others second-mate reads (or null entries), so every lane only ever sees reads of ONE mate (`mate`) and keeps that
+        // mate's per-cycle counters in registers.  Wave v takes the read tiles v, v + 16, ... and the segment tiles starting at
+        // a wave that rotates with the chunk.
+        const uint32_t n_seg = ch.count - ch.aux;
+        const uint32_t my_tiles = ch.aux > wave * tile_cap ? (ch.aux - wave * tile_cap + KS_WAVES * tile_cap - 1u) / (KS_WAVES * tile_cap) : 0u;
+        const uint32_t sw0 = (wave + KS_WAVES - (ci & (KS_WAVES - 1u))) & (KS_WAVES - 1u);
+        const uint32_t seg_tiles = n_seg > sw0 * tile_cap ? (n_seg - sw0 * tile_cap + KS_WAVES * tile_cap - 1u) / (KS_WAVES * tile_cap) : 0u;
+        for (uint32_t tix = 0; tix < my_tiles + seg_tiles; ++tix) {
+        const bool seg_tile = tix >= my_tiles; // wave-uniform
+        const uint32_t tb = seg_tile ? (sw0 + (tix - my_tiles) * KS_WAVES) * tile_cap : (wave + tix * KS_WAVES) * tile_cap;
+        const uint32_t p_first = seg_tile ? ch.aux : 0u, p_n = seg_tile ? n_seg : ch.aux;
         const uint32_t tn = min(tile_cap, p_n - tb); // entries of this wave's tile (a multiple of rpw)
         // ---- phase A: lane per read — per-read statistics, and the read's record for phase B into LDS
         {
@@ -601,12 +599,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             const uint32_t m0 = WM[ln * KS_MW];
             if (m0 & KM_PRIM) {
                 const uint32_t L = (m0 >> 20) & 0xFFu, sum = WM[ln * KS_MW + 2] - WM[ln * KS_MW + 1];
-                const uint32_t qs = sum & 0xFFFFu, nN = (sum >> 16) & 0xFFu, nGC = sum >> 24;
-                atomicAdd(&lds[KS_NC + mate * (KS_CT + 1) + nN], 1u);
-                atomicAdd(&lds[KS_GC + mate * (KS_CT + 1) + nGC], 1u);
+                const uint32_t qs = sum & 0xFFFFu, nN = (sum >> 16) & 0xFFu, nGC = sum >> 24, rm = (m0 & 0x40u) ? 0u : 1u;
+                atomicAdd(&lds[KS_NC + rm * (KS_CT + 1) + nN], 1u);
+                atomicAdd(&lds[KS_GC + rm * (KS_CT + 1) + nGC], 1u);
                 if (L > 0) { // round-half-away and ceil of qs/L in exact integer arithmetic
-                    atomicAdd(&lds[KS_AQ + mate * 256 + (((2u * qs + L) / (2u * L)) & 255u)], 1u);
-                    atomicAdd(&lds[KS_AC + mate * 256 + (((qs + L - 1u) / L) & 255u)], 1u);
+                    atomicAdd(&lds[KS_AQ + rm * 256 + (((2u * qs + L) / (2u * L)) & 255u)], 1u);
+                    atomicAdd(&lds[KS_AC + rm * 256 + (((qs + L - 1u) / L) & 255u)], 1u);
                 }
             }
         }

@@ -3,7 +3,7 @@
 #   kernel-trace stats of bench.py, FETCH_SIZE / WRITE_SIZE in separate --pmc passes, and the same two
 #   counters for k_calib_read4 (1 GiB, 4-byte-per-lane loads) to calibrate FETCH_SIZE for this access width.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r1b; rm -rf $O; mkdir -p $O
+O=gpurun_out/prof_r1c; rm -rf $O; mkdir -p $O
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 10 --warmup 2 --no-cpu > $O/bench_under_rocprof.json 2> $O/kt.err
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 3 --warmup 0 --no-cpu > /dev/null 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 3 --warmup 0 --no-cpu > /dev/null 2>&1
@@ -12,7 +12,7 @@ timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- python -c "from bamqc_amd import _lib; _lib.load().bqc_calib_read4(1<<30, 3)" > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, collections, json
-O = "gpurun_out/prof_r1b"
+O = "gpurun_out/prof_r1c"
 out = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_tcc", "cal_fetch", "cal_dram"):
     for f in glob.glob(O + "/" + name + "/*/*counter_collection.csv"):
