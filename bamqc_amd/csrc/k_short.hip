@@ -653,21 +653,21 @@ extern "C" hipError_t bqc_short_init()
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_short), hipFuncAttributeMaxDynamicSharedMemorySize, KS_WORDS * 4);
 }
 
-// Fold the per-workgroup 8-mer rows into the state vector and clear them: thread per LDS dword (4 bins).
+// Fold the per-workgroup 8-mer rows into the state vector and clear them: thread per LDS dword (4 bins) and slice of 16 rows.
 __global__ __launch_bounds__(256) void k_t8_reduce(uint4* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ em)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 16384u) return;
-    uint64_t a = 0, b = 0, c = 0, d = 0;
-    for (uint32_t r = 0; r < n_rows; ++r) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // < 16384
+    uint64_t A = 0, B = 0, C = 0, D = 0;
+    const uint32_t r0 = blockIdx.y * 16u, r1 = min(n_rows, r0 + 16u);
+    for (uint32_t r = r0; r < r1; ++r) {
         const uint4 x = rows[(size_t)r * 16384u + i];
         if (x.x | x.y | x.z | x.w) rows[(size_t)r * 16384u + i] = make_uint4(0, 0, 0, 0);
-        a += x.x; b += x.y; c += x.z; d += x.w;
+        A += x.x; B += x.y; C += x.z; D += x.w;
     }
-    if (a) gadd(em + 4u * i + 0u, a);
-    if (b) gadd(em + 4u * i + 3u, b);
-    if (c) gadd(em + 4u * i + 2u, c);
-    if (d) gadd(em + 4u * i + 1u, d);
+    if (A) gadd(em + 4u * i + 0u, A);
+    if (B) gadd(em + 4u * i + 3u, B);
+    if (C) gadd(em + 4u * i + 2u, C);
+    if (D) gadd(em + 4u * i + 1u, D);
 }
 
 extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
@@ -678,5 +678,5 @@ extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint6
     static uint32_t period = 0;
     if (!period) { const char* e = getenv("BQC_T8_PERIOD"); period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : KS_T8_PERIOD; } // tuning knob
     hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_lane, period);
-    hipLaunchKernelGGL(k_t8_reduce, dim3(64), dim3(256), 0, s, (uint4*)t8rows, grid, state + sl.lane_base(t8_lane) + sl.o_eightmer);
+    hipLaunchKernelGGL(k_t8_reduce, dim3(64, (grid + 15) / 16), dim3(256), 0, s, (uint4*)t8rows, grid, state + sl.lane_base(t8_lane) + sl.o_eightmer);
 }
