@@ -31,6 +31,7 @@ void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, ui
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
 uint32_t bqc_short_parts();
+void bqc_launch_t8_reduce(uint32_t* t8rows, uint32_t n_rows, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
 }
 
 static thread_local char g_create_err[512];
@@ -72,7 +73,10 @@ struct bqc_ctx {
     uint32_t n_cu = 256;
     uint64_t* d_state = nullptr;
     uint32_t* d_err = nullptr;
-    uint32_t* d_t8rows = nullptr; // [n_cu][65536] per-workgroup 8-mer rows of k_short (zero between launches)
+    uint32_t* d_t8rows = nullptr; // [n_cu][65536] per-workgroup 8-mer rows of k_short: counts of read group t8_rows_lane that are
+                                  // not yet in d_state (folded in by fold_t8 before the state is read, or another group needs the rows)
+    bool t8_dirty = false;
+    uint32_t t8_rows_lane = 0;
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
     uint32_t* d_parity = nullptr; // [lane]
     uint8_t* d_started = nullptr; // [lane]
@@ -654,6 +658,13 @@ static void tick(bqc_ctx* c, const char* name)
     c->n_timed++;
 }
 
+static void fold_t8(bqc_ctx* c)
+{
+    if (!c->t8_dirty) return;
+    bqc_launch_t8_reduce(c->d_t8rows, c->n_cu, c->sl, c->d_state, c->t8_rows_lane, c->stream);
+    c->t8_dirty = false;
+}
+
 extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
 {
     if (!c || !db) return fail(c, BQC_ERR_ARG, "bqc_process: null argument");
@@ -676,7 +687,9 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
             bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
             tick(c, "k_reads");
         }
+        if (c->t8_rows_lane != db->t8_lane) { fold_t8(c); c->t8_rows_lane = db->t8_lane; }
         bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->d_t8rows, db->t8_lane, c->stream);
+        c->t8_dirty = true;
         tick(c, "k_short");
     }
     if (slow.n_chunks) {
@@ -721,6 +734,7 @@ extern "C" int bqc_reset(bqc_ctx* c)
 {
     if (!c) return BQC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    fold_t8(c); // (leaves the scratch rows zero)
     HIPCHK(c, hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_carry, 0, (size_t)c->opt.n_lanes * 2 * 2000 * 4, c->stream));
@@ -761,6 +775,7 @@ extern "C" int bqc_flush(bqc_ctx* c)
     if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
     if (c->flushed) return 0;
     HIPCHK(c, hipSetDevice(c->device));
+    fold_t8(c);
     bqc_launch_cov_final(c->sl, c->d_state, c->d_carry, c->d_parity, c->d_started, c->stream);
     HIPCHK(c, hipGetLastError());
     int rc = check_device_error(c);
@@ -785,6 +800,7 @@ extern "C" int bqc_state_import(bqc_ctx* c, const void* src)
 {
     if (!c || !src) return BQC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    fold_t8(c);
     HIPCHK(c, hipMemcpyAsync(c->d_state, src, c->sl.words * 8, hipMemcpyDeviceToDevice, c->stream));
     if (c->sketch) sketch_state_import(c->sketch, (const uint64_t*)src + c->sl.words, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -812,6 +828,8 @@ extern "C" int bqc_state_import_host(bqc_ctx* c, const uint64_t* src)
 {
     if (!c || !src) return BQC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    fold_t8(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_state, src, c->sl.words * 8, hipMemcpyHostToDevice));
     if (c->sketch) {
         uint64_t* tmp = nullptr;

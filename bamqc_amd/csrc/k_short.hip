@@ -678,5 +678,10 @@ extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint6
     static uint32_t period = 0;
     if (!period) { const char* e = getenv("BQC_T8_PERIOD"); period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : KS_T8_PERIOD; } // tuning knob
     hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_lane, period);
-    hipLaunchKernelGGL(k_t8_reduce, dim3(64, (grid + 15) / 16), dim3(256), 0, s, (uint4*)t8rows, grid, state + sl.lane_base(t8_lane) + sl.o_eightmer);
+}
+
+// fold the scratch rows into the 8-mer counters of `lane` (the rows are zero afterwards)
+extern "C" void bqc_launch_t8_reduce(uint32_t* t8rows, uint32_t n_rows, const StateLayout& sl, uint64_t* state, uint32_t lane, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_t8_reduce, dim3(64, (n_rows + 15) / 16), dim3(256), 0, s, (uint4*)t8rows, n_rows, state + sl.lane_base(lane) + sl.o_eightmer);
 }
