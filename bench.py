@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — BAM records/s of the per-read aggregation hot path on N MI355X (one process per GPU).
 
-A "step" is one pass of the hot path (k_reads + k_bases + k_cov) over one device-resident batch of
+A "step" is one pass of the hot path (k_short + k_cov; k_reads + k_long for long reads) over one device-resident batch of
 synthetic 150 bp paired-end reads (config 2 of BASELINE.json: 10 M reads over 4 x 25 Mb contigs).
 Each rank owns its own batch (records shard by read batch: weak scaling, no data-path collective);
 at the end of the job the flat uint64 state vectors are summed onto rank 0 with one RCCL reduce.
@@ -117,7 +117,7 @@ def main():
                        "reads_per_gpu_per_step": args.reads, "parallelism": "shard by read batch; RCCL reduce of state vector at end"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
                          "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": traffic,
-                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 calibrated)" if traffic else None,
+                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated)" if traffic else None,
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_read": abytes / args.reads,
                          "kernel_ms": kavg},
             "host": {"generate_s": t_gen, "prepass_upload_s": t_up,
