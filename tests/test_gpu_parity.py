@@ -121,6 +121,34 @@ def test_triplet_weird_cigars():
     assert_parity(synth.concat(recs), [ref], hist_cap=1024)
 
 
+def test_triplet_contig_edges_and_segments():
+    """Reads hanging over both contig ends (with N in the overhang), segments whose virtual start is negative, the fast-path
+    length limit (255 / 256 bases) and indel reads of several read groups in one batch."""
+    rng = np.random.default_rng(9)
+    reflen = 700
+    ref = rng.integers(0, 4, size=reflen).astype(np.uint8)
+    ref[5:9] = 4  # N run near the start
+    ok = P | PR
+    recs = []
+    for trial in range(400):
+        L = int(rng.choice([3, 17, 100, 150, 151, 254, 255, 256, 300]))
+        pos = int(rng.choice([0, 1, 2, 7, reflen - L - 2, reflen - L, reflen - L + 3, reflen - 20, reflen - 2, int(rng.integers(0, reflen))]))
+        pos = max(pos, 0)
+        kind = trial % 4
+        if kind == 0: ops = [(L, "M")]
+        elif kind == 1: ops = [(3, "I"), (L - 3, "M")] if L > 6 else [(L, "M")]         # first op an insertion: segment starts before pos
+        elif kind == 2: ops = [(L // 2, "M"), (2, "D"), (L - L // 2, "M")]
+        else: ops = [(L // 3, "M"), (4, "N"), (L // 3, "M"), (1, "I"), (L - 2 * (L // 3) - 1, "M")]
+        codes = np.pad(ref, (0, 400))[pos:pos + L].astype(np.int64)  # beyond the contig: 'A'
+        codes[rng.random(L) < 0.03] = 4
+        seq = "".join("ACGTN"[int(c)] for c in codes)
+        q = rng.integers(15, 45, size=L).tolist()
+        nm = sum(n for n, c in ops if c in "ID")
+        flag = ok | (REV if trial & 4 else 0) | (FIRST if trial & 8 else LAST)
+        recs.append(synth.single_read(seq, q, ops, flag, pos=pos, mapq=60, as_=90, nm=nm, lane=trial % 3))
+    assert_parity(synth.concat(recs), [ref], n_lanes=3, hist_cap=1024, max_read_len=512)
+
+
 def test_error_codes_match():
     ref = np.zeros(1000, np.uint8)
     ok = P | PR | FIRST
