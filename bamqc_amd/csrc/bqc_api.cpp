@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/bamqc.h"
@@ -46,7 +47,7 @@ struct LaneCov { // host side of OverallNumbers' window state machine (OverallNu
 
 struct bqc_dbatch {
     void* dmem = nullptr;
-    size_t dbytes = 0;
+    size_t dbytes = 0, dcap = 0;
     DevBatch d{};
     uint8_t* d_lane_mask = nullptr; // [n_lanes] lanes that own coverage tiles in this batch
     uint64_t algo_bytes = 0;
@@ -77,6 +78,7 @@ struct bqc_ctx {
                                   // not yet in d_state (folded in by fold_t8 before the state is read, or another group needs the rows)
     bool t8_dirty = false;
     uint32_t t8_rows_lane = 0;
+    std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
     uint32_t* d_parity = nullptr; // [lane]
     uint8_t* d_started = nullptr; // [lane]
@@ -228,6 +230,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     for (auto p : c->d_refn) if (p) (void)hipFree(p);
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
+    for (auto& pb : c->pool) (void)hipFree(pb.first);
     (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
     (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
     for (auto e : c->ev) (void)hipEventDestroy(e);
@@ -502,16 +505,10 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
             uint32_t t = w / BQC_COV_TILE_WINDOWS;
             if (need.empty() || need.back() < t) need.push_back(t);
         };
-        size_t k = 0;
-        uint32_t specials[4] = {0, 1, W1, W1 + 1};
-        // merge the (sorted) read windows with the special windows
-        std::vector<uint32_t> ws;
-        ws.reserve(win.size() * 2 + 4);
-        for (k = 0; k < win.size(); ++k) { ws.push_back(win[k]); ws.push_back(win[k] + 1); }
-        if (started_before[l]) { ws.push_back(specials[0]); ws.push_back(specials[1]); }
-        ws.push_back(specials[2]); ws.push_back(specials[3]);
-        std::sort(ws.begin(), ws.end());
-        for (uint32_t w : ws) push_tile(w);
+        // tiles that hold a live window of some read (its first and the next one), the two windows carried in from the previous
+        // batch and the two carried out (W1, W1 + 1 = the last read's).  `win` never decreases, so one ordered pass suffices.
+        if (started_before[l]) push_tile(0), push_tile(1);
+        for (size_t k = 0; k < win.size(); ++k) { push_tile(win[k]); push_tile(win[k] + 1); }
         uint64_t covered_final = 0;
         for (uint32_t t : need) {
             const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
@@ -548,7 +545,8 @@ extern "C" void bqc_dbatch_free(bqc_ctx* c, bqc_dbatch* db)
 {
     if (!db) return;
     if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
-    (void)hipFree(db->dmem);
+    if (c && db->dmem && c->pool.size() < 3) c->pool.emplace_back(db->dmem, db->dcap);
+    else (void)hipFree(db->dmem);
     delete db;
 }
 extern "C" uint64_t bqc_dbatch_bytes(const bqc_dbatch* db) { return db ? db->algo_bytes : 0; }
@@ -560,8 +558,11 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_upload after bqc_flush/bqc_finalize (call bqc_reset first)");
     HIPCHK(c, hipSetDevice(c->device));
     Prep P;
+    const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '2';
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = prepass(c, b, P);
     if (rc) { c->poisoned = true; return rc; }
+    const auto t1 = std::chrono::steady_clock::now();
     const uint32_t n = b->n_reads;
     bqc_dbatch* db = new bqc_dbatch();
     Carver cv;
@@ -575,7 +576,18 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
                  o_clist = cv.take(sizeof(CovEntry) * P.cov_list.size()), o_tiles = cv.take(sizeof(CovTile) * P.tiles.size()),
                  o_rsum = cv.take(P.chunks.empty() ? 0 : 12ull * n), o_mask = cv.take(c->opt.n_lanes), o_started = cv.take(c->opt.n_lanes), o_aidx = cv.take(8ull * P.add_idx.size()), o_aval = cv.take(8ull * P.add_val.size());
     db->dbytes = cv.off + 256;
-    hipError_t he = hipMalloc(&db->dmem, db->dbytes);
+    hipError_t he = hipSuccess;
+    for (size_t k = 0; k < c->pool.size(); ++k)
+        if (c->pool[k].second >= db->dbytes && c->pool[k].second <= 2 * db->dbytes + (64u << 20)) { // a freed buffer of a similar size
+            db->dmem = c->pool[k].first; db->dcap = c->pool[k].second;
+            c->pool.erase(c->pool.begin() + k);
+            break;
+        }
+    if (!db->dmem) {
+        if (c->pool.size() >= 3) { (void)hipFree(c->pool.front().first); c->pool.erase(c->pool.begin()); }
+        db->dcap = db->dbytes + db->dbytes / 16; // a little slack, so that the next batch of about this size fits as well
+        he = hipMalloc(&db->dmem, db->dcap);
+    }
     if (he != hipSuccess) { delete db; c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", db->dbytes, hipGetErrorString(he)); }
     char* base = (char*)db->dmem;
 #define UP(off, src, bytes)                                                                                     \
@@ -603,6 +615,11 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     UP(o_started, st.data(), c->opt.n_lanes);
     UP(o_aidx, P.add_idx.data(), 8ull * P.add_idx.size()); UP(o_aval, P.add_val.data(), 8ull * P.add_val.size());
     he = hipStreamSynchronize(c->stream); // buffers may be reused by the caller on return
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] upload of %u reads: pre-pass %.3f s, H2D %.3f s (%.1f MB)\n", b->n_reads, std::chrono::duration<double>(t1 - t0).count(),
+                std::chrono::duration<double>(t2 - t1).count(), db->dbytes / 1e6);
+    }
     if (he != hipSuccess) { bqc_dbatch_free(c, db); c->poisoned = true; return fail(c, BQC_ERR_DEVICE, "upload sync failed: %s", hipGetErrorString(he)); }
     DevBatch& d = db->d;
     d.n_reads = n;

@@ -1,9 +1,11 @@
 // bam_io.cpp — see bam_io.h
 #include "bam_io.h"
 
+#include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 bqc_batch HostBatch::view() const
 {
@@ -96,120 +98,180 @@ bool BamReader::open(const char* path, std::string& err)
     return true;
 }
 
+// One record's variable part, decoded by parse_record.
+namespace {
+struct RecErr { size_t index = SIZE_MAX; std::string msg; int code = 0; };
+
+template <typename F>
+void parallel_ranges(size_t n, unsigned threads, F f) // f(thread, lo, hi) over contiguous ranges
+{
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 4096 + 1));
+    if (nt == 1) { f(0u, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([=, &f]() { f(t, n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
+} // namespace
+
+// Decoding is done in two steps so that it can use every host core: (1) a serial walk over the block_size chain that
+// finds the record boundaries and fixes where every record's seq / qual / CIGAR goes in the batch (prefix sums);
+// (2) the records are decoded into the columns in parallel (tag scan, copies).  Unknown RG ids (std::map::operator[]
+// inserts them with lane 0, bamqualcheck.cpp:86) and the per-record error rules are resolved in record order afterwards.
 int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std::string& err, int& err_code)
 {
     o.clear();
-    size_t bases = 0;
     err_code = 0;
-    while (o.n() < max_reads && bases < max_bases) {
+    struct Rec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; }; // off: relative to cur_
+    std::vector<Rec> recs;
+    recs.reserve(std::min<size_t>(max_reads, 1u << 20));
+    size_t bases = 0, so = 0, qo = 0, co = 0;
+    size_t rel = 0; // bytes of this batch walked so far; cur_ stays at the batch start, so fill() never drops them
+    bool io_error = false;
+    while (recs.size() < max_reads && bases < max_bases) {
         std::string e;
-        if (!fill(4, e)) {
-            if (!e.empty() || buf_.size() != cur_) { err = e.empty() ? "truncated BAM record" : e; err_code = BQC_ERR_IO; return -1; }
+        if (!fill(rel + 4, e)) {
+            if (!e.empty() || buf_.size() != cur_ + rel) { err = e.empty() ? "truncated BAM record" : e; io_error = true; }
             break;
         }
-        const uint32_t bs = rd32(buf_.data() + cur_);
-        if (bs < 32 || !fill(4 + (size_t)bs, e)) { err = e.empty() ? "truncated BAM record" : e; err_code = BQC_ERR_IO; return -1; }
-        const uint8_t* r = buf_.data() + cur_ + 4;
-        const int32_t rid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
-        const uint32_t l_name = r[8], mapq = r[9];
-        const uint32_t n_cig = rd16(r + 12), flag = rd16(r + 14), l_seq = rd32(r + 16);
-        const int32_t rnext = (int32_t)rd32(r + 20), tlen = (int32_t)rd32(r + 28);
+        const uint32_t bs = rd32(buf_.data() + cur_ + rel);
+        if (bs < 32 || !fill(rel + 4 + (size_t)bs, e)) { err = e.empty() ? "truncated BAM record" : e; io_error = true; break; }
+        const uint8_t* r = buf_.data() + cur_ + rel + 4;
+        const int32_t rid = (int32_t)rd32(r);
+        const uint32_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
         const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
-        if (var > bs) { err = "corrupt BAM record"; err_code = BQC_ERR_IO; return -1; }
-        if (filter_) {
-            const bool keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
-            if (!keep) { cur_ += 4 + (size_t)bs; ++nrec_; continue; }
+        if (var > bs) { err = "corrupt BAM record"; io_error = true; break; }
+        bool keep = true;
+        if (filter_) keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
+        if (keep) {
+            recs.push_back(Rec{rel, bs, l_seq, n_cig, so, qo, co, nrec_});
+            so += (l_seq + 1) / 2; qo += l_seq; co += n_cig;
+            bases += l_seq;
         }
-        const uint8_t* cig = r + 32 + l_name;
-        const uint8_t* sq = cig + 4ull * n_cig;
-        const uint8_t* ql = sq + (l_seq + 1) / 2;
-        const uint8_t* tg = ql + l_seq;
-        const uint8_t* te = r + bs;
-        // one linear tag scan: RG (getLane, bamqualcheck.cpp:72-100), every integer NM (QualityCheck.hpp:201-209),
-        // first AS (TripletCounting.hpp:113-127)
-        int lane = -1;
-        bool rg_seen = false, rg_bad = false, as_seen = false;
-        int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
-        bool nm_seen = false;
-        const uint32_t idx = (uint32_t)o.n();
-        while (tg + 3 <= te) {
-            const char k0 = (char)tg[0], k1 = (char)tg[1], ty = (char)tg[2];
-            const uint8_t* v = tg + 3;
-            size_t len = 0;
-            switch (ty) {
-            case 'A': case 'c': case 'C': len = 1; break;
-            case 's': case 'S': len = 2; break;
-            case 'i': case 'I': case 'f': len = 4; break;
-            case 'Z': case 'H': { const void* z = memchr(v, 0, (size_t)(te - v)); len = z ? (size_t)((const uint8_t*)z - v) + 1 : (size_t)(te - v); break; }
-            case 'B': {
-                if (v + 5 > te) { len = (size_t)(te - v); break; }
-                const char st = (char)v[0];
-                const size_t cnt = rd32(v + 1);
-                const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
-                len = 5 + cnt * es;
-                break;
-            }
-            default: len = (size_t)(te - v); break;
-            }
-            if (v + len > te) { err = "corrupt BAM tags"; err_code = BQC_ERR_IO; return -1; }
-            if (k0 == 'R' && k1 == 'G' && !rg_seen) {
-                rg_seen = true;
-                if (ty == 'Z') {
-                    std::string id((const char*)v, len ? len - 1 : 0);
-                    auto it = hdr_.lane_names.find(id);
-                    if (it == hdr_.lane_names.end()) { hdr_.lane_names[id] = 0; lane = 0; } // std::map::operator[] inserts 0 (:86)
-                    else lane = (int)it->second;
-                } else rg_bad = true;
-            } else if (k0 == 'N' && k1 == 'M' && (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I')) {
-                uint32_t x = 0;
-                switch (ty) {
-                case 'c': x = (uint32_t)(int32_t)(int8_t)v[0]; break;
-                case 'C': x = v[0]; break;
-                case 's': x = (uint32_t)(int32_t)(int16_t)rd16(v); break;
-                case 'S': x = rd16(v); break;
-                default: x = rd32(v); break;
-                }
-                if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
-                else { o.nm_extra_read.push_back(idx); o.nm_extra_val.push_back((int32_t)x); }
-            } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
-                as_seen = true;
-                switch (ty) {
-                case 'A': as = (int32_t)(char)v[0]; break;
-                case 'c': as = (int8_t)v[0]; break;
-                case 'C': as = v[0]; break;
-                case 's': as = (int16_t)rd16(v); break;
-                case 'S': as = rd16(v); break;
-                case 'i': case 'I': as = (int32_t)rd32(v); break;
-                case 'f': { float f; uint32_t u = rd32(v); memcpy(&f, &u, 4); as = (int32_t)f; break; }
-                default: as = BQC_AS_ABSENT; break; // extractTagValue fails -> "Could not read AS tag"
-                }
-            }
-            tg = v + len;
-        }
-        if (rg_bad) { err = "Read does not have Z"; err_code = BQC_ERR_ARG; return -1; }
-        if (!rg_seen) { // DEFINED: the reference falls off the end of getLane() (undefined behaviour)
-            err = "ERROR: read without RG tag (record " + std::to_string(nrec_) + ")";
-            err_code = BQC_ERR_ARG;
-            return -1;
-        }
-        if ((unsigned)lane >= hdr_.lane_count) { err = "ERROR: read group index out of range (no @RG lines in the header?)"; err_code = BQC_ERR_ARG; return -1; }
-        if (nm_seen && nm == BQC_NM_ABSENT) { err = "NM tag value 0xFFFFFFFF is not representable"; err_code = BQC_ERR_RANGE; return -1; }
-        uint32_t f = flag & 0x0FFFu;
-        if (rnext >= 0 && (size_t)rnext < main_.size() && main_[rnext]) f |= BQC_FLAG_MATE_MAIN;
-        if (l_seq > 0 && ql[0] == 0xFF) f |= BQC_FLAG_NO_QUAL;
-        o.flag.push_back((uint16_t)f); o.mapq.push_back((uint8_t)mapq); o.lane.push_back((uint8_t)lane); o.rid.push_back(rid);
-        o.pos.push_back(pos); o.tlen.push_back(tlen); o.nm.push_back(nm); o.as.push_back(as); o.l_seq.push_back(l_seq);
-        o.n_cigar.push_back((uint16_t)n_cig);
-        const size_t c0 = o.cigar.size();
-        o.cigar.resize(c0 + n_cig);
-        if (n_cig) memcpy(o.cigar.data() + c0, cig, 4ull * n_cig);
-        o.seq.insert(o.seq.end(), sq, sq + (l_seq + 1) / 2);
-        o.qual.insert(o.qual.end(), ql, ql + l_seq);
-        bases += l_seq;
-        cur_ += 4 + (size_t)bs;
+        rel += 4 + (size_t)bs;
         ++nrec_;
     }
-    return o.n() ? 1 : 0;
+    const size_t n = recs.size();
+    o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);
+    o.nm.resize(n); o.as.resize(n); o.l_seq.resize(n); o.n_cigar.resize(n);
+    o.seq.resize(so); o.qual.resize(qo); o.cigar.resize(co);
+    const unsigned nt_max = bg_.threads();
+    std::vector<RecErr> errs(nt_max);
+    std::vector<std::vector<std::pair<uint32_t, int32_t>>> extra(nt_max);          // further NM tags: (read, value)
+    std::vector<std::vector<std::pair<uint32_t, std::string>>> unknown_rg(nt_max); // reads whose RG id is not in the header
+    const uint8_t* base = buf_.data() + cur_;
+    const auto& lane_names = hdr_.lane_names;
+    parallel_ranges(n, nt_max, [&](unsigned t, size_t lo, size_t hi) {
+        std::string last_id;
+        int last_lane = -1;
+        bool have_last = false;
+        for (size_t i = lo; i < hi; ++i) {
+            const Rec& R = recs[i];
+            const uint8_t* r = base + R.off + 4;
+            const int32_t rid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+            const uint32_t l_name = r[8], mapq = r[9];
+            const uint32_t n_cig = R.n_cig, flag = rd16(r + 14), l_seq = R.l_seq;
+            const int32_t rnext = (int32_t)rd32(r + 20), tlen = (int32_t)rd32(r + 28);
+            const uint8_t* cig = r + 32 + l_name;
+            const uint8_t* sq = cig + 4ull * n_cig;
+            const uint8_t* ql = sq + (l_seq + 1) / 2;
+            const uint8_t* tg = ql + l_seq;
+            const uint8_t* te = r + R.bs;
+            // one linear tag scan: RG (getLane, bamqualcheck.cpp:72-100), every integer NM (QualityCheck.hpp:201-209),
+            // first AS (TripletCounting.hpp:113-127)
+            int lane = -1;
+            bool rg_seen = false, rg_bad = false, as_seen = false, nm_seen = false, bad_tags = false;
+            int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
+            while (tg + 3 <= te) {
+                const char k0 = (char)tg[0], k1 = (char)tg[1], ty = (char)tg[2];
+                const uint8_t* v = tg + 3;
+                size_t len = 0;
+                switch (ty) {
+                case 'A': case 'c': case 'C': len = 1; break;
+                case 's': case 'S': len = 2; break;
+                case 'i': case 'I': case 'f': len = 4; break;
+                case 'Z': case 'H': { const void* z = memchr(v, 0, (size_t)(te - v)); len = z ? (size_t)((const uint8_t*)z - v) + 1 : (size_t)(te - v); break; }
+                case 'B': {
+                    if (v + 5 > te) { len = (size_t)(te - v); break; }
+                    const char st = (char)v[0];
+                    const size_t cnt = rd32(v + 1);
+                    const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                    len = 5 + cnt * es;
+                    break;
+                }
+                default: len = (size_t)(te - v); break;
+                }
+                if (v + len > te) { bad_tags = true; break; }
+                if (k0 == 'R' && k1 == 'G' && !rg_seen) {
+                    rg_seen = true;
+                    if (ty == 'Z') {
+                        const size_t idl = len ? len - 1 : 0;
+                        if (have_last && last_id.size() == idl && memcmp(last_id.data(), v, idl) == 0) lane = last_lane;
+                        else {
+                            std::string id((const char*)v, idl);
+                            auto it = lane_names.find(id);
+                            if (it == lane_names.end()) { unknown_rg[t].emplace_back((uint32_t)i, id); lane = 0; } // operator[] would insert 0 (:86)
+                            else { lane = (int)it->second; last_id.swap(id); last_lane = lane; have_last = true; }
+                        }
+                    } else rg_bad = true;
+                } else if (k0 == 'N' && k1 == 'M' && (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I')) {
+                    uint32_t x = 0;
+                    switch (ty) {
+                    case 'c': x = (uint32_t)(int32_t)(int8_t)v[0]; break;
+                    case 'C': x = v[0]; break;
+                    case 's': x = (uint32_t)(int32_t)(int16_t)rd16(v); break;
+                    case 'S': x = rd16(v); break;
+                    default: x = rd32(v); break;
+                    }
+                    if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
+                    else extra[t].emplace_back((uint32_t)i, (int32_t)x);
+                } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
+                    as_seen = true;
+                    switch (ty) {
+                    case 'A': as = (int32_t)(char)v[0]; break;
+                    case 'c': as = (int8_t)v[0]; break;
+                    case 'C': as = v[0]; break;
+                    case 's': as = (int16_t)rd16(v); break;
+                    case 'S': as = rd16(v); break;
+                    case 'i': case 'I': as = (int32_t)rd32(v); break;
+                    case 'f': { float f; uint32_t u = rd32(v); memcpy(&f, &u, 4); as = (int32_t)f; break; }
+                    default: as = BQC_AS_ABSENT; break; // extractTagValue fails -> "Could not read AS tag"
+                    }
+                }
+                tg = v + len;
+            }
+            RecErr& E = errs[t];
+            if (E.index == SIZE_MAX) { // the first failing record of this range, by the reference's order of checks
+                if (bad_tags) { E.index = i; E.msg = "corrupt BAM tags"; E.code = BQC_ERR_IO; }
+                else if (rg_bad) { E.index = i; E.msg = "Read does not have Z"; E.code = BQC_ERR_ARG; }
+                else if (!rg_seen) { // DEFINED: the reference falls off the end of getLane() (undefined behaviour)
+                    E.index = i; E.msg = "ERROR: read without RG tag (record " + std::to_string(R.nrec) + ")"; E.code = BQC_ERR_ARG;
+                } else if ((unsigned)lane >= hdr_.lane_count) { E.index = i; E.msg = "ERROR: read group index out of range (no @RG lines in the header?)"; E.code = BQC_ERR_ARG; }
+                else if (nm_seen && nm == BQC_NM_ABSENT) { E.index = i; E.msg = "NM tag value 0xFFFFFFFF is not representable"; E.code = BQC_ERR_RANGE; }
+            }
+            uint32_t f = flag & 0x0FFFu;
+            if (rnext >= 0 && (size_t)rnext < main_.size() && main_[rnext]) f |= BQC_FLAG_MATE_MAIN;
+            if (l_seq > 0 && ql[0] == 0xFF) f |= BQC_FLAG_NO_QUAL;
+            o.flag[i] = (uint16_t)f; o.mapq[i] = (uint8_t)mapq; o.lane[i] = (uint8_t)(lane < 0 ? 0 : lane); o.rid[i] = rid;
+            o.pos[i] = pos; o.tlen[i] = tlen; o.nm[i] = nm; o.as[i] = as; o.l_seq[i] = l_seq; o.n_cigar[i] = (uint16_t)n_cig;
+            if (n_cig) memcpy(o.cigar.data() + R.co, cig, 4ull * n_cig);
+            memcpy(o.seq.data() + R.so, sq, (l_seq + 1) / 2);
+            memcpy(o.qual.data() + R.qo, ql, l_seq);
+        }
+    });
+    cur_ += rel; // the decoded records may now be dropped from the buffer
+    // unknown read groups, in record order: the first use inserts the id with lane 0
+    for (auto& u : unknown_rg)
+        for (auto& kv : u)
+            if (hdr_.lane_names.find(kv.second) == hdr_.lane_names.end()) hdr_.lane_names[kv.second] = 0;
+    for (auto& x : extra)
+        for (auto& kv : x) { o.nm_extra_read.push_back(kv.first); o.nm_extra_val.push_back(kv.second); }
+    // the first error in record order wins; an I/O error of the walk comes after every indexed record
+    const RecErr* first = nullptr;
+    for (auto& E : errs)
+        if (E.index != SIZE_MAX && (!first || E.index < first->index)) first = &E;
+    if (first) { err = first->msg; err_code = first->code; return -1; }
+    if (io_error) { err_code = BQC_ERR_IO; return -1; }
+    return n ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -5,6 +5,8 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -21,11 +23,22 @@ struct BamHeader {
     unsigned lane_count = 0;                    // laneNames.size() after the header (bamqualcheck.cpp:297)
 };
 
+// std::vector::resize without the zero fill (the decoder overwrites every element it creates)
+template <typename T>
+struct no_init_alloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = no_init_alloc<U>; };
+    template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <typename T> using raw_vector = std::vector<T, no_init_alloc<T>>;
+
 struct HostBatch { // owning storage behind a bqc_batch
-    std::vector<uint16_t> flag, n_cigar;
-    std::vector<uint8_t> mapq, lane, seq, qual;
-    std::vector<int32_t> rid, pos, tlen, nm, as, nm_extra_val;
-    std::vector<uint32_t> l_seq, cigar, nm_extra_read;
+    raw_vector<uint16_t> flag, n_cigar;
+    raw_vector<uint8_t> mapq, lane, seq, qual;
+    raw_vector<int32_t> rid, pos, tlen, nm, as;
+    raw_vector<uint32_t> l_seq, cigar;
+    std::vector<int32_t> nm_extra_val;
+    std::vector<uint32_t> nm_extra_read;
     bqc_batch view() const;
     void clear();
     size_t n() const { return flag.size(); }

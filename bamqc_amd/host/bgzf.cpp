@@ -34,7 +34,46 @@ void parallel_for(size_t n, unsigned threads, F f)
 }
 } // namespace
 
-BgzfReader::~BgzfReader() { if (f_) fclose(f_); }
+BgzfReader::~BgzfReader()
+{
+    if (ra_started_) {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        ra_.join();
+    }
+    if (f_) fclose(f_);
+}
+
+void BgzfReader::read_ahead()
+{
+    for (;;) {
+        Item it;
+        it.ok = next_chunk_sync(it.data, it.err);
+        const bool last = !it.ok;
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.size() < 2 || stop_; });
+        if (stop_) return;
+        q_.push_back(std::move(it));
+        if (last) ra_done_ = true;
+        cv_.notify_all();
+        if (last) return;
+    }
+}
+
+bool BgzfReader::next_chunk(std::vector<uint8_t>& out, std::string& err)
+{
+    if (!ra_started_) { ra_started_ = true; ra_ = std::thread([this] { read_ahead(); }); }
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [&] { return !q_.empty() || ra_done_; });
+    if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
+    Item it = std::move(q_.front());
+    q_.pop_front();
+    cv_.notify_all();
+    lk.unlock();
+    out.swap(it.data);
+    if (!it.ok) { err = it.err; out.clear(); return false; }
+    return true;
+}
 
 bool BgzfReader::open(const char* path, std::string& err, unsigned threads)
 {
@@ -45,11 +84,11 @@ bool BgzfReader::open(const char* path, std::string& err, unsigned threads)
     return true;
 }
 
-bool BgzfReader::next_chunk(std::vector<uint8_t>& out, std::string& err)
+bool BgzfReader::next_chunk_sync(std::vector<uint8_t>& out, std::string& err)
 {
     out.clear();
     if (eof_) return false;
-    const size_t want = (size_t)threads_ * 8 * kMaxBlock; // compressed bytes per round
+    const size_t want = (size_t)threads_ * 16 * kMaxBlock; // compressed bytes per round
     // keep the tail of the previous round (a partial block) at the front of raw_
     size_t have = raw_.size();
     raw_.resize(have + want);

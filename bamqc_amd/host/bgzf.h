@@ -2,9 +2,13 @@
 // Replaces SeqAn's BAM stream layer (reference src/bamqualcheck.cpp:262, readRecord :306).
 // Format: public SAM/BAM specification (gzip members <= 64 KiB with a "BC" extra field).
 #pragma once
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 class BgzfReader {
@@ -12,11 +16,20 @@ public:
     ~BgzfReader();
     bool open(const char* path, std::string& err, unsigned threads = 0);
     // Fills `out` with the next run of uncompressed bytes (many blocks at once); returns false at EOF.
-    // On a malformed stream sets err and returns false.
+    // On a malformed stream sets err and returns false.  A read-ahead thread inflates the following runs meanwhile.
     bool next_chunk(std::vector<uint8_t>& out, std::string& err);
     uint64_t compressed_bytes_read() const { return cbytes_; }
+    unsigned threads() const { return threads_; }
 
 private:
+    bool next_chunk_sync(std::vector<uint8_t>& out, std::string& err);
+    void read_ahead();
+    struct Item { std::vector<uint8_t> data; std::string err; bool ok = false; };
+    std::thread ra_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Item> q_;
+    bool ra_started_ = false, ra_done_ = false, stop_ = false;
     FILE* f_ = nullptr;
     unsigned threads_ = 1;
     uint64_t cbytes_ = 0;

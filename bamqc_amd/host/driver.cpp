@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -419,6 +420,13 @@ extern "C" int bqc_main(int argc, const char** argv)
     fa.clear();
     fa.shrink_to_fit();
 
+    // BQC_TIMING=1: where the wall time of a run goes (stderr)
+    const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t_setup = clk::now();
+    double t_wait = 0, t_submit = 0, t_decode = 0;
+    uint64_t n_total = 0;
     // decode thread feeds batches; this thread submits them
     BatchQueue Q;
     std::thread dec([&]() {
@@ -426,7 +434,9 @@ extern "C" int bqc_main(int argc, const char** argv)
             auto hb = std::make_unique<HostBatch>();
             int code = 0;
             std::string e;
+            const auto d0 = clk::now();
             const int r = rd.next_batch(*hb, opt.batch_reads, 256ull << 20, e, code);
+            t_decode += secs(d0, clk::now());
             std::unique_lock<std::mutex> lk(Q.m);
             if (r < 0) { Q.err = e; Q.err_code = code; Q.done = true; Q.cv.notify_all(); return; }
             if (r == 0) { Q.done = true; Q.cv.notify_all(); return; }
@@ -439,6 +449,7 @@ extern "C" int bqc_main(int argc, const char** argv)
     bool warned_qual = false;
     for (;;) {
         std::unique_ptr<HostBatch> hb;
+        const auto w0 = clk::now();
         {
             std::unique_lock<std::mutex> lk(Q.m);
             Q.cv.wait(lk, [&] { return !Q.q.empty() || Q.done; });
@@ -455,9 +466,16 @@ extern "C" int bqc_main(int argc, const char** argv)
                 break;
             }
         const bqc_batch v = hb->view();
+        const auto s0 = clk::now();
+        t_wait += secs(w0, s0);
+        n_total += v.n_reads;
         if ((rc = bqc_submit(ctx, &v))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
+        t_submit += secs(s0, clk::now());
     }
     dec.join();
+    if (timing)
+        fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit (pre-pass + upload + kernels) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
+                (unsigned long long)n_total, t_decode, t_submit, t_wait, secs(t_setup, clk::now()));
     if (!status && Q.err_code) {
         if (Q.err_code == BQC_ERR_IO) fprintf(stderr, "ERROR: Could not read record from BAM File %s\n", opt.bamFile.c_str()); // :308
         else fprintf(Q.err == "Read does not have Z" ? stdout : stderr, "%s\n", Q.err.c_str());
