@@ -527,24 +527,21 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 // Branch-free: every lane issues all 16 returning atomics; a blocked window (and every window of a lane without
                 // valid cycles) adds 0.  The address is the LDS byte address itself: KS_T8 = 0 and the dynamic LDS block starts
                 // at 0 (checked at kernel entry), which saves the base addition per window.
-                if (nv)
+                if (nv) { // all 16 atomics are issued before the first returned value is looked at
+                    uint32_t old[16];
 #pragma unroll
-                for (int hb = 0; hb < 16; hb += 8) { // two batches of 8 windows: issue the atomics, then look at the old values
-                    uint32_t old[8];
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int kw = hb + kk;
+                    for (int kw = 0; kw < 16; ++kw) {
                         const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw); // window in the low 16 bits
                         const uint32_t one = bfe(kw < 8 ? f0 : f1, 28 - 4 * (kw & 7), 1);
-                        old[kk] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    uint32_t hot = 0;
+                    uint32_t hot0 = 0, hot1 = 0;
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) hot |= old[kk];
-                    if (hot & 0x80808080u) { // some counter of a touched dword is >= 128: look precisely (rare)
-                        if (hb == 0) t8_check<0>(em, c32, cx, f0, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
-                        else t8_check<8>(em, c32, cx, f1, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
-                    }
+                    for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
+                    if (hot0 & 0x80808080u) // some counter of a touched dword is >= 128: look precisely (rare)
+                        t8_check<0>(em, c32, cx, f0, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
+                    if (hot1 & 0x80808080u)
+                        t8_check<8>(em, c32, cx, f1, old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
                 }
             }
             // ---- triplets in cycle space (single-operation CIGAR: chromPos = pos + i)
