@@ -122,6 +122,11 @@ __device__ __forceinline__ void rotl_128(uint64_t& hi, uint64_t& lo, uint32_t t)
     hi = nh; lo = nl;
 }
 
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x3 __attribute__((aligned(1))) u32x3_u;
+typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+
 #define SK_F2 32768
 #define SK_THREADS 1024
 
@@ -180,46 +185,79 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
             uint64_t hh = 0, hl = 0, th = 0, tl = 0;
             uint32_t t = 0; // number of consecutive valid bases ending at the current one
             uint32_t n_hash = 0;
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t i = rc ? L - 1 - j : j;
-                const uint32_t by = sq[i >> 1];
-                const uint32_t nib = (i & 1u) ? (by & 15u) : (by >> 4);
-                const int32_t qc = (int32_t)(int8_t)(uint8_t)(ql[i] + 33u);
-                if (nib == 15u || qc < P.q_thr) { t = 0; continue; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
-                const uint32_t c = nidx[nib];
-                if (t < P.k) { // RepHash::init(const char*) built incrementally, :85-97
-                    if (t == 0) { hh = hl = th = tl = 0; }
-                    rotl1_128(hh, hl);
-                    hh ^= hv[2 * c]; hl ^= hv[2 * c + 1];
-                    uint64_t xh = hv[2 * tw[c]], xl = hv[2 * tw[c] + 1];
-                    rotl_128(xh, xl, t); // reverse-strand hash: sum_u rotl^u(hvals[twin[s_u]])
-                    th ^= xh; tl ^= xl;
-                    ++t;
-                    if (t < P.k) continue;
-                } else { // RepHash::update(out, in), :99-113
-                    const uint32_t jo = j - P.k, io = rc ? L - 1 - jo : jo;
-                    const uint32_t bo = sq[io >> 1];
-                    const uint32_t co = nidx[(io & 1u) ? (bo & 15u) : (bo >> 4)];
-                    rotl1_128(hh, hl);
-                    hh ^= hv[64 + 2 * co] ^ hv[2 * c];         // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
-                    hl ^= hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
-                    th ^= hv[2 * tw[co]] ^ hv[64 + 2 * tw[c]]; // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
-                    tl ^= hv[2 * tw[co] + 1] ^ hv[64 + 2 * tw[c] + 1];
-                    rotr1_128(th, tl);
+            // The read is walked in sequencing order, 16 bases at a time from registers: one 16-byte load of qualities and
+            // one 12-byte load of packed bases per chunk (a reverse read: the mirrored window, reversed in registers) instead
+            // of three dependent byte loads per base.  hist[d] = the nibbles of the chunk d chunks ago, for the base that
+            // leaves the k-mer (k <= 63: at most 4 chunks back).
+            uint64_t hist[5] = {0, 0, 0, 0, 0};
+            const uint32_t kq = P.k >> 4, kr = P.k & 15u; // position j - k lies kq chunks back (and one more), kr nibbles into it
+            for (uint32_t cb = 0; cb < L; cb += 16) {
+                const int32_t i_lo = rc ? (int32_t)L - 16 - (int32_t)cb : (int32_t)cb; // first BAM position of the chunk's window (may be < 0)
+                const u32x4 qv = *(const __attribute__((address_space(1))) u32x4_u*)(uintptr_t)(ql + i_lo);
+                const int32_t sb = i_lo >> 1;                                            // floor
+                const u32x3 sv = *(const __attribute__((address_space(1))) u32x3_u*)(uintptr_t)(sq + sb);
+                // qualities in sequencing order, position jj in byte jj (little-endian over q[0..3])
+                uint64_t qlo, qhi; // positions 0..7 / 8..15, one byte each
+                if (rc) {
+                    qlo = (uint64_t)__builtin_bswap32(qv.w) | ((uint64_t)__builtin_bswap32(qv.z) << 32);
+                    qhi = (uint64_t)__builtin_bswap32(qv.y) | ((uint64_t)__builtin_bswap32(qv.x) << 32);
+                } else { qlo = (uint64_t)qv.x | ((uint64_t)qv.y << 32); qhi = (uint64_t)qv.z | ((uint64_t)qv.w << 32); }
+                // nibbles in sequencing order, position jj in bits [63 - 4jj : 60 - 4jj]
+                uint64_t ns;
+                {
+                    const uint64_t b0 = __builtin_bswap32(sv.x), b1 = __builtin_bswap32(sv.y), b2 = __builtin_bswap32(sv.z);
+                    uint64_t w = (b0 << 32) | b1;                             // nibbles 2*sb .. 2*sb+15
+                    if (i_lo & 1) w = (w << 4) | (b2 >> 28);                   // window starts at an odd nibble
+                    if (rc) {                                                 // reverse the order of the 16 nibbles
+                        w = __builtin_bswap64(w);
+                        w = ((w & 0x0F0F0F0F0F0F0F0Full) << 4) | ((w >> 4) & 0x0F0F0F0F0F0F0F0Full);
+                    }
+                    ns = w;
                 }
-                // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
-                const uint64_t hash = hl ^ tl;
-                ++n_hash;
-                if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
-                else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
-                uint32_t w = hash ? (uint32_t)__ffsll((unsigned long long)hash) - 1u : 63u; // bitScanForward (lsb.cpp:26-29)
-                if (w >= P.levels) w = P.levels - 1;
-                if (mine && ((sat_mask >> w) & 1ull)) continue; // M[w] == size*countsPerLong*maxVal: every counter is 15
-                const uint64_t index = (hash >> (w + 1)) & (uint64_t)P.ctr_mask;
-                uint32_t* ctr = D.counters + (uint64_t)w * P.ctr_per_level + index;
-                if (*(volatile uint32_t*)ctr < 15u) {
-                    const uint32_t old = atomicAdd(ctr, 1u);
-                    if (old < 15u) { if (mine) atomicAdd(&lm[w], 1u); else gadd(D.misc + 1 + w, 1); }
+                hist[4] = hist[3]; hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = ns;
+                // nibbles of the positions k back: the 16-nibble window ending k positions before this chunk's end
+                uint64_t outs;
+                {
+                    const uint64_t hi = kq == 0 ? hist[1] : kq == 1 ? hist[2] : kq == 2 ? hist[3] : hist[4];
+                    const uint64_t lo = kq == 0 ? hist[0] : kq == 1 ? hist[1] : kq == 2 ? hist[2] : hist[3];
+                    outs = kr == 0 ? lo : (hi << (64u - 4u * kr)) | (lo >> (4u * kr));
+                }
+                const uint32_t nb = min(16u, L - cb);
+                for (uint32_t jj = 0; jj < nb; ++jj) {
+                    const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
+                    const int32_t qc = (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u);
+                    if (nib == 15u || qc < P.q_thr) { t = 0; continue; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
+                    const uint32_t c = nidx[nib];
+                    if (t < P.k) { // RepHash::init(const char*) built incrementally, :85-97
+                        if (t == 0) { hh = hl = th = tl = 0; }
+                        rotl1_128(hh, hl);
+                        hh ^= hv[2 * c]; hl ^= hv[2 * c + 1];
+                        uint64_t xh = hv[2 * tw[c]], xl = hv[2 * tw[c] + 1];
+                        rotl_128(xh, xl, t); // reverse-strand hash: sum_u rotl^u(hvals[twin[s_u]])
+                        th ^= xh; tl ^= xl;
+                        ++t;
+                        if (t < P.k) continue;
+                    } else { // RepHash::update(out, in), :99-113
+                        const uint32_t co = nidx[(uint32_t)(outs >> (60 - 4 * jj)) & 15u];
+                        rotl1_128(hh, hl);
+                        hh ^= hv[64 + 2 * co] ^ hv[2 * c];         // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
+                        hl ^= hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
+                        th ^= hv[2 * tw[co]] ^ hv[64 + 2 * tw[c]]; // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
+                        tl ^= hv[2 * tw[co] + 1] ^ hv[64 + 2 * tw[c] + 1];
+                        rotr1_128(th, tl);
+                    }
+                    // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
+                    const uint64_t hash = hl ^ tl;
+                    ++n_hash;
+                    if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
+                    else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
+                    uint32_t w = hash ? (uint32_t)__ffsll((unsigned long long)hash) - 1u : 63u; // bitScanForward (lsb.cpp:26-29)
+                    if (w >= P.levels) w = P.levels - 1;
+                    if (mine && ((sat_mask >> w) & 1ull)) continue; // M[w] == size*countsPerLong*maxVal: every counter is 15
+                    const uint64_t index = (hash >> (w + 1)) & (uint64_t)P.ctr_mask;
+                    // fire and forget: the counter's value is min(15, raw); k_sketch_levels clamps the raw counts after every
+                    // batch and finds the levels in which every counter has reached 15
+                    atomicAdd(D.counters + (uint64_t)w * P.ctr_per_level + index, 1u);
                 }
             }
             if (mine) atomicAdd(&lm[32], n_hash); else if (n_hash) gadd(D.misc, n_hash);
@@ -234,17 +272,22 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     }
 }
 
-// after every batch: levels whose successful-increment count reached 15 * counters are fully saturated
-__global__ void k_sketch_levels(const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps, uint32_t n_pairs, uint32_t n)
+// after every batch, workgroup per (sketch, level): clamp the raw counters to 15 and mark the level as saturated once every
+// counter has reached 15 (the reference's M[w] early-out, StreamCounter.hpp:81-83); saturated levels are not scanned again
+__global__ __launch_bounds__(256) void k_sketch_levels(const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps, uint32_t n_pairs)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const DevSketch D = dsk[i];
-    const PairParams P = pps[i % n_pairs];
-    uint64_t m = 0;
-    for (uint32_t w = 0; w < P.levels; ++w)
-        if (D.misc[1 + w] >= 15ull * P.ctr_per_level) m |= 1ull << w;
-    D.misc[40] = m;
+    const DevSketch D = dsk[blockIdx.x];
+    const PairParams P = pps[blockIdx.x % n_pairs];
+    const uint32_t w = blockIdx.y;
+    if (w >= P.levels || ((D.misc[40] >> w) & 1ull)) return;
+    uint32_t* ctr = D.counters + (uint64_t)w * P.ctr_per_level;
+    bool below = false;
+    for (uint32_t i = threadIdx.x; i < P.ctr_per_level; i += blockDim.x) {
+        const uint32_t v = ctr[i];
+        if (v > 15u) ctr[i] = 15u;
+        below |= v < 15u;
+    }
+    if (!__syncthreads_or(below) && threadIdx.x == 0) atomicOr((unsigned long long*)(D.misc + 40), 1ull << w);
 }
 
 // state vector <-> device tables: [sumCount][F2 table][counters as saturated bytes, 8 per word]
@@ -374,7 +417,7 @@ void sketch_process(SketchDevice* sk, const DevBatch& b, hipStream_t s)
     hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), (SK_F2 + 256 + 64 + 16) * 4, s, b, sk->d_ds, sk->d_pp,
                        (const uint64_t*)sk->d_hv, sk->d_idx, sk->n_pairs, per);
     const uint32_t n = sk->n_lanes * sk->n_pairs;
-    hipLaunchKernelGGL(k_sketch_levels, dim3((n + 63) / 64), dim3(64), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs, n);
+    hipLaunchKernelGGL(k_sketch_levels, dim3(n, 32), dim3(256), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs);
 }
 
 static uint64_t words_per_sketch(const SketchDevice* sk) { return 1 + sk->f2size + sk->ctr_per_level * 32 / 8; }

@@ -9,7 +9,7 @@ agg.set_timing(True)
 from tests import synth as tsynth
 n = 1_000_000
 all_cols = synth.batch(3, 10 * n, lens, refs)
-for k in range(10):
+for k in range(3):
     cols = tsynth.slice_batch(all_cols, k * n, (k + 1) * n)
     db = agg.upload(cols); agg.process(db); agg.sync()
     t = agg.last_timing(); db.free()
