@@ -1,0 +1,139 @@
+"""CPU: the `.bamqc` format stays consumable by the reference's downstream tool.
+
+bamqc_summary.py:96-131 (read_bamqc_output) only learns a lane's fixed read length when the last read_length_histogram entry
+equals total_read_pairs, i.e. on properly paired fixed-length data; the seeded config-1 reads are therefore reduced to
+complete pairs (equal numbers of primary first / second reads) before the oracle writes the file.
+  * always: the line rules of read_bamqc_output, restated here, accept the file and yield every key summarize() reads
+    (bamqc_summary.py:459-543);
+  * in the build container (reference tree present): the reference's own read_bamqc_output + summarize run on the file and
+    reproduce tests/golden/config1_summary.json (made by tests/golden/make_config1_summary.py)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from bamqc_amd import hostio
+from tests.oracle_lib import Oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("BAMQC_REFERENCE", "/root/reference")
+
+
+def take(cols, idx):
+    """Reads `idx` (ascending) of a column dict as a new dict."""
+    l = cols["l_seq"].astype(np.int64)
+    so = np.concatenate([[0], np.cumsum((l + 1) // 2)])
+    qo = np.concatenate([[0], np.cumsum(l)])
+    co = np.concatenate([[0], np.cumsum(cols["n_cigar"].astype(np.int64))])
+    out = {}
+    for k, v in cols.items():
+        if k == "seq":
+            out[k] = np.concatenate([v[so[i]:so[i + 1]] for i in idx]) if len(idx) else v[:0]
+        elif k == "qual":
+            out[k] = np.concatenate([v[qo[i]:qo[i + 1]] for i in idx]) if len(idx) else v[:0]
+        elif k == "cigar":
+            out[k] = np.concatenate([v[co[i]:co[i + 1]] for i in idx]) if len(idx) else v[:0]
+        elif k in ("nm_extra_read", "nm_extra_val"):
+            continue
+        else:
+            out[k] = v[idx]
+    return out
+
+
+def paired_config1_bamqc(tmp_path):
+    bam, fa = str(tmp_path / "c1.bam"), str(tmp_path / "c1.fa")
+    hostio.synth_write(bam, fa, seed=1001, n_reads=10_000, ref_names=["chr1"], ref_lens=[1_000_000])
+    f = hostio.BamFile(bam)
+    main = np.array([1], np.uint8)
+    f.set_main_chrom(main)
+    refs = hostio.load_fasta(fa)
+    cols = next(iter(f.batches(max_reads=1 << 20)))
+    fl = cols["flag"].astype(np.uint32)
+    prim = (fl & 0x900) == 0
+    first = np.nonzero(prim & ((fl & 0x40) != 0))[0]
+    second = np.nonzero(prim & ((fl & 0x40) == 0) & ((fl & 0x80) != 0))[0]
+    n = min(len(first), len(second))
+    keep = np.sort(np.concatenate([first[:n], second[:n]]))
+    o = Oracle(n_lanes=f.lane_count, n_refs=1, isize=1000, main_chrom=main, fasta_index=np.array([0], np.int32), klist=(32,), qlist=(17,))
+    o.reference(0, refs[0][1])
+    assert o.process(take(cols, keep)) == 0
+    o.finalize()
+    lanes = f.lanes()
+    out = str(tmp_path / "paired.bamqc")
+    o.write_bamqc(out, sample_id=f.sample_id, lane_names=[nm for nm, _ in lanes], lane_index=[i for _, i in lanes])
+    return out, n
+
+
+def read_rules(path):
+    """bamqc_summary.py:96-131 restated (one lane per 'lane' line)."""
+    lanes, lane, sample = [], None, None
+    for raw in open(path):
+        t = raw.split()
+        if t[0] == "sample_id":
+            sample = t[1]
+        elif t[0] == "lane":
+            if lane is not None:
+                lanes.append(lane)
+            lane = {"sample_id": sample, "lane": t[1], "read_length": "variable"}
+        elif t[0].startswith("read_length_histogram"):
+            sfx = t[0][21:]
+            if len(t) == 1:
+                lane["read_length" + sfx] = 0
+            elif int(t[-1]) == lane["total_read_pairs"]:
+                lane["read_length" + sfx] = len(t) - 2
+            else:
+                lane[t[0]] = [float(x) for x in t[1:]]
+        elif t[0].startswith("nr"):
+            lane[t[0]] = [t[1], int(t[2])]
+        elif len(t) == 2 and "histogram" not in t[0]:
+            lane[t[0]] = int(t[1])
+        else:
+            lane[t[0]] = [float(x) for x in t[1:]]
+    if lane is not None:
+        lanes.append(lane)
+    for ln in lanes:
+        if ln.get("read_length_first") is not None and ln.get("read_length_first") == ln.get("read_length_second"):
+            ln["read_length"] = ln["read_length_first"]
+    return lanes
+
+
+NEEDED = ["total_read_pairs", "total_bps", "average_base_qual_histogram_first", "average_base_qual_histogram_second", "N_count_histogram_first",
+          "N_count_histogram_second", "GC_content_histogram_first", "GC_content_histogram_second", "average_base_qual_by_position_first",
+          "average_base_qual_by_position_second", "Ns_by_position_first", "As_by_position_second", "Cs_by_position_first", "Gs_by_position_second",
+          "Ts_by_position_first", "distinct_32mer_count_after_qual_clipping_17", "unique_32mer_count_after_qual_clipping_17",
+          "32mer_count_after_qual_clipping_17", "8mer_count", "marked_duplicate", "first_read_unmapped", "second_read_unmapped", "both_reads_unmapped",
+          "FF_RR_oriented_pairs", "total_proper_pairs", "total_proper_pairs_autosome", "first_and_or_second_read_mapped", "genome_coverage_histogram",
+          "insert_size_histogram", "mapping_qual_histogram_first", "mapping_qual_histogram_second", "soft_clipping_5_prime_by_position_first",
+          "soft_clipping_3_prime_by_position_second", "mismatch_count_histogram_first", "deletion_count_histogram_second",
+          "insertion_count_histogram_first", "triplet_counts_A_1st_FW", "triplet_counts_T_2nd_RC"]
+
+
+def test_paired_output_follows_the_consumer_rules(tmp_path):
+    path, n = paired_config1_bamqc(tmp_path)
+    lanes = read_rules(path)
+    assert len(lanes) == 1
+    lane = lanes[0]
+    assert lane["total_read_pairs"] == n and lane["read_length"] == 150 and lane["read_length_first"] == 150
+    missing = [k for k in NEEDED if k not in lane]
+    assert not missing, missing
+    assert len(lane["8mer_count"]) == 65536 and len(lane["genome_coverage_histogram"]) == 101
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "bamqc_summary.py")), reason="reference tree not present")
+def test_reference_consumer_reproduces_the_golden_summary(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_config1_summary", os.path.join(HERE, "golden", "make_config1_summary.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    path, _ = paired_config1_bamqc(tmp_path)
+    got = mk.summarize_file(mk.load_reference_module(), path)
+    want = json.load(open(os.path.join(HERE, "golden", "config1_summary.json")))["lanes"]
+    assert len(got) == len(want) == 1
+    for k, v in want[0].items():
+        g = got[0][k]
+        if isinstance(v, float):
+            assert g is not None and math.isclose(g, v, rel_tol=1e-12, abs_tol=1e-12), k
+        else:
+            assert g == v, k
