@@ -2,6 +2,7 @@
 #include "bam_io.h"
 
 #include <algorithm>
+#include <cctype>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -45,7 +46,7 @@ bool BamReader::fill(size_t need, std::string& err)
 }
 
 // getSampleIdAndLaneNames, bamqualcheck.cpp:44-66
-static void parse_read_groups(BamHeader& h)
+void parse_read_groups(BamHeader& h)
 {
     size_t p = 0;
     const std::string& t = h.text;
@@ -272,6 +273,159 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     if (first) { err = first->msg; err_code = first->code; return -1; }
     if (io_error) { err_code = BQC_ERR_IO; return -1; }
     return n ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SAM text
+// ---------------------------------------------------------------------------------------------------
+bool SamReader::getline(std::string& line)
+{
+    line.clear();
+    if (eof_) return false;
+    char buf[1 << 16];
+    for (;;) {
+        if (!fgets(buf, sizeof buf, f_)) { eof_ = true; return !line.empty(); }
+        const size_t n = strlen(buf);
+        line.append(buf, n);
+        if (n && buf[n - 1] == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+    }
+}
+
+bool SamReader::open(FILE* f, std::string& err)
+{
+    f_ = f;
+    if (!f_) { err = "no input stream"; return false; }
+    std::string line;
+    while (getline(line)) {
+        if (line.empty()) continue;
+        if (line[0] != '@') { pending_ = line; have_pending_ = true; break; }
+        hdr_.text += line; hdr_.text += '\n';
+        if (line.compare(0, 3, "@SQ") == 0) {
+            std::string name;
+            uint32_t len = 0;
+            size_t p = 3;
+            while (p < line.size()) {
+                size_t e = line.find('\t', p + 1);
+                if (e == std::string::npos) e = line.size();
+                const std::string fld = line.substr(p + 1, e - p - 1);
+                if (fld.compare(0, 3, "SN:") == 0) name = fld.substr(3);
+                if (fld.compare(0, 3, "LN:") == 0) len = (uint32_t)strtoul(fld.c_str() + 3, nullptr, 10);
+                p = e;
+            }
+            ref_index_[name] = (int32_t)hdr_.ref_names.size();
+            hdr_.ref_names.push_back(name);
+            hdr_.ref_lens.push_back(len);
+        }
+    }
+    parse_read_groups(hdr_);
+    return true;
+}
+
+int SamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std::string& err, int& err_code)
+{
+    static const char kOps[] = "MIDNSHP=X";
+    static const char kNib[] = "=ACMGRSVTWYHKDBN";
+    o.clear();
+    err_code = 0;
+    size_t bases = 0;
+    std::string line;
+    std::vector<std::string> f;
+    auto fail = [&](const std::string& m, int code) { err = m; err_code = code; return -1; };
+    while (o.n() < max_reads && bases < max_bases) {
+        if (have_pending_) { line.swap(pending_); have_pending_ = false; }
+        else if (!getline(line)) break;
+        if (line.empty() || line[0] == '@') continue;
+        f.clear();
+        for (size_t p = 0;;) {
+            const size_t e = line.find('\t', p);
+            f.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
+            if (e == std::string::npos) break;
+            p = e + 1;
+        }
+        if (f.size() < 11) return fail("corrupt SAM record (fewer than 11 fields)", BQC_ERR_IO);
+        auto ref_of = [&](const std::string& name) -> int32_t {
+            if (name == "*") return -1;
+            auto it = ref_index_.find(name);
+            return it == ref_index_.end() ? -1 : it->second;
+        };
+        const uint32_t flag = (uint32_t)strtoul(f[1].c_str(), nullptr, 10);
+        const int32_t rid = ref_of(f[2]);
+        const int32_t pos = (int32_t)strtol(f[3].c_str(), nullptr, 10) - 1;
+        const uint32_t mapq = (uint32_t)strtoul(f[4].c_str(), nullptr, 10);
+        const int32_t rnext = f[6] == "=" ? rid : ref_of(f[6]);
+        const int32_t tlen = (int32_t)strtol(f[8].c_str(), nullptr, 10);
+        const size_t c0 = o.cigar.size();
+        uint32_t n_cig = 0;
+        if (f[5] != "*") {
+            const char* p = f[5].c_str();
+            while (*p) {
+                char* e = nullptr;
+                const unsigned long n = strtoul(p, &e, 10);
+                const char* opc = e && *e ? strchr(kOps, *e) : nullptr;
+                if (e == p || !opc || n >= (1ul << 28)) return fail("corrupt SAM record (CIGAR)", BQC_ERR_IO);
+                o.cigar.push_back((uint32_t)(n << 4) | (uint32_t)(opc - kOps));
+                ++n_cig;
+                p = e + 1;
+            }
+            if (n_cig > 65535) return fail("corrupt SAM record (more than 65535 CIGAR operations)", BQC_ERR_IO);
+        }
+        const std::string& sq = f[9];
+        const std::string& ql = f[10];
+        const uint32_t l_seq = sq == "*" ? 0u : (uint32_t)sq.size();
+        if (ql != "*" && ql.size() != l_seq) return fail("corrupt SAM record (SEQ and QUAL differ in length)", BQC_ERR_IO);
+        const size_t s0 = o.seq.size(), q0 = o.qual.size();
+        o.seq.resize(s0 + (l_seq + 1) / 2);
+        o.qual.resize(q0 + l_seq);
+        for (uint32_t i = 0; i < l_seq; i += 2) {
+            auto code = [&](char ch) -> uint32_t { const char* z = strchr(kNib, toupper((unsigned char)ch)); return z && ch ? (uint32_t)(z - kNib) : 15u; };
+            o.seq[s0 + i / 2] = (uint8_t)((code(sq[i]) << 4) | (i + 1 < l_seq ? code(sq[i + 1]) : 0u));
+        }
+        for (uint32_t i = 0; i < l_seq; ++i) o.qual[q0 + i] = ql == "*" ? (uint8_t)0xFF : (uint8_t)(ql[i] - 33);
+        // tags: RG (getLane, bamqualcheck.cpp:72-100), every integer NM (QualityCheck.hpp:201-209), first AS (TripletCounting.hpp:113-127)
+        int lane = -1;
+        bool rg_seen = false, rg_bad = false, as_seen = false, nm_seen = false;
+        int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
+        const uint32_t idx = (uint32_t)o.n();
+        for (size_t t = 11; t < f.size(); ++t) {
+            const std::string& tg = f[t];
+            if (tg.size() < 5 || tg[2] != ':' || tg[4] != ':') continue;
+            const char k0 = tg[0], k1 = tg[1], ty = tg[3];
+            const char* v = tg.c_str() + 5;
+            if (k0 == 'R' && k1 == 'G' && !rg_seen) {
+                rg_seen = true;
+                if (ty == 'Z') {
+                    const std::string id(v);
+                    auto it = hdr_.lane_names.find(id);
+                    if (it == hdr_.lane_names.end()) { hdr_.lane_names[id] = 0; lane = 0; } // std::map::operator[] inserts 0 (:86)
+                    else lane = (int)it->second;
+                } else rg_bad = true;
+            } else if (k0 == 'N' && k1 == 'M' && ty == 'i') {
+                const uint32_t x = (uint32_t)strtoll(v, nullptr, 10);
+                if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
+                else { o.nm_extra_read.push_back(idx); o.nm_extra_val.push_back((int32_t)x); }
+            } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
+                as_seen = true;
+                if (ty == 'i') as = (int32_t)strtoll(v, nullptr, 10);
+                else if (ty == 'A') as = (int32_t)v[0];
+                else if (ty == 'f') as = (int32_t)strtof(v, nullptr);
+                else as = BQC_AS_ABSENT;
+            }
+        }
+        if (rg_bad) return fail("Read does not have Z", BQC_ERR_ARG);
+        if (!rg_seen) return fail("ERROR: read without RG tag (record " + std::to_string(nrec_) + ")", BQC_ERR_ARG);
+        if ((unsigned)lane >= hdr_.lane_count) return fail("ERROR: read group index out of range (no @RG lines in the header?)", BQC_ERR_ARG);
+        if (nm_seen && nm == BQC_NM_ABSENT) return fail("NM tag value 0xFFFFFFFF is not representable", BQC_ERR_RANGE);
+        uint32_t fl = flag & 0x0FFFu;
+        if (rnext >= 0 && (size_t)rnext < main_.size() && main_[rnext]) fl |= BQC_FLAG_MATE_MAIN;
+        if (l_seq > 0 && ql == "*") fl |= BQC_FLAG_NO_QUAL;
+        o.flag.push_back((uint16_t)fl); o.mapq.push_back((uint8_t)mapq); o.lane.push_back((uint8_t)lane); o.rid.push_back(rid);
+        o.pos.push_back(pos); o.tlen.push_back(tlen); o.nm.push_back(nm); o.as.push_back(as); o.l_seq.push_back(l_seq);
+        o.n_cigar.push_back((uint16_t)n_cig);
+        (void)c0;
+        bases += l_seq;
+        ++nrec_;
+    }
+    return o.n() ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

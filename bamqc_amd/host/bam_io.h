@@ -44,19 +44,30 @@ struct HostBatch { // owning storage behind a bqc_batch
     size_t n() const { return flag.size(); }
 };
 
-class BamReader {
+// what the driver needs from an input stream of alignment records
+class RecordReader {
+public:
+    virtual ~RecordReader() {}
+    virtual BamHeader& header() = 0;
+    virtual void set_main_chrom(const std::vector<uint8_t>& mc) = 0;
+    virtual int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) = 0;
+};
+
+void parse_read_groups(BamHeader& h); // getSampleIdAndLaneNames, bamqualcheck.cpp:44-66
+
+class BamReader : public RecordReader {
 public:
     bool open(const char* path, std::string& err);
     const BamHeader& header() const { return hdr_; }
-    BamHeader& header() { return hdr_; }
-    void set_main_chrom(const std::vector<uint8_t>& mc) { main_ = mc; }
+    BamHeader& header() override { return hdr_; }
+    void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
     // keep only records whose refID is selected (keep[rid] != 0; refID -1 follows keep_unplaced): used to shard
     // a coordinate-sorted BAM by chromosome across ranks
     void set_rid_filter(const std::vector<uint8_t>& keep, bool keep_unplaced) { keep_ = keep; keep_unplaced_ = keep_unplaced; filter_ = true; }
     // Decodes up to max_reads records (and at most max_bases bases) into `out`.
     // Returns 1 = batch filled (maybe partially, more may follow), 0 = end of file and nothing read,
     // -1 = error (err set; code in err_code: BQC_ERR_IO for a corrupt file, BQC_ERR_ARG for the RG-tag rule).
-    int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code);
+    int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
 
 private:
@@ -68,6 +79,27 @@ private:
     bool eof_ = false;
     std::vector<uint8_t> main_, keep_;
     bool filter_ = false, keep_unplaced_ = true;
+    uint64_t nrec_ = 0;
+};
+
+// SAM text from a stream (the reference reads SAM from stdin when the input is "-": bamqualcheck.cpp:252-260,
+// CommandLineParser.hpp:92-107).  Fills the same batch as BamReader: same tag rules, POS - 1, QUAL '*' -> 0xFF bytes.
+// Format: public SAM specification.
+class SamReader : public RecordReader {
+public:
+    bool open(FILE* f, std::string& err); // reads the header (@ lines)
+    BamHeader& header() override { return hdr_; }
+    void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
+    int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
+
+private:
+    bool getline(std::string& line);
+    FILE* f_ = nullptr;
+    BamHeader hdr_;
+    std::map<std::string, int32_t> ref_index_;
+    std::vector<uint8_t> main_;
+    std::string pending_; // first record line, read while looking for the end of the header
+    bool have_pending_ = false, eof_ = false;
     uint64_t nrec_ = 0;
 };
 

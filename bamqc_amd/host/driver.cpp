@@ -86,7 +86,13 @@ static bool load_fasta(const char* path, const std::vector<std::string>* want, s
 // C wrappers around the reader (python drivers, tests)
 // ---------------------------------------------------------------------------------------------------
 struct bqc_bam {
-    BamReader rd;
+    BamReader bam;
+    SamReader sam;
+    bool is_sam = false;
+    FILE* sam_file = nullptr;
+    RecordReader& rd() { return is_sam ? static_cast<RecordReader&>(sam) : static_cast<RecordReader&>(bam); }
+    const BamHeader& hdr() const { return const_cast<bqc_bam*>(this)->rd().header(); }
+    ~bqc_bam() { if (sam_file && sam_file != stdin) fclose(sam_file); }
     HostBatch hb;
     bqc_batch view;
     std::string err;
@@ -95,7 +101,7 @@ struct bqc_bam {
     void refresh_lanes()
     {
         lane_sorted.clear(); lane_idx.clear();
-        for (auto& kv : rd.header().lane_names) { lane_sorted.push_back(kv.first); lane_idx.push_back(kv.second); }
+        for (auto& kv : rd().header().lane_names) { lane_sorted.push_back(kv.first); lane_idx.push_back(kv.second); }
     }
 };
 
@@ -103,38 +109,45 @@ extern "C" int bqc_bam_open(const char* path, bqc_bam** out)
 {
     if (!path || !out) return BQC_ERR_ARG;
     auto* b = new bqc_bam();
-    if (!b->rd.open(path, b->err)) { *out = b; return BQC_ERR_IO; }
+    const size_t n = strlen(path);
+    if (strcmp(path, "-") == 0 || (n > 4 && strcmp(path + n - 4, ".sam") == 0)) { // SAM text: stdin or a file
+        b->is_sam = true;
+        b->sam_file = strcmp(path, "-") == 0 ? stdin : fopen(path, "r");
+        if (!b->sam_file) { b->err = std::string("could not open ") + path; *out = b; return BQC_ERR_IO; }
+        if (!b->sam.open(b->sam_file, b->err)) { *out = b; return BQC_ERR_IO; }
+    } else if (!b->bam.open(path, b->err)) { *out = b; return BQC_ERR_IO; }
     b->refresh_lanes();
     *out = b;
     return 0;
 }
 extern "C" void bqc_bam_close(bqc_bam* b) { delete b; }
 extern "C" const char* bqc_bam_error(const bqc_bam* b) { return b ? b->err.c_str() : ""; }
-extern "C" uint32_t bqc_bam_n_refs(const bqc_bam* b) { return (uint32_t)b->rd.header().ref_names.size(); }
-extern "C" const char* bqc_bam_ref_name(const bqc_bam* b, uint32_t i) { return b->rd.header().ref_names[i].c_str(); }
-extern "C" uint32_t bqc_bam_ref_len(const bqc_bam* b, uint32_t i) { return b->rd.header().ref_lens[i]; }
-extern "C" const char* bqc_bam_sample_id(const bqc_bam* b) { return b->rd.header().sample_id.c_str(); }
-extern "C" uint32_t bqc_bam_lane_count(const bqc_bam* b) { return b->rd.header().lane_count; }
+extern "C" uint32_t bqc_bam_n_refs(const bqc_bam* b) { return (uint32_t)b->hdr().ref_names.size(); }
+extern "C" const char* bqc_bam_ref_name(const bqc_bam* b, uint32_t i) { return b->hdr().ref_names[i].c_str(); }
+extern "C" uint32_t bqc_bam_ref_len(const bqc_bam* b, uint32_t i) { return b->hdr().ref_lens[i]; }
+extern "C" const char* bqc_bam_sample_id(const bqc_bam* b) { return b->hdr().sample_id.c_str(); }
+extern "C" uint32_t bqc_bam_lane_count(const bqc_bam* b) { return b->hdr().lane_count; }
 extern "C" uint32_t bqc_bam_n_lane_names(bqc_bam* b) { b->refresh_lanes(); return (uint32_t)b->lane_sorted.size(); }
 extern "C" const char* bqc_bam_lane_name(const bqc_bam* b, uint32_t i) { return b->lane_sorted[i].c_str(); }
 extern "C" uint32_t bqc_bam_lane_index(const bqc_bam* b, uint32_t i) { return b->lane_idx[i]; }
 extern "C" int bqc_bam_set_main_chrom(bqc_bam* b, const uint8_t* mc)
 {
     if (!b || !mc) return BQC_ERR_ARG;
-    b->rd.set_main_chrom(std::vector<uint8_t>(mc, mc + b->rd.header().ref_names.size()));
+    b->rd().set_main_chrom(std::vector<uint8_t>(mc, mc + b->hdr().ref_names.size()));
     return 0;
 }
 extern "C" int bqc_bam_set_rid_filter(bqc_bam* b, const uint8_t* keep, int keep_unplaced)
 {
     if (!b || !keep) return BQC_ERR_ARG;
-    b->rd.set_rid_filter(std::vector<uint8_t>(keep, keep + b->rd.header().ref_names.size()), keep_unplaced != 0);
+    if (b->is_sam) return BQC_ERR_ARG; // (chromosome sharding needs the BAM reader)
+    b->bam.set_rid_filter(std::vector<uint8_t>(keep, keep + b->hdr().ref_names.size()), keep_unplaced != 0);
     return 0;
 }
 extern "C" int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_batch** out)
 {
     if (!b || !out) return -BQC_ERR_ARG;
     int code = 0;
-    const int rc = b->rd.next_batch(b->hb, max_reads, max_bases, b->err, code);
+    const int rc = b->rd().next_batch(b->hb, max_reads, max_bases, b->err, code);
     if (rc < 0) return -code;
     b->view = b->hb.view();
     *out = &b->view;
@@ -355,16 +368,16 @@ extern "C" int bqc_main(int argc, const char** argv)
     const int pr = parse_args(argc, argv, opt, perr);
     if (pr == 2) return 0;
     if (pr == 1) { fprintf(stderr, "%s\n", perr.c_str()); return 1; }
-    if (opt.bamFile == "-" || (opt.bamFile.size() > 4 && opt.bamFile.substr(opt.bamFile.size() - 4) == ".sam")) {
-        fprintf(stderr, "ERROR: SAM input is not supported by this build (BAM only); could not open %s for reading.\n", opt.bamFile.c_str());
-        return 1;
-    }
-    BamReader rd;
+    // "-": SAM text from stdin; everything else is opened as BAM (bamqualcheck.cpp:252-262: a .sam path fails to open there too)
+    BamReader bam_rd;
+    SamReader sam_rd;
     std::string err;
-    if (!rd.open(opt.bamFile.c_str(), err)) {
+    const bool from_stdin = opt.bamFile == "-";
+    if (from_stdin ? !sam_rd.open(stdin, err) : !bam_rd.open(opt.bamFile.c_str(), err)) {
         fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
         return 1;
     }
+    RecordReader& rd = from_stdin ? static_cast<RecordReader&>(sam_rd) : static_cast<RecordReader&>(bam_rd);
     FILE* of = fopen(opt.outputFile.c_str(), "wb"); // opened (truncated) before the scan, :278-283
     if (!of) { fprintf(stderr, "ERROR: Could not open output file %s\n", opt.outputFile.c_str()); return 1; }
     fclose(of);

@@ -62,6 +62,28 @@ def read_bam(path):
     return text, refs, recs
 
 
+def bam_to_sam_text(path):
+    """The BAM file as SAM text (header + one line per record; integer tags as type i)."""
+    text, refs, recs = read_bam(path)
+    table = "=ACMGRSVTWYHKDBN"
+    lines = [text.rstrip("\n")]
+    for r in recs:
+        nib = []
+        for b in r["seq"]:
+            nib += [b >> 4, b & 15]
+        seq = "".join(table[x] for x in nib[:r["l_seq"]]) or "*"
+        qual = "*" if r["l_seq"] == 0 or r["qual"][0] == 0xFF else "".join(chr(int(q) + 33) for q in r["qual"])
+        cig = "".join("%d%s" % (int(c) >> 4, "MIDNSHP=X"[int(c) & 15]) for c in r["cigar"]) or "*"
+        rname = refs[r["rid"]][0] if r["rid"] >= 0 else "*"
+        rnext = "*" if r["rnext"] < 0 else ("=" if r["rnext"] == r["rid"] else refs[r["rnext"]][0])
+        tags = []
+        for key, vals in r["tags"].items():
+            for ty, val in vals:
+                tags.append("%s:%s:%s" % (key, "i" if ty in "cCsSiI" else ty, val))
+        lines.append("\t".join([r["name"] or "*", str(r["flag"]), rname, str(r["pos"] + 1), str(r["mapq"]), cig, rnext, "0", str(r["tlen"]), seq, qual] + tags))
+    return "\n".join(lines) + "\n"
+
+
 def read_fasta(path):
     out = []
     name, seq = None, []

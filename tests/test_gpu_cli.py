@@ -57,3 +57,17 @@ def test_output_dir_missing(tmp_path):
     hostio.synth_write(bam, fa, seed=9, n_reads=100, ref_names=["chr1"], ref_lens=[100_000])
     r = run_cli("-r", fa, "-o", str(tmp_path / "no" / "dir" / "o.bamqc"), bam)
     assert r.returncode == 1 and "Could not open output file" in r.stderr
+
+
+def test_sam_from_stdin_matches_the_bam_run(tmp_path):
+    """`bamqualcheck ... -` reads SAM text from stdin (bamqualcheck.cpp:252-260): same bytes as the BAM run."""
+    from tests import pybam
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    hostio.synth_write(bam, fa, seed=77, n_reads=6_000, ref_names=["chr1", "chr2"], ref_lens=[300_000, 200_000], n_lanes=2)
+    sam = pybam.bam_to_sam_text(bam).encode()
+    out_b, out_s = str(tmp_path / "b.bamqc"), str(tmp_path / "s.bamqc")
+    p = run_cli("-r", fa, "-o", out_b, "-c", "chr1,chr2", bam)
+    assert p.returncode == 0, p.stderr
+    q = subprocess.run([EXE, "-r", fa, "-o", out_s, "-c", "chr1,chr2", "-"], input=sam, capture_output=True)
+    assert q.returncode == 0, q.stderr
+    assert filecmp.cmp(out_b, out_s, shallow=False)

@@ -136,3 +136,19 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 1 and "illegal option" in r.stderr
     r = subprocess.run([exe, "-r", "g.fa", "-o", str(tmp_path / "o"), str(tmp_path / "missing.bam")], capture_output=True, text=True)
     assert r.returncode == 1 and "Could not open" in r.stderr
+
+
+def test_sam_text_decodes_to_the_same_batches(synth_files, tmp_path):
+    """N4: the SAM text reader (stdin mode of the program) fills the same columns as the BAM reader."""
+    bam, fa = synth_files
+    sam = str(tmp_path / "s.sam")
+    open(sam, "w").write(pybam.bam_to_sam_text(bam))
+    fb, fs = hostio.BamFile(bam), hostio.BamFile(sam)
+    assert fs.ref_names == fb.ref_names and fs.ref_lens == fb.ref_lens
+    assert fs.sample_id == fb.sample_id and fs.lane_count == fb.lane_count and fs.lanes() == fb.lanes()
+    fb.set_main_chrom([1, 0]); fs.set_main_chrom([1, 0])
+    from tests.synth import concat
+    gb, gs = concat(list(fb.batches(max_reads=2500))), concat(list(fs.batches(max_reads=1700)))
+    assert set(gb) == set(gs)
+    for k in gb:
+        assert np.array_equal(gb[k], gs[k]), k
