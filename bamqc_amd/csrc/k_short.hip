@@ -90,7 +90,7 @@ __device__ __forceinline__ Planes planes_of(uint32_t x)
     const uint32_t p0 = x & M, p1 = (x >> 1) & M, p2 = (x >> 2) & M, p3 = (x >> 3) & M;
     const uint32_t s = p0 + p1 + p2 + p3;          // per-nibble popcount (0..4)
     Planes P;
-    P.oh = s & ~(s >> 1) & ~(s >> 2) & M;           // popcount == 1
+    P.oh = __builtin_amdgcn_bitop3_b32(s, s >> 1, s >> 2, 0x10) & M; // a & ~b & ~c: popcount == 1
     P.n = (s >> 2) & M;                             // popcount == 4: literal 'N' (code 15)
     P.a = p0 & P.oh; P.c = p1 & P.oh; P.g = p2 & P.oh; P.t = p3 & P.oh;
     return P;
