@@ -1,3 +1,6 @@
+"""End-to-end throughput of bin/bamqualcheck on a synthetic coordinate-sorted BAM (N2): writes the BAM + FASTA to /tmp,
+runs the program with and without the k-mer sketch and prints reads/s; BQC_TIMING shows where the wall time goes.
+usage: python tools/cli_throughput.py [n_reads]"""
 import sys, time, os, subprocess
 sys.path.insert(0, ".")
 from bamqc_amd import hostio

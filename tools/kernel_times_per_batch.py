@@ -1,3 +1,5 @@
+"""Per-kernel HIP-event times (bqc_last_timing) of consecutive 1 M-read batches with the k-mer sketch enabled.
+usage: python tools/kernel_times_per_batch.py"""
 import sys
 sys.path.insert(0, ".")
 from bamqc_amd import Aggregator, synth
