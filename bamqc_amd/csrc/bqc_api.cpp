@@ -412,7 +412,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
         const uint32_t h0 = (rpw + 1) / 2, h1 = rpw / 2; // slots per mate
-        const uint32_t groups_cap = 16u * (64u / rpw);  // groups per chunk: 16 waves x one tile of whole groups (see k_short)
+        const uint32_t groups_cap = BQC_FAST_WAVES * (64u / rpw); // groups per chunk: one tile of whole groups per wave of k_short
         std::vector<uint32_t> np;
         np.reserve(n + n / 4);
         std::vector<uint32_t> q[2];    // reads of the current fast chunk per mate, in stream order

@@ -11,6 +11,7 @@
 #define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
 #define BQC_CHUNK_READS 128      // max reads per chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
+#define BQC_FAST_WAVES 16        // waves per workgroup of k_short = tiles per fast chunk (host chunk layout and kernel must agree)
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)

@@ -26,8 +26,8 @@
 #include "kernels_common.h"
 #include "read_stats.h"
 
-#define KS_THREADS 1024
-#define KS_WAVES (KS_THREADS / 64)
+#define KS_WAVES BQC_FAST_WAVES
+#define KS_THREADS (KS_WAVES * 64)
 #define KS_CT 256                                  // cycles held in LDS ( > BQC_FAST_MAXLEN )
 // LDS map (uint32 words)
 #define KS_T8    0                                 // 16384: 65536 u8 8-mer counters, four per dword
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         // a wave that rotates with the chunk.
         const uint32_t n_seg = ch.count - ch.aux;
         const uint32_t my_tiles = ch.aux > wave * tile_cap ? (ch.aux - wave * tile_cap + KS_WAVES * tile_cap - 1u) / (KS_WAVES * tile_cap) : 0u;
-        const uint32_t sw0 = (wave + KS_WAVES - (ci & (KS_WAVES - 1u))) & (KS_WAVES - 1u);
+        const uint32_t sw0 = (wave + KS_WAVES - ci % KS_WAVES) % KS_WAVES;
         const uint32_t seg_tiles = n_seg > sw0 * tile_cap ? (n_seg - sw0 * tile_cap + KS_WAVES * tile_cap - 1u) / (KS_WAVES * tile_cap) : 0u;
         for (uint32_t tix = 0; tix < my_tiles + seg_tiles; ++tix) {
         const bool seg_tile = tix >= my_tiles; // wave-uniform
