@@ -6,6 +6,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <thread>
 
 bqc_batch HostBatch::view() const
@@ -35,12 +36,17 @@ bool BamReader::fill(size_t need, std::string& err)
         if (eof_) return false;
         if (cur_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + cur_); cur_ = 0; }
         std::string e;
-        if (!bg_.next_chunk(chunk_, e)) {
+        const auto w0 = std::chrono::steady_clock::now();
+        const bool got = bg_.next_chunk(chunk_, e);
+        const auto w1 = std::chrono::steady_clock::now();
+        t_wait_ += std::chrono::duration<double>(w1 - w0).count();
+        if (!got) {
             eof_ = true;
             if (!e.empty()) { err = e; return false; }
             continue;
         }
         buf_.insert(buf_.end(), chunk_.begin(), chunk_.end());
+        t_copy_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
     }
     return true;
 }
@@ -122,6 +128,8 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
 {
     o.clear();
     err_code = 0;
+    static const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '3';
+    const auto t0 = std::chrono::steady_clock::now();
     struct Rec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; }; // off: relative to cur_
     std::vector<Rec> recs;
     recs.reserve(std::min<size_t>(max_reads, 1u << 20));
@@ -129,14 +137,20 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     size_t rel = 0; // bytes of this batch walked so far; cur_ stays at the batch start, so fill() never drops them
     bool io_error = false;
     while (recs.size() < max_reads && bases < max_bases) {
-        std::string e;
-        if (!fill(rel + 4, e)) {
-            if (!e.empty() || buf_.size() != cur_ + rel) { err = e.empty() ? "truncated BAM record" : e; io_error = true; }
-            break;
+        // fast path: the whole record is already in the buffer (fill() is only called when it is not)
+        size_t avail = buf_.size() - cur_;
+        if (avail < rel + 4 || avail < rel + 4 + (size_t)rd32(buf_.data() + cur_ + rel)) {
+            std::string e;
+            if (!fill(rel + 4, e)) {
+                if (!e.empty() || buf_.size() != cur_ + rel) { err = e.empty() ? "truncated BAM record" : e; io_error = true; }
+                break;
+            }
+            const uint32_t bs0 = rd32(buf_.data() + cur_ + rel);
+            if (bs0 < 32 || !fill(rel + 4 + (size_t)bs0, e)) { err = e.empty() ? "truncated BAM record" : e; io_error = true; break; }
         }
-        const uint32_t bs = rd32(buf_.data() + cur_ + rel);
-        if (bs < 32 || !fill(rel + 4 + (size_t)bs, e)) { err = e.empty() ? "truncated BAM record" : e; io_error = true; break; }
         const uint8_t* r = buf_.data() + cur_ + rel + 4;
+        const uint32_t bs = rd32(r - 4);
+        if (bs < 32) { err = "truncated BAM record"; io_error = true; break; }
         const int32_t rid = (int32_t)rd32(r);
         const uint32_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
         const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
@@ -151,6 +165,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         rel += 4 + (size_t)bs;
         ++nrec_;
     }
+    const auto t1 = std::chrono::steady_clock::now();
     const size_t n = recs.size();
     o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);
     o.nm.resize(n); o.as.resize(n); o.l_seq.resize(n); o.n_cigar.resize(n);
@@ -260,6 +275,12 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         }
     });
     cur_ += rel; // the decoded records may now be dropped from the buffer
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] batch of %zu records: walk %.3f s (of which waiting for inflated data %.3f s, appending it %.3f s), parallel decode %.3f s\n", n,
+                std::chrono::duration<double>(t1 - t0).count(), t_wait_, t_copy_, std::chrono::duration<double>(t2 - t1).count());
+        t_wait_ = t_copy_ = 0;
+    }
     // unknown read groups, in record order: the first use inserts the id with lane 0
     for (auto& u : unknown_rg)
         for (auto& kv : u)

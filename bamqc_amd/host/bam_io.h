@@ -80,6 +80,7 @@ private:
     std::vector<uint8_t> main_, keep_;
     bool filter_ = false, keep_unplaced_ = true;
     uint64_t nrec_ = 0;
+    double t_wait_ = 0, t_copy_ = 0; // BQC_TIMING=3
 };
 
 // SAM text from a stream (the reference reads SAM from stdin when the input is "-": bamqualcheck.cpp:252-260,

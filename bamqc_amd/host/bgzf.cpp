@@ -18,7 +18,7 @@ unsigned default_threads()
 {
     unsigned n = std::thread::hardware_concurrency();
     if (const char* e = getenv("BQC_IO_THREADS")) n = (unsigned)atoi(e);
-    return std::max(1u, std::min(n, 32u));
+    return std::max(1u, std::min(n, 64u));
 }
 
 template <typename F>
@@ -51,7 +51,7 @@ void BgzfReader::read_ahead()
         it.ok = next_chunk_sync(it.data, it.err);
         const bool last = !it.ok;
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return q_.size() < 2 || stop_; });
+        cv_.wait(lk, [&] { return q_.size() < 3 || stop_; });
         if (stop_) return;
         q_.push_back(std::move(it));
         if (last) ra_done_ = true;
