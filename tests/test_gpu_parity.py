@@ -28,6 +28,16 @@ def test_synth_150bp(seed):
     assert_parity(cols, refs)
 
 
+@pytest.mark.parametrize("L", [36, 100, 151, 250, 255])
+def test_read_length_classes_two_read_groups(L):
+    # lanes per read 3 / 7 / 10 / 16 / 16 in k_short (reads per wave 21 / 9 / 6 / 4 / 4), reads of both read groups interleaved
+    from bamqc_amd import synth as csynth
+    lens = [1_500_000] * 2
+    refs = [csynth.reference(11, i, n) for i, n in enumerate(lens)]
+    cols = csynth.batch(11 + L, 60_000, lens, refs, read_len=L, n_lanes=2)
+    assert_parity(cols, refs, n_lanes=2)
+
+
 def test_synth_deep_coverage_slides():
     # dense reads: many window slides, depth beyond the clamp
     cols, refs = synth.synth(seed=11, n_reads=8000, n_refs=1, ref_len=60_000, density=120)
