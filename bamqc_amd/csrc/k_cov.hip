@@ -74,12 +74,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         int32_t loc = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) loc += (s0 + j < BQC_COV_TILE) ? d[j] : 0;
-        int32_t inc = loc; // inclusive wave scan of thread totals
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const int32_t v = __shfl_up(inc, o);
-            if (lane_id() >= o) inc += v;
-        }
+        const int32_t inc = (int32_t)wave_scan_incl((uint32_t)loc); // inclusive wave scan of the thread totals (wrapping arithmetic)
         if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = (uint32_t)inc;
         block_sync();
         // this thread's 16 entries are in registers: zero them for the next tile (its atomics come after the barrier on top)

@@ -63,17 +63,6 @@ __device__ __forceinline__ uint32_t lane_prev(uint32_t x) // value of lane - 1 (
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) // inclusive prefix sum over the 64 lanes
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
-    return v;
-}
-
 // 8 nibble-spaced 2-bit values (bits [1:0] of every nibble) -> 16 contiguous bits in the low half, first nibble on top.
 // Every step takes exactly the bits it needs (v_bfi), so the upper half of the result is junk.
 __device__ __forceinline__ uint32_t squeeze2(uint32_t c)

@@ -45,6 +45,18 @@ __device__ __forceinline__ void wave_inc(bool pred, uint64_t* addr)
     }
 }
 
+// inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts / broadcasts): no LDS round trips
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) 
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll
