@@ -72,6 +72,17 @@ __device__ __forceinline__ uint32_t squeeze2(uint32_t c)
     return (c & 0x00FF00FFu) | ((c >> 8) & ~0x00FF00FFu);
 }
 
+// a / b for a < 2^20, 0 < b < 2^10: float reciprocal estimate (off by at most one either way at these sizes), then exact
+// correction with the remainder — a fraction of the instructions of the generic 32-bit division
+__device__ __forceinline__ uint32_t small_div(uint32_t a, uint32_t b)
+{
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int32_t r = (int32_t)(a - q * b);
+    if (r < 0) { --q; r += (int32_t)b; }
+    if (r >= (int32_t)b) ++q;
+    return q;
+}
+
 struct Planes { uint32_t a, c, g, t, oh, n; }; // one-hot masked planes, one-hot mask, literal-N mask (nibble LSBs)
 __device__ __forceinline__ Planes planes_of(uint32_t x)
 {
@@ -588,9 +599,9 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 const uint32_t qs = sum & 0xFFFFu, nN = (sum >> 16) & 0xFFu, nGC = sum >> 24, rm = (m0 & 0x40u) ? 0u : 1u;
                 atomicAdd(&lds[KS_NC + rm * (KS_CT + 1) + nN], 1u);
                 atomicAdd(&lds[KS_GC + rm * (KS_CT + 1) + nGC], 1u);
-                if (L > 0) { // round-half-away and ceil of qs/L in exact integer arithmetic
-                    atomicAdd(&lds[KS_AQ + rm * 256 + (((2u * qs + L) / (2u * L)) & 255u)], 1u);
-                    atomicAdd(&lds[KS_AC + rm * 256 + (((qs + L - 1u) / L) & 255u)], 1u);
+                if (L > 0) { // round-half-away and ceil of qs/L, exact: small_div corrects the reciprocal estimate
+                    atomicAdd(&lds[KS_AQ + rm * 256 + (small_div(2u * qs + L, 2u * L) & 255u)], 1u);
+                    atomicAdd(&lds[KS_AC + rm * 256 + (small_div(qs + L - 1u, L) & 255u)], 1u);
                 }
             }
         }
