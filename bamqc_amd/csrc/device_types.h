@@ -7,9 +7,9 @@
 #define BQC_FLAG_TRIPLET 0x2000u // read passed checkFlagsAndQuality (TripletCounting.hpp:136-168)
 #define BQC_FLAG_COV     0x4000u // read enters OverallNumbers::coverage (bamqualcheck.cpp:430-433)
 
-#define BQC_TILE_STRIDE 56       // positions owned per wave tile (64 loaded: 8 look-ahead for 8-mers)
-#define BQC_CT 304               // per-cycle histogram capacity held in LDS; cycles beyond go to global atomics
-#define BQC_CHUNK_READS 128      // max reads per chunk
+#define BQC_TILE_STRIDE 56       // k_long: positions owned per wave step (64 loaded: 8 look-ahead for 8-mers)
+#define BQC_CT 304               // read_stats: read lengths / clip lengths up to here are counted in LDS, longer ones with global atomics
+#define BQC_CHUNK_READS 128      // max reads per generic chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_WAVES 16        // waves per workgroup of k_short = tiles per fast chunk (host chunk layout and kernel must agree)
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits

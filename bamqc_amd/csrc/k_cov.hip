@@ -173,7 +173,7 @@ extern "C" void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n
     if (n) hipLaunchKernelGGL(k_or_bytes, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
 }
 
-// ---- profiling aid: streams `n_dwords` with 4-byte-per-lane loads (the access width of k_short's staging) so that
+// ---- profiling aid: streams `n_dwords` with 4-byte-per-lane loads (and 8-byte-per-lane in k_calib_read8) so that
 // the rocprofv3 FETCH_SIZE counter can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section)
 __global__ void k_calib_read4(const uint32_t* __restrict__ p, uint64_t n_dwords, uint32_t* __restrict__ out)
 {

@@ -2,11 +2,10 @@
 // src/bamqualcheck.cpp:318-434) and the per-read histograms of QualityCheck
 // (src/QualityCheck.hpp:168-271: read_length, map_Q, insert_size, mis_match, cigar_count).
 //
-// Thread per read over the lane-uniform chunks of the generic path (the short-read fast path calls
-// read_stats from k_short).  Counters are privatised in LDS per
-// workgroup for the read group ("lane") the workgroup is currently in and flushed with one global
-// atomic per non-zero bin; bins beyond the LDS capacity and reads of another lane inside a mixed
-// wave go to global memory directly.  Reads 48 B of fixed columns + the CIGAR words per read.
+// Thread per read over the generic chunks, i.e. the reads k_long handles (k_short runs the same read_stats code on
+// its own reads).  Counters are privatised in LDS per workgroup for the read group ("lane") the workgroup is
+// currently in and flushed with one global atomic per non-zero bin; bins beyond the LDS capacity go to global memory
+// directly.  Reads the fixed columns + the CIGAR words of a read.
 #include "kernels_common.h"
 #include "read_stats.h"
 

@@ -19,8 +19,9 @@
 //   triplets     in cycle space as well: read and reference codes interleaved per nibble [r c]; flank equality,
 //                N exclusion, position range and quality thresholds are nibble-flag SWAR; the LDS bin index
 //                c(j-1) r(j) c(j) r(j+1) is ONE bit-field extract; ks_flush maps the bins (reverse-strand groups:
-//                complemented and mirrored) to the reference's layout (TripletCounting.hpp:195-236).  Reads whose
-//                CIGAR has more than one operation go to k_trip_list (k_trip.hip).
+//                complemented and mirrored) to the reference's layout (TripletCounting.hpp:195-236).  A read's record
+//                covers its first CIGAR operation; further match-like operations are triplet-segment entries of the
+//                chunk (TripSeg), handled by the same code with cycles / 8-mers switched off.
 //   per-read     flag cascade / scalars / per-read histograms (read_stats.h, the body of k_reads) run thread-per-read in
 //                phase A, where the read's columns are loaded anyway (bamqualcheck.cpp:318-434).
 #include "kernels_common.h"

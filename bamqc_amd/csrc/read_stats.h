@@ -1,5 +1,5 @@
 // read_stats.h — per-read statistics as a device function with LDS-privatised counters, shared by
-// k_reads (thread per read over a whole batch) and k_short (thread per read of a chunk).
+// k_reads (thread per read of the generic chunks) and k_short (lane per read of a wave's tile, phase A).
 #pragma once
 #include "kernels_common.h"
 
