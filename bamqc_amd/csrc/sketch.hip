@@ -272,22 +272,38 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     }
 }
 
-// after every batch, workgroup per (sketch, level): clamp the raw counters to 15 and mark the level as saturated once every
-// counter has reached 15 (the reference's M[w] early-out, StreamCounter.hpp:81-83); saturated levels are not scanned again
+// after every batch: clamp the raw counters to 15 and mark a level as saturated once every counter of it has reached 15
+// (the reference's M[w] early-out, StreamCounter.hpp:81-83); saturated levels are not scanned again.
+// Workgroup per (sketch, level, slice of 16 384 counters); misc[41] collects the levels that still have a counter below 15.
+#define SK_SLICE 16384u
 __global__ __launch_bounds__(256) void k_sketch_levels(const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps, uint32_t n_pairs)
 {
     const DevSketch D = dsk[blockIdx.x];
     const PairParams P = pps[blockIdx.x % n_pairs];
     const uint32_t w = blockIdx.y;
     if (w >= P.levels || ((D.misc[40] >> w) & 1ull)) return;
-    uint32_t* ctr = D.counters + (uint64_t)w * P.ctr_per_level;
+    const uint32_t lo = blockIdx.z * SK_SLICE, hi = min(P.ctr_per_level, lo + SK_SLICE);
+    uint4* ctr = (uint4*)(D.counters + (uint64_t)w * P.ctr_per_level); // (ctr_per_level is a power of two >= 8192)
     bool below = false;
-    for (uint32_t i = threadIdx.x; i < P.ctr_per_level; i += blockDim.x) {
-        const uint32_t v = ctr[i];
-        if (v > 15u) ctr[i] = 15u;
-        below |= v < 15u;
+    for (uint32_t i = lo / 4 + threadIdx.x; i < hi / 4; i += blockDim.x) {
+        uint4 v = ctr[i];
+        below |= v.x < 15u || v.y < 15u || v.z < 15u || v.w < 15u;
+        if (v.x > 15u || v.y > 15u || v.z > 15u || v.w > 15u) {
+            v.x = min(v.x, 15u); v.y = min(v.y, 15u); v.z = min(v.z, 15u); v.w = min(v.w, 15u);
+            ctr[i] = v;
+        }
     }
-    if (!__syncthreads_or(below) && threadIdx.x == 0) atomicOr((unsigned long long*)(D.misc + 40), 1ull << w);
+    if (__syncthreads_or(below) && threadIdx.x == 0) atomicOr((unsigned long long*)(D.misc + 41), 1ull << w);
+}
+__global__ void k_sketch_levels_commit(const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps, uint32_t n_pairs, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevSketch D = dsk[i];
+    const uint32_t levels = pps[i % n_pairs].levels;
+    const uint64_t all = levels >= 64 ? ~0ull : (1ull << levels) - 1ull;
+    D.misc[40] |= all & ~D.misc[41]; // no counter below 15 seen in this scan (levels already marked were not scanned: bit stays)
+    D.misc[41] = 0;
 }
 
 // state vector <-> device tables: [sumCount][F2 table][counters as saturated bytes, 8 per word]
@@ -312,7 +328,7 @@ __global__ void k_sketch_import(DevSketch D, const uint64_t* __restrict__ src, u
         for (int k = 0; k < 8; ++k) D.counters[i * 8 + k] = (uint32_t)((w >> (8 * k)) & 255u); // sums of per-rank min(15, .) ; clamped on use
     }
     if (i < 32) D.misc[1 + i] = 0; // successful-increment counts are not part of the vector: recomputed lazily (levels stay enabled)
-    if (i == 0) D.misc[40] = 0;
+    if (i == 0) { D.misc[40] = 0; D.misc[41] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -417,7 +433,8 @@ void sketch_process(SketchDevice* sk, const DevBatch& b, hipStream_t s)
     hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), (SK_F2 + 256 + 64 + 16) * 4, s, b, sk->d_ds, sk->d_pp,
                        (const uint64_t*)sk->d_hv, sk->d_idx, sk->n_pairs, per);
     const uint32_t n = sk->n_lanes * sk->n_pairs;
-    hipLaunchKernelGGL(k_sketch_levels, dim3(n, 32), dim3(256), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs);
+    hipLaunchKernelGGL(k_sketch_levels, dim3(n, 32, (uint32_t)((sk->ctr_per_level + SK_SLICE - 1) / SK_SLICE)), dim3(256), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs);
+    hipLaunchKernelGGL(k_sketch_levels_commit, dim3((n + 63) / 64), dim3(64), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs, n);
 }
 
 static uint64_t words_per_sketch(const SketchDevice* sk) { return 1 + sk->f2size + sk->ctr_per_level * 32 / 8; }
