@@ -1,5 +1,6 @@
 // bam_io.cpp — see bam_io.h
 #include "bam_io.h"
+#include "parallel.h"
 
 #include <algorithm>
 #include <cctype>
@@ -109,15 +110,6 @@ bool BamReader::open(const char* path, std::string& err)
 namespace {
 struct RecErr { size_t index = SIZE_MAX; std::string msg; int code = 0; };
 
-template <typename F>
-void parallel_ranges(size_t n, unsigned threads, F f) // f(thread, lo, hi) over contiguous ranges
-{
-    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 4096 + 1));
-    if (nt == 1) { f(0u, (size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t) th.emplace_back([=, &f]() { f(t, n * t / nt, n * (t + 1) / nt); });
-    for (auto& x : th) x.join();
-}
 } // namespace
 
 // Decoding is done in two steps so that it can use every host core: (1) a serial walk over the block_size chain that
@@ -176,7 +168,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     std::vector<std::vector<std::pair<uint32_t, std::string>>> unknown_rg(nt_max); // reads whose RG id is not in the header
     const uint8_t* base = buf_.data() + cur_;
     const auto& lane_names = hdr_.lane_names;
-    parallel_ranges(n, nt_max, [&](unsigned t, size_t lo, size_t hi) {
+    parallel_ranges(n, nt_max, 4096, [&](unsigned t, size_t lo, size_t hi) {
         std::string last_id;
         int last_lane = -1;
         bool have_last = false;

@@ -1,5 +1,6 @@
 // bgzf.cpp — see bgzf.h
 #include "bgzf.h"
+#include "parallel.h"
 
 #include <zlib.h>
 
@@ -14,12 +15,7 @@ const size_t kWriteBlock = 65280; // uncompressed payload per block (leaves room
 
 struct BlockRef { size_t off, csize, usize, uoff; };
 
-unsigned default_threads()
-{
-    unsigned n = std::thread::hardware_concurrency();
-    if (const char* e = getenv("BQC_IO_THREADS")) n = (unsigned)atoi(e);
-    return std::max(1u, std::min(n, 64u));
-}
+unsigned default_threads() { return bqc_host_threads(); }
 
 template <typename F>
 void parallel_for(size_t n, unsigned threads, F f)
