@@ -35,10 +35,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu_rehearsal = os.environ.get("BQC_BENCH_ONE_GPU") == "1"  # rehearse the N > 1 code path on a 1-GPU box: gloo, every rank on cuda:0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if one_gpu_rehearsal:
+            local = 0
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     dev = torch.device("cuda", local)
 
@@ -79,11 +84,16 @@ def main():
     if world > 1:  # end of job: one RCCL reduce of the flat state vector onto rank 0
         vec = torch.empty(agg.state_words, dtype=torch.int64, device=dev)
         agg.state_export_device(vec.data_ptr())
-        dist.reduce(vec, dst=0, op=dist.ReduceOp.SUM)
+        if one_gpu_rehearsal:
+            host = vec.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            vec.copy_(host)
+        else:
+            dist.reduce(vec, dst=0, op=dist.ReduceOp.SUM)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu_rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if rank == 0:
