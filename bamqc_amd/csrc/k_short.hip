@@ -373,6 +373,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         const uint32_t p_first = seg_tile ? ch.aux : 0u, p_n = seg_tile ? n_seg : ch.aux;
         const uint32_t tn = min(tile_cap, p_n - tb); // entries of this wave's tile (a multiple of rpw)
         // ---- phase A: lane per read — per-read statistics, and the read's record for phase B into LDS
+        __builtin_amdgcn_s_setprio(3); // few instructions between long waits: let them issue ahead of the other waves' phase B
         {
             const uint32_t t = ch.first + p_first + tb + ln;
             uint32_t r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         // reorder them
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
         // ---- phase B: groups of rpw reads; the next group's data is loaded while this one is processed
         const uint32_t n_groups = tn / rpw;
         Pre cur = ks_prefetch(lane_used ? WM + slot * KS_MW : DUMMY, w, g_seq, g_qual);
