@@ -374,14 +374,16 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         const uint32_t tn = min(tile_cap, p_n - tb); // entries of this wave's tile (a multiple of rpw)
         // ---- phase A: lane per read — per-read statistics, and the read's record for phase B into LDS
         __builtin_amdgcn_s_setprio(3); // few instructions between long waits: let them issue ahead of the other waves' phase B
+        uint32_t r;
+        bool stat; // this lane's entry is a read (per-read statistics below)
         {
             const uint32_t t = ch.first + p_first + tb + ln;
-            uint32_t r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
+            r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
             const bool live = r != 0xFFFFFFFFu;                // not a padding entry
             const bool seg = live && (r & BQC_ENTRY_SEG);      // triplet segment of a read (the read itself is another entry)
+            stat = live && !seg;
             TripSeg sg{0, 0, 0, 0};
             if (seg) { sg = b.segs[r & ~BQC_ENTRY_SEG]; r = sg.r; }
-            if ((parts & 8u) && __ballot(live && !seg)) read_stats(b, sl, state, refs, err, lds + KS_RS, live && !seg ? r : 0u, live && !seg, live && !seg);
             uint4 R0 = make_uint4(0u, KS_BIAS, KS_BIAS, 15u);
             uint4 R1 = make_uint4(0u, 24u << 16, (uint32_t)(uintptr_t)state, (uint32_t)((uintptr_t)state >> 32));
             if (live) {
@@ -430,10 +432,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         // reorder them
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_setprio(0);
         // ---- phase B: groups of rpw reads; the next group's data is loaded while this one is processed
         const uint32_t n_groups = tn / rpw;
         Pre cur = ks_prefetch(lane_used ? WM + slot * KS_MW : DUMMY, w, g_seq, g_qual);
+        // per-read statistics of the tile's reads, while the first group's data is on its way
+        if ((parts & 8u) && __ballot(stat)) read_stats(b, sl, state, refs, err, lds + KS_RS, stat ? r : 0u, stat, stat);
+        __builtin_amdgcn_s_setprio(0);
         for (uint32_t g = 0; g < n_groups; ++g) {
             const uint32_t k = g * rpw + slot; // this lane's record (lanes behind the last slot: unused)
             const uint32_t m0 = cur.m0, w5 = cur.w5, L = (m0 >> 20) & 0xFFu; // L = 0 unless the record reaches get_count
