@@ -248,9 +248,9 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
     uint8_t* p = nullptr;
     HIPCHK(c, hipMalloc(&p, len ? len : 1));
     HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
-    const uint64_t nd8 = (len + 7) / 8; // nibble table of the fast path: 2 pad dwords + nd8 + 2 pad dwords
+    const uint64_t nd8 = (len + 7) / 8; // nibble table of the fast path: BQC_FAST_NH pad dwords + nd8 + BQC_FAST_NH pad dwords
     uint32_t* pn = nullptr;
-    HIPCHK(c, hipMalloc(&pn, (nd8 + 4) * 4));
+    HIPCHK(c, hipMalloc(&pn, (nd8 + 2 * BQC_FAST_NH) * 4));
     bqc_launch_ref_nibbles(p, len, pn, nd8, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->d_ref[rid] = p;
@@ -498,7 +498,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         uint32_t maxfast = 0;
         if (!c->no_fast)
             for (uint32_t i = 0; i < n; ++i) if (b->l_seq[i] <= BQC_FAST_MAXLEN) maxfast = std::max(maxfast, b->l_seq[i]);
-        P.fast_w = std::max(1u, (maxfast + 15) / 16); // lanes per read: 16 sequencing cycles each
+        P.fast_w = std::max(1u, (maxfast + 8 * BQC_FAST_NH - 1) / (8 * BQC_FAST_NH)); // lanes per read: 8 * BQC_FAST_NH sequencing cycles each
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
         const uint32_t h0 = (rpw + 1) / 2, h1 = rpw / 2; // slots per mate
         const uint32_t groups_cap = BQC_FAST_WAVES * (64u / rpw); // groups per chunk: one tile of whole groups per wave of k_short

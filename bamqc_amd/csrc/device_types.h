@@ -12,6 +12,7 @@
 #define BQC_CHUNK_READS 128      // max reads per generic chunk
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_WAVES 16        // waves per workgroup of k_short = tiles per fast chunk (host chunk layout and kernel must agree)
+#define BQC_FAST_NH 2            // 8-cycle halves a lane of k_short owns (2: 16 cycles, 4: 32 cycles); also the pad dwords of the nibble tables
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)
@@ -85,10 +86,10 @@ struct DevBatch {
     const CovEntry* cov_list; // covered intervals per read group, in stream order (host pre-pass)
     const CovTile* cov_tiles;
     uint32_t n_cov_tiles;
-    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 16 * fast_w
+    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 8 * BQC_FAST_NH * fast_w
     const Chunk* chunks_fast;
     uint32_t n_chunks_fast;
-    uint32_t fast_w;           // lanes per read = ceil(max fast read length / 16)
+    uint32_t fast_w;           // lanes per read = ceil(max fast read length / (8 * BQC_FAST_NH))
     const TripSeg* segs;       // triplet segments of fast reads with several CIGAR operations
 };
 
@@ -98,6 +99,6 @@ struct DevRefs {
     const uint8_t* main_chrom; // [n_refs]
     uint32_t n_refs;
     // same contigs as nibbles r1 r0 ~r0 ~r1 (r = code & 3, N -> A as Dna5 -> Dna does), 8 bases per dword, first base in
-    // the top nibble, two zero dwords in front and at least two behind (see k_ref_nibbles)
+    // the top nibble, BQC_FAST_NH zero dwords in front and at least as many behind (see k_ref_nibbles)
     const uint32_t* const* refn;
 };

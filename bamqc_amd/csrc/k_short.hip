@@ -1,8 +1,8 @@
 // k_short.hip — short-read fast path (reads up to 255 bases, i.e. all Illumina-style data).
 //
 // One workgroup (16 waves) per CU walks lane-uniform chunks.  Inside a wave, `rpw = 64 / W` reads are processed at
-// once; lane (s, w) owns the 16 SEQUENCING CYCLES 16w..16w+15 of read slot s.  Everything is loaded straight from
-// global memory in cycle orientation — for a reverse-strand read the lane reads the mirrored 16-base window and
+// once; lane (s, w) owns 8 * BQC_FAST_NH = 16 SEQUENCING CYCLES (16w..16w+15) of read slot s.  Everything is loaded straight from
+// global memory in cycle orientation — for a reverse-strand read the lane reads the mirrored window and
 // reverses it in registers — one group ahead of its use, and all per-base work is SWAR on those registers:
 //
 //   orientation  the BAM base codes are one-hot nibbles (A1 C2 G4 T8), so v_bfrev_b32 yields the reversed AND
@@ -27,20 +27,25 @@
 #include "kernels_common.h"
 #include "read_stats.h"
 
+#define KS_NH BQC_FAST_NH                          // 8-cycle halves per lane
+#define KS_NB (8 * KS_NH)                         // sequencing cycles per lane
+#define KS_ND (2 * KS_NH)                         // quality dwords per lane
+#define KS_CSTRIDE (256 / KS_NB)                   // LDS cycle tile: cycle c at (c % KS_NB) * KS_CSTRIDE + c / KS_NB
+#define KS_LUTW (KS_NH == 2 ? 8 : 16)              // words per mask-table entry: KS_NH nibble masks, then (at word 4) KS_ND byte masks
 #define KS_WAVES BQC_FAST_WAVES
 #define KS_THREADS (KS_WAVES * 64)
 #define KS_CT 256                                  // cycles held in LDS ( > BQC_FAST_MAXLEN )
 // LDS map (uint32 words)
 #define KS_T8    0                                 // 16384: 65536 u8 8-mer counters, four per dword
 #define KS_TRIP  (KS_T8 + 16384)                   // [4 groups][256]
-#define KS_CYC   (KS_TRIP + 1024)                  // [2 mates][6: A C G T other qual][KS_CT], cycle c at (c & 15) * 16 + (c >> 4):
-                                                   // the lanes of a read (c >> 4 = w) hit different banks when they add the same c & 15
+#define KS_CYC   (KS_TRIP + 1024)                  // [2 mates][6: A C G T other qual][KS_CT], cycle c at (c % KS_NB) * KS_CSTRIDE + c / KS_NB:
+                                                   // the lanes of a read (c / KS_NB = w) hit different banks when they add the same c % KS_NB
 #define KS_NC    (KS_CYC + 2 * 6 * KS_CT)          // [2 mates][KS_CT + 1]
 #define KS_GC    (KS_NC + 2 * (KS_CT + 1))
 #define KS_AQ    (KS_GC + 2 * (KS_CT + 1))         // [2][256]
 #define KS_AC    (KS_AQ + 512)
-#define KS_LUT   (KS_AC + 512)                     // [17][8] masks for "the first n of 16 cycles": nibbles (2), pad (2), bytes (4)
-#define KS_META  (KS_LUT + 17 * 8)                 // per-read records: 64 per wave (the reads the wave is working on)
+#define KS_LUT   (KS_AC + 512)                     // [KS_NB + 1][KS_LUTW] masks for "the first n of the lane's cycles"
+#define KS_META  (KS_LUT + (KS_NB + 1) * KS_LUTW + (((KS_NB + 1) * KS_LUTW) % 4 ? 4 - ((KS_NB + 1) * KS_LUTW) % 4 : 0))                 // per-read records: 64 per wave (the reads the wave is working on)
 #define KS_MW    8
 #define KS_RS    (KS_META + (KS_WAVES * 64 + 1) * KS_MW)  // (16 waves x 64 records + one dummy record); per-read statistics (read_stats.h)
 #define KS_WORDS (KS_RS + RS_WORDS)
@@ -167,7 +172,7 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
         const uint32_t v = lds[KS_CYC + i];
         if (!v) continue;
         lds[KS_CYC + i] = 0;
-        const uint32_t m = i / (6 * KS_CT), c = (i / KS_CT) % 6, jj = i % KS_CT, j = (jj & 15u) * 16u + (jj >> 4);
+        const uint32_t m = i / (6 * KS_CT), c = (i / KS_CT) % 6, jj = i % KS_CT, j = (jj % KS_CSTRIDE) * KS_NB + jj / KS_CSTRIDE;
         if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
     }
     for (uint32_t i = threadIdx.x; i < 2 * (KS_CT + 1); i += blockDim.x) {
@@ -191,68 +196,69 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
     }
 }
 
-// Per-cycle accumulators of one lane (its 16 cycles), for the reads of ONE mate.
+// Per-cycle accumulators of one lane (its KS_NB cycles), for the reads of ONE mate.
 struct CycAcc {
-    uint32_t l1[2][4];   // [half][A C G T]: 4-bit vertical counters, nibble t <-> cycle 8*half + 7 - t
-    uint32_t qo[4], qe[4]; // quality sums of dword d (cycles 4d..4d+3), 16-bit fields: qo = cycles 4d | 4d+2, qe = 4d+1 | 4d+3
+    uint32_t l1[KS_NH][4];       // [half][A C G T]: 4-bit vertical counters, nibble t <-> cycle 8*half + 7 - t
+    uint32_t qo[KS_ND], qe[KS_ND]; // quality sums of dword d (cycles 4d..4d+3), 16-bit fields: qo = cycles 4d | 4d+2, qe = 4d+1 | 4d+3
 };
 __device__ __forceinline__ void cyc_zero(CycAcc& A)
 {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { A.l1[0][p] = 0; A.l1[1][p] = 0; A.qo[p] = 0; A.qe[p] = 0; }
+    for (int h = 0; h < KS_NH; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) A.l1[h][p] = 0;
+#pragma unroll
+    for (int d = 0; d < KS_ND; ++d) { A.qo[d] = 0; A.qe[d] = 0; }
 }
 // The counters go to the LDS cycle tile through real functions with by-value arguments (registers, no scratch): rare.
-__device__ __noinline__ void cyc_spill_lds(uint32_t a0, uint32_t a1, uint32_t c0, uint32_t c1, uint32_t g0, uint32_t g1, uint32_t t0, uint32_t t1,
-                                           uint32_t* base /* lds + KS_CYC + mate * 6 * KS_CT + w */)
+__device__ __noinline__ void cyc_spill_half(uint32_t a, uint32_t c, uint32_t g, uint32_t t, uint32_t* base /* lds + KS_CYC + mate * 6 * KS_CT + w + KS_CSTRIDE * 8 * half */)
 {
-    const uint32_t v[8] = {a0, a1, c0, c1, g0, g1, t0, t1};
+    const uint32_t v[4] = {a, c, g, t};
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) atomicAdd(base + p * KS_CT + 16 * (8 * h + 7 - t), (v[2 * p + h] >> (4 * t)) & 15u);
+        for (int n = 0; n < 8; ++n) atomicAdd(base + p * KS_CT + KS_CSTRIDE * (7 - n), (v[p] >> (4 * n)) & 15u);
 }
-__device__ __noinline__ void cyc_qflush_lds(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t o2, uint32_t e2, uint32_t o3, uint32_t e3,
-                                            uint32_t* base /* lds + KS_CYC + (mate * 6 + 5) * KS_CT + w */)
+__device__ __noinline__ void cyc_qflush_pair(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t* base /* lds + KS_CYC + (mate * 6 + 5) * KS_CT + w + KS_CSTRIDE * 8 * half */)
 {
-    const uint32_t vo[4] = {o0, o1, o2, o3}, ve[4] = {e0, e1, e2, e3};
+    const uint32_t vo[2] = {o0, o1}, ve[2] = {e0, e1};
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        atomicAdd(base + 16 * (4 * d + 0), vo[d] >> 16);
-        atomicAdd(base + 16 * (4 * d + 1), ve[d] >> 16);
-        atomicAdd(base + 16 * (4 * d + 2), vo[d] & 0xFFFFu);
-        atomicAdd(base + 16 * (4 * d + 3), ve[d] & 0xFFFFu);
+    for (int d = 0; d < 2; ++d) {
+        atomicAdd(base + KS_CSTRIDE * (4 * d + 0), vo[d] >> 16);
+        atomicAdd(base + KS_CSTRIDE * (4 * d + 1), ve[d] >> 16);
+        atomicAdd(base + KS_CSTRIDE * (4 * d + 2), vo[d] & 0xFFFFu);
+        atomicAdd(base + KS_CSTRIDE * (4 * d + 3), ve[d] & 0xFFFFu);
     }
 }
 __device__ __forceinline__ void cyc_spill(CycAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
 {
-    cyc_spill_lds(A.l1[0][0], A.l1[1][0], A.l1[0][1], A.l1[1][1], A.l1[0][2], A.l1[1][2], A.l1[0][3], A.l1[1][3], lds + KS_CYC + mate * 6 * KS_CT + w);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { A.l1[0][p] = 0; A.l1[1][p] = 0; }
+    for (int h = 0; h < KS_NH; ++h) {
+        cyc_spill_half(A.l1[h][0], A.l1[h][1], A.l1[h][2], A.l1[h][3], lds + KS_CYC + mate * 6 * KS_CT + w + KS_CSTRIDE * 8 * h);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) A.l1[h][p] = 0;
+    }
 }
 __device__ __forceinline__ void cyc_qflush(CycAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
 {
-    cyc_qflush_lds(A.qo[0], A.qe[0], A.qo[1], A.qe[1], A.qo[2], A.qe[2], A.qo[3], A.qe[3], lds + KS_CYC + (mate * 6 + 5) * KS_CT + w);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { A.qo[p] = 0; A.qe[p] = 0; }
+    for (int h = 0; h < KS_NH; ++h) {
+        cyc_qflush_pair(A.qo[2 * h], A.qe[2 * h], A.qo[2 * h + 1], A.qe[2 * h + 1], lds + KS_CYC + (mate * 6 + 5) * KS_CT + w + KS_CSTRIDE * 8 * h);
+        A.qo[2 * h] = A.qe[2 * h] = A.qo[2 * h + 1] = A.qe[2 * h + 1] = 0;
+    }
 }
-__device__ __forceinline__ void cyc_add(CycAcc& A, const Planes& P0, const Planes& P1, const uint32_t (&Q)[4])
+__device__ __forceinline__ void cyc_add(CycAcc& A, const Planes (&P)[KS_NH], const uint32_t (&Q)[KS_ND])
 {
-    A.l1[0][0] += P0.a; A.l1[0][1] += P0.c; A.l1[0][2] += P0.g; A.l1[0][3] += P0.t;
-    A.l1[1][0] += P1.a; A.l1[1][1] += P1.c; A.l1[1][2] += P1.g; A.l1[1][3] += P1.t;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) { A.qe[d] += Q[d] & 0x00FF00FFu; A.qo[d] += (Q[d] >> 8) & 0x00FF00FFu; }
+    for (int h = 0; h < KS_NH; ++h) { A.l1[h][0] += P[h].a; A.l1[h][1] += P[h].c; A.l1[h][2] += P[h].g; A.l1[h][3] += P[h].t; }
+#pragma unroll
+    for (int d = 0; d < KS_ND; ++d) { A.qe[d] += Q[d] & 0x00FF00FFu; A.qo[d] += (Q[d] >> 8) & 0x00FF00FFu; }
 }
 
 // explicit global-address-space loads (generic/flat loads would count on lgkmcnt and make every LDS wait also wait for
 // the prefetch); the 12- and 16-byte loads are unaligned
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x3 __attribute__((aligned(1))) u32x3_u;
-typedef u32x4 __attribute__((aligned(1))) u32x4_u;
-typedef u32x3 __attribute__((aligned(4))) u32x3_a;
-typedef const __attribute__((address_space(1))) uint8_t* g_u8p;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ lds_u32* lds_at(uint32_t byte_addr) { return (lds_u32*)(uintptr_t)byte_addr; }
 
@@ -263,29 +269,67 @@ __device__ __forceinline__ lds_u32* lds_at(uint32_t byte_addr) { return (lds_u32
 // word 0: BAM flag (low 16 bits) | KM_* | L << 20 (L = 0 unless KM_PRIM)
 //      1: seq byte offset of the window of lane w = 0 (+ KS_BIAS)      -> after the group was computed: packed sums before the read
 //      2: qual byte offset of the window of lane w = 0 (+ KS_BIAS)     ->                               packed sums after the read
-//      3: reference nibble index of that window (pos + o0 + 15; the table has 16 pad nibbles in front)
+//      3: reference nibble index of that window, minus one (pos + o0 + NB - 1; the table has NB = 8 * BQC_FAST_NH pad nibbles in front)
 //      4: last loadable dword index of the contig's table     5: ja | jb << 8 | seq funnel shift << 16
 //      6-7: pointer to the contig's nibble table
-// Lane w of a forward read loads the window starting at base 16 w, of a reverse read the one starting at L - 16 - 16 w.
+// Lane w of a forward read loads the window starting at base NB w, of a reverse read the one starting at L - NB - NB w.
 
-struct Pre { u32x3 s; u32x4 q; u32x3 e; uint32_t m0, pp, w5; }; // raw data of the NEXT group, in flight while the current one is computed
+// NH nibble masks / ND byte masks of one mask-table entry (16-byte LDS reads)
+__device__ __forceinline__ void lut_nib(uint32_t (&d)[KS_NH], const uint32_t* e)
+{
+    if (KS_NH == 2) { const uint2 v = *(const uint2*)e; d[0] = v.x; d[1] = v.y; }
+    else { const uint4 v = *(const uint4*)e; d[0] = v.x; d[1] = v.y; d[KS_NH - 2] = v.z; d[KS_NH - 1] = v.w; }
+}
+__device__ __forceinline__ void lut_byte(uint32_t (&d)[KS_ND], const uint32_t* e)
+{
+#pragma unroll
+    for (int q = 0; q < KS_ND / 4; ++q) { const uint4 v = *(const uint4*)(e + 4 * q); d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w; }
+}
+
+// raw data of the NEXT group, in flight while the current one is computed: KS_NH + 1 dwords of packed bases (the window may start
+// up to two nibbles into them), KS_ND dwords of qualities, KS_NH + 1 dwords of reference nibbles
+struct Pre { uint32_t s[KS_NH + 1], q[KS_ND], e[KS_NH + 1]; uint32_t m0, pp, w5; };
+
+// N dwords from global memory with one or two vector loads; U: any byte address, A: dword-aligned address
+typedef u32x3 __attribute__((aligned(1))) u32x3_u;
+typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+typedef uint32_t __attribute__((aligned(1))) u32_u;
+typedef u32x3 __attribute__((aligned(4))) u32x3_a;
+typedef u32x4 __attribute__((aligned(4))) u32x4_a;
+#define KS_GLOBAL(T, p) (*(const __attribute__((address_space(1))) T*)(uintptr_t)(p))
+template <int N> struct GVec;
+template <> struct GVec<3> {
+    static __device__ __forceinline__ void ldu(uint32_t* d, const uint8_t* p) { const u32x3 v = KS_GLOBAL(u32x3_u, p); d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+    static __device__ __forceinline__ void lda(uint32_t* d, const uint8_t* p) { const u32x3 v = KS_GLOBAL(u32x3_a, p); d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+};
+template <> struct GVec<4> {
+    static __device__ __forceinline__ void ldu(uint32_t* d, const uint8_t* p) { const u32x4 v = KS_GLOBAL(u32x4_u, p); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+    static __device__ __forceinline__ void lda(uint32_t* d, const uint8_t* p) { const u32x4 v = KS_GLOBAL(u32x4_a, p); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+};
+template <> struct GVec<5> {
+    static __device__ __forceinline__ void ldu(uint32_t* d, const uint8_t* p) { GVec<4>::ldu(d, p); d[4] = KS_GLOBAL(u32_u, p + 16); }
+    static __device__ __forceinline__ void lda(uint32_t* d, const uint8_t* p) { GVec<4>::lda(d, p); d[4] = KS_GLOBAL(uint32_t, p + 16); }
+};
+template <> struct GVec<8> {
+    static __device__ __forceinline__ void ldu(uint32_t* d, const uint8_t* p) { GVec<4>::ldu(d, p); GVec<4>::ldu(d + 4, p + 16); }
+};
 
 // Issue the global loads of one group for this lane.  Branch-free: records of non-primary reads, padding entries and the
 // dummy record used by lanes past the end of the chunk carry L = 0 and offsets / pointers that are safe to load from
 // (the buffers are padded on both sides), so every lane always loads; what must not be used is masked when consumed.
-__device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, g_u8p seqb, g_u8p qualb)
+__device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, const uint8_t* seqb, const uint8_t* qualb)
 {
     const uint4 ma = *(const uint4*)rec, mb = *(const uint4*)(rec + 4);
     const int32_t sw = (ma.x & 0x10u) ? -(int32_t)w : (int32_t)w;
     Pre P;
     P.m0 = ma.x;
     P.w5 = mb.y;
-    P.pp = ma.w + (uint32_t)(16 * sw);
-    P.s = *(const __attribute__((address_space(1))) u32x3_u*)(seqb + (uint32_t)(ma.y + (uint32_t)(8 * sw)));
-    P.q = *(const __attribute__((address_space(1))) u32x4_u*)(qualb + (uint32_t)(ma.z + (uint32_t)(16 * sw)));
+    P.pp = ma.w + (uint32_t)(KS_NB * sw);
+    GVec<KS_NH + 1>::ldu(P.s, seqb + (uint32_t)(ma.y + (uint32_t)(KS_NB / 2 * sw)));
+    GVec<KS_ND>::ldu(P.q, qualb + (uint32_t)(ma.z + (uint32_t)(KS_NB * sw)));
     const uint32_t* rn = (const uint32_t*)(uintptr_t)((uint64_t)mb.z | ((uint64_t)mb.w << 32));
     const int32_t di = min(max((int32_t)P.pp >> 3, 0), (int32_t)mb.x);
-    P.e = *(const __attribute__((address_space(1))) u32x3_a*)(uintptr_t)(rn + di);
+    GVec<KS_NH + 1>::lda(P.e, (const uint8_t*)(rn + di));
     return P;
 }
 
@@ -303,26 +347,28 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     const uint32_t M = 0x11111111u;
     const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t W = b.fast_w, rpw = 64u / W;
-    const uint32_t slot = ln / W, w = ln % W, w16 = 16u * w;
+    const uint32_t slot = ln / W, w = ln % W, wnb = KS_NB * w;
     const bool lane_used = slot < rpw;
     const bool last_w = (w + 1u >= W) || ln == 63u;   // the next lane belongs to another read
     const uint32_t tile_cap = rpw * (64u / rpw);        // reads a wave takes at a time: one record per lane, whole groups
     uint32_t* WM = lds + KS_META + wave * 64u * KS_MW;   // this wave's records
     const uint32_t* DUMMY = lds + KS_META + KS_WAVES * 64u * KS_MW; // record for lanes behind the last slot
     const uint32_t* LUT = lds + KS_LUT;
-    if (threadIdx.x < 17u) { // masks for "the first n of the lane's 16 cycles"
-        const uint32_t n = threadIdx.x, n0 = n < 8u ? n : 8u, n1 = n - n0;
-        uint32_t* e = lds + KS_LUT + 8 * n;
-        e[0] = n0 ? 0xFFFFFFFFu << (4u * (8u - n0)) : 0u;
-        e[1] = n1 ? 0xFFFFFFFFu << (4u * (8u - n1)) : 0u;
-        for (uint32_t d = 0; d < 4; ++d) {
+    if (threadIdx.x <= KS_NB) { // masks for "the first n of the lane's cycles"
+        const uint32_t n = threadIdx.x;
+        uint32_t* e = lds + KS_LUT + KS_LUTW * n;
+        for (uint32_t h = 0; h < KS_NH; ++h) {
+            const uint32_t v = n > 8u * h ? (n - 8u * h < 8u ? n - 8u * h : 8u) : 0u;
+            e[h] = v ? 0xFFFFFFFFu << (4u * (8u - v)) : 0u;
+        }
+        for (uint32_t d = 0; d < KS_ND; ++d) {
             const uint32_t v = n > 4u * d ? (n - 4u * d < 4u ? n - 4u * d : 4u) : 0u;
             e[4 + d] = v ? 0xFFFFFFFFu << (8u * (4u - v)) : 0u; // qualities are kept big-endian: first cycle in the top byte
         }
     }
     if (threadIdx.x < KS_MW) { // dummy record: L = 0, loadable offsets / pointer
         const uint32_t t = threadIdx.x;
-        lds[KS_META + KS_WAVES * 64u * KS_MW + t] = t == 1 || t == 2 ? KS_BIAS : t == 3 ? 15u : t == 5 ? (24u << 16) : t == 6 ? (uint32_t)(uintptr_t)state
+        lds[KS_META + KS_WAVES * 64u * KS_MW + t] = t == 1 || t == 2 ? KS_BIAS : t == 3 ? 8u * KS_NH - 1u : t == 5 ? (24u << 16) : t == 6 ? (uint32_t)(uintptr_t)state
                                    : t == 7 ? (uint32_t)((uintptr_t)state >> 32) : 0u;
     }
     block_sync();
@@ -332,8 +378,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     uint32_t n1 = 0, n2 = 0; // groups since the last counter spill / quality flush (wave-uniform)
     uint32_t cur_lane = 0xFFFFFFFFu, since_t8 = 0;
 
-    const g_u8p g_seq = (g_u8p)(uintptr_t)(b.seq - KS_BIAS);
-    const g_u8p g_qual = (g_u8p)(uintptr_t)(b.qual - KS_BIAS);
+    const uint8_t* g_seq = b.seq - KS_BIAS;
+    const uint8_t* g_qual = b.qual - KS_BIAS;
     const uint32_t n_chunks = b.n_chunks_fast;
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane (single call site)
         const bool done = ci >= n_chunks;
@@ -384,7 +430,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             stat = live && !seg;
             TripSeg sg{0, 0, 0, 0};
             if (seg) { sg = b.segs[r & ~BQC_ENTRY_SEG]; r = sg.r; }
-            uint4 R0 = make_uint4(0u, KS_BIAS, KS_BIAS, 15u);
+            uint4 R0 = make_uint4(0u, KS_BIAS, KS_BIAS, 8u * KS_NH - 1u);
             uint4 R1 = make_uint4(0u, 24u << 16, (uint32_t)(uintptr_t)state, (uint32_t)((uintptr_t)state >> 32));
             if (live) {
                 const uint32_t fl = b.flag[r];
@@ -392,7 +438,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 if (!(fl & 0x900u) && (fl & 0xC0u)) { // reaches get_count / count8mers
                     const uint32_t L = b.l_seq[r];
                     const bool rc = fl & 0x10u, noq = fl & BQC_FLAG_NO_QUAL;
-                    const int32_t o0 = rc ? (int32_t)L - 16 : 0;
+                    const int32_t o0 = rc ? (int32_t)L - KS_NB : 0;
                     R0.x |= (seg ? KM_SEG : KM_PRIM) | (L << 20);
                     R0.y = b.seq_off[r] + (uint32_t)((o0 - 1) >> 1) + KS_BIAS; // the window is loaded from one byte (odd o0: one nibble) earlier
                     R0.z = (noq ? 0u : b.qual_off[r]) + (uint32_t)o0 + KS_BIAS;
@@ -416,8 +462,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                             const uint32_t ja = rc ? L - (uint32_t)ib : (uint32_t)ia, jb = rc ? L - (uint32_t)ia : (uint32_t)ib; // the same range in cycles
                             const uint64_t nd8 = (uint64_t)(reflen + 7) >> 3;
                             R0.x |= KM_TRIP;
-                            R0.w = (uint32_t)((int32_t)pos + o0 + 15);
-                            R1.x = (uint32_t)(nd8 + 1);
+                            R0.w = (uint32_t)((int32_t)pos + o0 + 8 * KS_NH - 1);
+                            R1.x = (uint32_t)(nd8 + KS_NH - 1);
                             R1.y |= ja | (jb << 8);
                             const uint64_t rn = (uint64_t)(uintptr_t)refs.refn[rid];
                             R1.z = (uint32_t)rn; R1.w = (uint32_t)(rn >> 32);
@@ -443,67 +489,82 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             const uint32_t m0 = cur.m0, w5 = cur.w5, L = (m0 >> 20) & 0xFFu; // L = 0 unless the record reaches get_count
             const bool rc = m0 & 0x10u;
             const bool segg = (uint32_t)__builtin_amdgcn_readfirstlane((int)m0) & KM_SEG; // a group of triplet segments: triplets only
-            const uint32_t nv = (uint32_t)min(max((int32_t)L - (int32_t)w16, 0), 16);   // valid cycles of this lane
+            const uint32_t nv = (uint32_t)min(max((int32_t)L - (int32_t)wnb, 0), KS_NB);   // valid cycles of this lane
             const uint32_t nvq = (m0 & BQC_FLAG_NO_QUAL) ? 0u : nv;
-            const uint2 xm = *(const uint2*)(LUT + 8u * nv);
-            const uint4 qm = *(const uint4*)(LUT + 8u * nvq + 4u);
-            // ---------------- the lane's 16 cycles: one-hot base nibbles X0 | X1 (first cycle in the top nibble) ...
-            uint32_t X0, X1;
+            uint32_t xm[KS_NH], qm[KS_ND];
+            lut_nib(xm, LUT + KS_LUTW * nv);
+            lut_byte(qm, LUT + KS_LUTW * nvq + 4u);
+            // ---------------- the lane's cycles: one-hot base nibbles X[h] = cycles 8h..8h+7 (first cycle in the top nibble) ...
+            uint32_t X[KS_NH];
             {
                 const uint32_t sh = w5 >> 16; // 24 / 28: the loaded bytes start 2 / 1 nibbles before the window
-                const uint32_t b0 = bswap32(cur.s.x), b1 = bswap32(cur.s.y), b2 = bswap32(cur.s.z);
-                const uint32_t F0 = alignbit(b0, b1, sh), F1 = alignbit(b1, b2, sh);
-                X0 = (rc ? __brev(F1) : F0) & xm.x; // bit reversal = reversed base order and complemented one-hot codes (IUPAC too)
-                X1 = (rc ? __brev(F0) : F1) & xm.y;
+                uint32_t bs[KS_NH + 1], F[KS_NH];
+#pragma unroll
+                for (int h = 0; h <= KS_NH; ++h) bs[h] = bswap32(cur.s[h]);
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) F[h] = alignbit(bs[h], bs[h + 1], sh);
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) // bit reversal = reversed base order and complemented one-hot codes (IUPAC too)
+                    X[h] = (rc ? __brev(F[KS_NH - 1 - h]) : F[h]) & xm[h];
             }
             // ... and qualities Q[d] = cycles 4d..4d+3, first cycle in the top byte
-            uint32_t Q[4];
+            uint32_t Q[KS_ND];
             {
                 const uint32_t sel = rc ? 0x07060504u : 0x00010203u; // reverse read: dwords in reverse order; forward read: bytes swapped
-                Q[0] = vperm(cur.q.w, cur.q.x, sel) & qm.x;
-                Q[1] = vperm(cur.q.z, cur.q.y, sel) & qm.y;
-                Q[2] = vperm(cur.q.y, cur.q.z, sel) & qm.z;
-                Q[3] = vperm(cur.q.x, cur.q.w, sel) & qm.w;
-                const uint32_t hi = (Q[0] | Q[1] | Q[2] | Q[3]) & 0x80808080u;
-                if (hi) { // some Phred >= 128: check the 222 limit precisely
+                uint32_t any = 0;
+#pragma unroll
+                for (int d = 0; d < KS_ND; ++d) { Q[d] = vperm(cur.q[KS_ND - 1 - d], cur.q[d], sel) & qm[d]; any |= Q[d]; }
+                if (any & 0x80808080u) { // some Phred >= 128: check the 222 limit precisely
                     bool bad = false;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d)
+                    for (int d = 0; d < KS_ND; ++d)
 #pragma unroll
                         for (int k8 = 0; k8 < 4; ++k8) bad |= ((Q[d] >> (8 * k8)) & 0xFFu) > 222u;
                     if (bad) atomicOr(err, BQC_DEVERR_QUAL);
                 }
             }
             // ... and the reference window as nibbles r1 r0 ~r0 ~r1: bit reversal = reverse complement here too
-            uint32_t E0, E1;
+            uint32_t E[KS_NH];
             {
                 const uint32_t sh = 28u - 4u * (cur.pp & 7u);
-                const uint32_t F0 = alignbit(cur.e.x, cur.e.y, sh), F1 = alignbit(cur.e.y, cur.e.z, sh);
-                E0 = rc ? __brev(F1) : F0;
-                E1 = rc ? __brev(F0) : F1;
+                uint32_t F[KS_NH];
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) F[h] = alignbit(cur.e[h], cur.e[h + 1], sh);
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) E[h] = rc ? __brev(F[KS_NH - 1 - h]) : F[h];
             }
             { // the raw registers are free again: issue the loads of this wave's next group
                 cur = ks_prefetch(lane_used && g + 1u < n_groups ? WM + (k + rpw) * KS_MW : DUMMY, w, g_seq, g_qual);
             }
-            const Planes P0 = planes_of(X0), P1 = planes_of(X1);
-            // ---- per-cycle counters (the group's mate selects the register set: wave-uniform branch)
+            Planes P[KS_NH];
+#pragma unroll
+            for (int h = 0; h < KS_NH; ++h) P[h] = planes_of(X[h]);
+            // ---- per-cycle counters (this lane's mate is fixed: one register set)
             if ((parts & 1u) && !segg) {
-                cyc_add(A, P0, P1, Q);
+                cyc_add(A, P, Q);
                 if (++n1 == 15u) { if (lane_used) cyc_spill(A, lds, mate, w); n1 = 0; }
                 if (++n2 == 255u) { if (lane_used) cyc_qflush(A, lds, mate, w); n2 = 0; }
                 // cycles holding anything but A/C/G/T (Dna5 'N' bin) are rare: counted directly
-                uint32_t o0 = xm.x & M & ~P0.oh, o1 = xm.y & M & ~P1.oh;
-                if (o0 | o1) {
+                uint32_t oth[KS_NH], oany = 0;
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) { oth[h] = xm[h] & M & ~P[h].oh; oany |= oth[h]; }
+                if (oany) {
                     uint32_t* ob = lds + KS_CYC + (mate * 6 + 4) * KS_CT + w;
-                    while (o0) { const uint32_t bit = (uint32_t)__ffs((int)o0) - 1u; o0 &= o0 - 1u; atomicAdd(ob + 16u * (7u - (bit >> 2)), 1u); }
-                    while (o1) { const uint32_t bit = (uint32_t)__ffs((int)o1) - 1u; o1 &= o1 - 1u; atomicAdd(ob + 16u * (15u - (bit >> 2)), 1u); }
+#pragma unroll
+                    for (int h = 0; h < KS_NH; ++h) {
+                        uint32_t o = oth[h];
+                        while (o) { const uint32_t bit = (uint32_t)__ffs((int)o) - 1u; o &= o - 1u; atomicAdd(ob + KS_CSTRIDE * (8u * h + 7u - (bit >> 2)), 1u); }
+                    }
                 }
                 // per-read sums: quality | N << 16 | GC << 24 (L <= 255), one wave-wide prefix scan; the lane at the start of
                 // a slot leaves the running sum before its read in record word 1 and, for the previous slot, after it in word 2
-                uint32_t v = __builtin_amdgcn_sad_u8(Q[0], 0u, 0u);
-                v = __builtin_amdgcn_sad_u8(Q[1], 0u, v); v = __builtin_amdgcn_sad_u8(Q[2], 0u, v); v = __builtin_amdgcn_sad_u8(Q[3], 0u, v);
-                v |= ((uint32_t)__popc(P0.n) + (uint32_t)__popc(P1.n)) << 16;
-                v += ((uint32_t)__popc(P0.c | P0.g) + (uint32_t)__popc(P1.c | P1.g)) << 24;
+                uint32_t v = 0, vn = 0, vgc = 0;
+#pragma unroll
+                for (int d = 0; d < KS_ND; ++d) v = __builtin_amdgcn_sad_u8(Q[d], 0u, v);
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) { vn += (uint32_t)__popc(P[h].n); vgc += (uint32_t)__popc(P[h].c | P[h].g); }
+                v |= vn << 16;
+                v += vgc << 24;
                 const uint32_t si = wave_scan_incl(v);
                 const uint32_t bs = lane_prev(si);
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)si, 63);
@@ -514,84 +575,107 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 }
             }
             // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
-            const uint32_t cn0 = (P0.c | P0.t) | ((P0.g | P0.t) << 1), cn1 = (P1.c | P1.t) | ((P1.g | P1.t) << 1);
-            // literal N or past the end of the read: blocks 8-mer windows and triplet flanks
-            const uint32_t nb0 = P0.n | (~xm.x & M), nb1 = P1.n | (~xm.y & M);
-            // ---- 8-mers: windows starting at the lane's 16 cycles
+            uint32_t cn[KS_NH], nb[KS_NH + 1];
+#pragma unroll
+            for (int h = 0; h < KS_NH; ++h) {
+                cn[h] = (P[h].c | P[h].t) | ((P[h].g | P[h].t) << 1);
+                nb[h] = P[h].n | (~xm[h] & M); // literal N or past the end of the read: blocks 8-mer windows and triplet flanks
+            }
+            // ---- 8-mers: windows starting at the lane's cycles
             if ((parts & 2u) && !segg) {
-                const uint32_t c32 = vperm(squeeze2(cn0), squeeze2(cn1), 0x05040100u); // cycle 16w in the top two bits
-                const uint32_t cx = lane_next(c32);
-                uint32_t nbx = lane_next(nb0);
-                if (last_w) nbx = M;
-                // a window is blocked when any of its 8 cycles is: OR-smear over the next 7 positions of the flag stream nb0 nb1 nbx
-                uint32_t f0, f1;
+                uint32_t S[KS_NH / 2 + 1]; // 2-bit codes of 16 cycles per register, first cycle in the top two bits; then the next lane's
+#pragma unroll
+                for (int j = 0; j < KS_NH / 2; ++j) S[j] = vperm(squeeze2(cn[2 * j]), squeeze2(cn[2 * j + 1]), 0x05040100u);
+                S[KS_NH / 2] = lane_next(S[0]);
+                nb[KS_NH] = lane_next(nb[0]);
+                if (last_w) nb[KS_NH] = M;
+                // a window is blocked when any of its 8 cycles is: OR-smear over the next 7 positions of the flag stream
+                uint32_t f[KS_NH];
                 {
-                    const uint32_t a0 = nb0 | alignbit(nb0, nb1, 28), a1 = nb1 | alignbit(nb1, nbx, 28), ax = nbx | (nbx << 4);
-                    const uint32_t b0 = a0 | alignbit(a0, a1, 24), b1 = a1 | alignbit(a1, ax, 24), bx = ax | (ax << 8);
-                    f0 = ~(b0 | alignbit(b0, b1, 16)); // nibble LSB set <=> the window starting there is counted
-                    f1 = ~(b1 | alignbit(b1, bx, 16));
+                    uint32_t sa[KS_NH + 1], sb[KS_NH + 1];
+#pragma unroll
+                    for (int h = 0; h < KS_NH; ++h) sa[h] = nb[h] | alignbit(nb[h], nb[h + 1], 28);
+                    sa[KS_NH] = nb[KS_NH] | (nb[KS_NH] << 4);
+#pragma unroll
+                    for (int h = 0; h < KS_NH; ++h) sb[h] = sa[h] | alignbit(sa[h], sa[h + 1], 24);
+                    sb[KS_NH] = sa[KS_NH] | (sa[KS_NH] << 8);
+#pragma unroll
+                    for (int h = 0; h < KS_NH; ++h) f[h] = ~(sb[h] | alignbit(sb[h], sb[h + 1], 16)); // nibble LSB set <=> the window starting there is counted
                 }
-                // Branch-free: every lane issues all 16 returning atomics; a blocked window (and every window of a lane without
-                // valid cycles) adds 0.  The address is the LDS byte address itself: KS_T8 = 0 and the dynamic LDS block starts
-                // at 0 (checked at kernel entry), which saves the base addition per window.
-                if (nv) { // all 16 atomics are issued before the first returned value is looked at
-                    uint32_t old[16];
+                // Branch-free inside a batch of 16 windows: every lane with a valid cycle there issues all 16 returning atomics;
+                // a blocked window adds 0.  The address is the LDS byte address itself: KS_T8 = 0 and the dynamic LDS block
+                // starts at 0 (checked at kernel entry), which saves the base addition per window.
 #pragma unroll
-                    for (int kw = 0; kw < 16; ++kw) {
-                        const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw); // window in the low 16 bits
-                        const uint32_t one = bfe(kw < 8 ? f0 : f1, 28 - 4 * (kw & 7), 1);
-                        old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int j = 0; j < KS_NH / 2; ++j) {
+                    if (nv > 16u * j) { // all 16 atomics are issued before the first returned value is looked at
+                        const uint32_t c32 = S[j], cx = S[j + 1];
+                        uint32_t old[16];
+#pragma unroll
+                        for (int kw = 0; kw < 16; ++kw) {
+                            const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw); // window in the low 16 bits
+                            const uint32_t one = bfe(f[2 * j + (kw >> 3)], 28 - 4 * (kw & 7), 1);
+                            old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        uint32_t hot0 = 0, hot1 = 0;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
+                        if (hot0 & 0x80808080u) // some counter of a touched dword is >= 128: look precisely (rare)
+                            t8_check<0>(em, c32, cx, f[2 * j], old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
+                        if (hot1 & 0x80808080u)
+                            t8_check<8>(em, c32, cx, f[2 * j + 1], old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
                     }
-                    uint32_t hot0 = 0, hot1 = 0;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
-                    if (hot0 & 0x80808080u) // some counter of a touched dword is >= 128: look precisely (rare)
-                        t8_check<0>(em, c32, cx, f0, old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
-                    if (hot1 & 0x80808080u)
-                        t8_check<8>(em, c32, cx, f1, old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
                 }
             }
             // ---- triplets in cycle space (single-operation CIGAR: chromPos = pos + i)
             if ((parts & 4u) && __ballot(m0 & KM_TRIP)) {
                 // The reference converts the BAM-orientation char to Dna (anything but A/C/G/T -> A); in the cycle space of a
                 // reverse read that 'A' is the complement's code 3.  (For 8-mers the conversion comes after the reverse complement.)
-                const uint32_t x0 = ~P0.oh & M, x1 = ~P1.oh & M, rcm = rc ? 0x33333333u : 0u;
-                const uint32_t ct0 = cn0 | ((x0 | (x0 << 1)) & rcm), ct1 = cn1 | ((x1 | (x1 << 1)) & rcm);
-                const uint32_t I0 = (E0 & 0xCCCCCCCCu) | ct0, I1 = (E1 & 0xCCCCCCCCu) | ct1; // nibble = [r c]
-                const uint32_t t0 = I0 ^ (I0 >> 2), t1 = I1 ^ (I1 >> 2);
-                const uint32_t bad0 = ((t0 | (t0 >> 1)) & M) | nb0, bad1 = ((t1 | (t1 >> 1)) & M) | nb1; // as a flank: mismatch or N
-                const uint32_t badp = lane_prev(bad1), badn = lane_next(bad0); // (cycle 0 / L-1 are never evaluated)
-                const uint32_t fl0 = alignbit(badp, bad0, 4) | alignbit(bad0, bad1, 28);
-                const uint32_t fl1 = alignbit(bad0, bad1, 4) | alignbit(bad1, badn, 28);
-                // position range [ja, jb) of the read in cycles
-                const uint32_t ja = (uint32_t)min(max((int32_t)(w5 & 0xFFu) - (int32_t)w16, 0), 16);
-                const uint32_t jb = (uint32_t)min(max((int32_t)((w5 >> 8) & 0xFFu) - (int32_t)w16, 0), 16);
-                const uint2 pa = *(const uint2*)(LUT + 8u * ja), pb = *(const uint2*)(LUT + 8u * jb);
-                // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then compressed to nibble LSBs
-                uint32_t qf[4];
+                const uint32_t rcm = rc ? 0x33333333u : 0u;
+                uint32_t I[KS_NH + 2], bad[KS_NH + 2]; // [1 .. KS_NH] = this lane, [0] / [KS_NH + 1] = the last / first dword of its neighbours
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
+                for (int h = 0; h < KS_NH; ++h) {
+                    const uint32_t x = ~P[h].oh & M;
+                    const uint32_t ct = cn[h] | ((x | (x << 1)) & rcm);
+                    I[h + 1] = (E[h] & 0xCCCCCCCCu) | ct; // nibble = [r c]
+                    const uint32_t t = I[h + 1] ^ (I[h + 1] >> 2);
+                    bad[h + 1] = ((t | (t >> 1)) & M) | nb[h]; // as a flank: mismatch or N
+                }
+                bad[0] = lane_prev(bad[KS_NH]); bad[KS_NH + 1] = lane_next(bad[1]); // (cycle 0 / L-1 are never evaluated)
+                I[0] = lane_prev(I[KS_NH]); I[KS_NH + 1] = lane_next(I[1]);          // (cross-lane: outside the divergent branch)
+                // position range [ja, jb) of the read in cycles
+                const uint32_t ja = (uint32_t)min(max((int32_t)(w5 & 0xFFu) - (int32_t)wnb, 0), KS_NB);
+                const uint32_t jb = (uint32_t)min(max((int32_t)((w5 >> 8) & 0xFFu) - (int32_t)wnb, 0), KS_NB);
+                uint32_t pa[KS_NH], pb[KS_NH];
+                lut_nib(pa, LUT + KS_LUTW * ja);
+                lut_nib(pb, LUT + KS_LUTW * jb);
+                // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then compressed to nibble LSBs
+                uint32_t qf[KS_ND];
+#pragma unroll
+                for (int d = 0; d < KS_ND; ++d) {
                     const uint32_t x = Q[d] & 0x7F7F7F7Fu;
-                    const uint32_t f = (x + 0x6C6C6C6Cu) & ~(x + 0x21212121u) & ~Q[d]; // >= 20, not >= 95, not >= 128
-                    uint32_t y = (f >> 3) & 0x10101010u;              // cycle 4d+k: bit 28 - 8k
+                    const uint32_t fq = (x + 0x6C6C6C6Cu) & ~(x + 0x21212121u) & ~Q[d]; // >= 20, not >= 95, not >= 128
+                    uint32_t y = (fq >> 3) & 0x10101010u;             // cycle 4d+k: bit 28 - 8k
                     y = (y | (y << 4)) & 0xFF00FF00u;                  // 28 24 | 12 8
                     qf[d] = y | (y << 8);                              // top half: 28 24 20 16
                 }
-                const uint32_t ok0 = P0.oh & ~fl0 & pb.x & ~pa.x & vperm(qf[0], qf[1], 0x07060302u);
-                const uint32_t ok1 = P1.oh & ~fl1 & pb.y & ~pa.y & vperm(qf[2], qf[3], 0x07060302u);
-                const uint32_t Ip = lane_prev(I1), In = lane_next(I0); // (cross-lane: outside the divergent branch)
-                if (ok0 | ok1) {
+                uint32_t ok[KS_NH], okany = 0;
+#pragma unroll
+                for (int h = 0; h < KS_NH; ++h) {
+                    const uint32_t fl = alignbit(bad[h], bad[h + 1], 4) | alignbit(bad[h + 1], bad[h + 2], 28);
+                    ok[h] = P[h].oh & ~fl & pb[h] & ~pa[h] & vperm(qf[2 * h], qf[2 * h + 1], 0x07060302u);
+                    okany |= ok[h];
+                }
+                if (okany) {
                     uint32_t* tbin = lds + KS_TRIP + ((rc ? 2u : 0u) + ((m0 & 0x40u) ? 0u : 1u)) * 256u; // fwd1st fwd2nd rev1st rev2nd
-                    const uint32_t SA0 = alignbit(Ip, I0, 6), SB0 = alignbit(I0, I1, 22), SA1 = alignbit(I0, I1, 6), SB1 = alignbit(I1, In, 22);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) { // bin = c(j-1) r(j) c(j) r(j+1): 8 contiguous bits of the [r c] stream
-                        const uint32_t i0 = t < 6 ? bfe(SA0, 20 - 4 * t, 8) : bfe(SB0, 12 - 4 * (t - 6), 8);
-                        if (ok0 & (1u << (28 - 4 * t))) atomicAdd(tbin + i0, 1u);
-                    }
+                    for (int h = 0; h < KS_NH; ++h) {
+                        if (!ok[h]) continue;
+                        const uint32_t SA = alignbit(I[h], I[h + 1], 6), SB = alignbit(I[h + 1], I[h + 2], 22);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const uint32_t i1 = t < 6 ? bfe(SA1, 20 - 4 * t, 8) : bfe(SB1, 12 - 4 * (t - 6), 8);
-                        if (ok1 & (1u << (28 - 4 * t))) atomicAdd(tbin + i1, 1u);
+                        for (int t = 0; t < 8; ++t) { // bin = c(j-1) r(j) c(j) r(j+1): 8 contiguous bits of the [r c] stream
+                            const uint32_t ix = t < 6 ? bfe(SA, 20 - 4 * t, 8) : bfe(SB, 12 - 4 * (t - 6), 8);
+                            if (ok[h] & (1u << (28 - 4 * t))) atomicAdd(tbin + ix, 1u);
+                        }
                     }
                 }
             }
@@ -620,16 +704,17 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
 
 
 // Dna5 bytes -> reference table of the fast path: one nibble  r1 r0 ~r0 ~r1  per base (r = Dna5 code & 3, i.e. N -> A like
-// Dna5 -> Dna), 8 bases per dword, first base in the top nibble; bases 0.. start at dword 2 (two zero dwords in front, at
-// least two behind): nd8 + 4 dwords for nd8 = ceil(len / 8).  Bit-reversing a dword yields the reverse complement.
+// Dna5 -> Dna), 8 bases per dword, first base in the top nibble; bases 0.. start at dword BQC_FAST_NH (that many zero dwords in
+// front, at least as many behind): nd8 + 2 * BQC_FAST_NH dwords for nd8 = ceil(len / 8).  Bit-reversing a dword yields the
+// reverse complement.
 __global__ void k_ref_nibbles(const uint8_t* __restrict__ dna5, uint64_t len, uint32_t* __restrict__ out, uint64_t nd8)
 {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= nd8 + 4) return;
+    if (d >= nd8 + 2 * KS_NH) return;
     uint32_t v = 0;
-    if (d >= 2)
+    if (d >= KS_NH)
         for (uint32_t t = 0; t < 8; ++t) {
-            const uint64_t p = (d - 2) * 8 + t;
+            const uint64_t p = (d - KS_NH) * 8 + t;
             if (p < len) {
                 const uint32_t r = dna5[p] & 3u;
                 v |= ((r << 2) | ((~r & 1u) << 1) | ((~r >> 1) & 1u)) << (28u - 4u * t);
@@ -640,7 +725,7 @@ __global__ void k_ref_nibbles(const uint8_t* __restrict__ dna5, uint64_t len, ui
 
 extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t nd8, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((nd8 + 4 + 255) / 256)), dim3(256), 0, s, dna5, len, out, nd8);
+    hipLaunchKernelGGL(k_ref_nibbles, dim3((uint32_t)((nd8 + 2 * KS_NH + 255) / 256)), dim3(256), 0, s, dna5, len, out, nd8);
 }
 
 // BQC_SHORT_PARTS: ablation switch for profiling (1 cycles + per-read sums, 2 8-mers, 4 triplets, 8 per-read statistics;
