@@ -252,7 +252,7 @@ __device__ __forceinline__ void cyc_add(CycAcc& A, const Planes (&P)[KS_NH], con
 #pragma unroll
     for (int h = 0; h < KS_NH; ++h) { A.l1[h][0] += P[h].a; A.l1[h][1] += P[h].c; A.l1[h][2] += P[h].g; A.l1[h][3] += P[h].t; }
 #pragma unroll
-    for (int d = 0; d < KS_ND; ++d) { A.qe[d] += Q[d] & 0x00FF00FFu; A.qo[d] += (Q[d] >> 8) & 0x00FF00FFu; }
+    for (int d = 0; d < KS_ND; ++d) { A.qe[d] += Q[d] & 0x00FF00FFu; A.qo[d] += __builtin_amdgcn_perm(0u, Q[d], 0x0C030C01u); } // (Q >> 8) & 0x00FF00FF
 }
 
 // explicit global-address-space loads (generic/flat loads would count on lgkmcnt and make every LDS wait also wait for
@@ -648,21 +648,21 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 uint32_t pa[KS_NH], pb[KS_NH];
                 lut_nib(pa, LUT + KS_LUTW * ja);
                 lut_nib(pb, LUT + KS_LUTW * jb);
-                // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then compressed to nibble LSBs
+                // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then moved next to each other in pairs:
+                // bytes 3 and 1 of qf[d] hold the flags of cycles 4d, 4d+1 and 4d+2, 4d+3 at their bits 7 and 3
                 uint32_t qf[KS_ND];
 #pragma unroll
                 for (int d = 0; d < KS_ND; ++d) {
                     const uint32_t x = Q[d] & 0x7F7F7F7Fu;
                     const uint32_t fq = (x + 0x6C6C6C6Cu) & ~(x + 0x21212121u) & ~Q[d]; // >= 20, not >= 95, not >= 128
-                    uint32_t y = (fq >> 3) & 0x10101010u;             // cycle 4d+k: bit 28 - 8k
-                    y = (y | (y << 4)) & 0xFF00FF00u;                  // 28 24 | 12 8
-                    qf[d] = y | (y << 8);                              // top half: 28 24 20 16
+                    const uint32_t y = fq & 0x80808080u;
+                    qf[d] = y | (y << 4);
                 }
                 uint32_t ok[KS_NH], okany = 0;
 #pragma unroll
                 for (int h = 0; h < KS_NH; ++h) {
                     const uint32_t fl = alignbit(bad[h], bad[h + 1], 4) | alignbit(bad[h + 1], bad[h + 2], 28);
-                    ok[h] = P[h].oh & ~fl & pb[h] & ~pa[h] & vperm(qf[2 * h], qf[2 * h + 1], 0x07060302u);
+                    ok[h] = P[h].oh & ~fl & pb[h] & ~pa[h] & (vperm(qf[2 * h], qf[2 * h + 1], 0x07050301u) >> 3); // nibble MSB -> LSB
                     okany |= ok[h];
                 }
                 if (okany) {
