@@ -61,6 +61,8 @@ _SIGNATURES = {
     "bqc_fasta_free": (None, [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_abi.u8p), _abi.u64p]),
     "bqc_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "bqc_calib_read4": (C.c_int, [C.c_uint64, C.c_int]),
+    "bqc_inflate_raw": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
+    "bqc_crc32": (C.c_uint32, [C.c_char_p, C.c_uint64]),
 }
 
 _LIB = None

@@ -46,6 +46,9 @@ bool BamReader::fill(size_t need, std::string& err)
             if (!e.empty()) { err = e; return false; }
             continue;
         }
+        if (buf_.capacity() < buf_.size() + chunk_.size()) { // grow rarely and far: reallocation copies the whole batch read so far
+            try { buf_.reserve(std::max<size_t>(768u << 20, 2 * (buf_.size() + chunk_.size()))); } catch (const std::bad_alloc&) {}
+        }
         buf_.insert(buf_.end(), chunk_.begin(), chunk_.end());
         t_copy_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
     }

@@ -12,6 +12,7 @@
 
 #include "../../include/bamqc.h"
 #include "bgzf.h"
+#include "raw_vector.h"
 
 struct BamHeader {
     std::string text;
@@ -22,15 +23,6 @@ struct BamHeader {
     std::map<std::string, unsigned> lane_names; // @RG ID -> lane index, iterated lexicographically at output
     unsigned lane_count = 0;                    // laneNames.size() after the header (bamqualcheck.cpp:297)
 };
-
-// std::vector::resize without the zero fill (the decoder overwrites every element it creates)
-template <typename T>
-struct no_init_alloc : std::allocator<T> {
-    template <typename U> struct rebind { using other = no_init_alloc<U>; };
-    template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
-    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
-};
-template <typename T> using raw_vector = std::vector<T, no_init_alloc<T>>;
 
 struct HostBatch { // owning storage behind a bqc_batch
     raw_vector<uint16_t> flag, n_cigar;
@@ -74,7 +66,7 @@ private:
     bool fill(size_t need, std::string& err); // ensure `need` bytes are available at cur_
     BgzfReader bg_;
     BamHeader hdr_;
-    std::vector<uint8_t> buf_, chunk_;
+    raw_vector<uint8_t> buf_, chunk_;
     size_t cur_ = 0;
     bool eof_ = false;
     std::vector<uint8_t> main_, keep_;

@@ -1,5 +1,7 @@
 // bgzf.cpp — see bgzf.h
 #include "bgzf.h"
+#include "crc32_fast.h"
+#include "inflate_fast.h"
 #include "parallel.h"
 
 #include <zlib.h>
@@ -44,6 +46,10 @@ void BgzfReader::read_ahead()
 {
     for (;;) {
         Item it;
+        { // reuse a buffer the consumer has handed back: no fresh pages to fault in for every run
+            std::lock_guard<std::mutex> lk(m_);
+            if (!spare_.empty()) { it.data.swap(spare_.back()); spare_.pop_back(); }
+        }
         it.ok = next_chunk_sync(it.data, it.err);
         const bool last = !it.ok;
         std::unique_lock<std::mutex> lk(m_);
@@ -56,7 +62,7 @@ void BgzfReader::read_ahead()
     }
 }
 
-bool BgzfReader::next_chunk(std::vector<uint8_t>& out, std::string& err)
+bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
 {
     if (!ra_started_) { ra_started_ = true; ra_ = std::thread([this] { read_ahead(); }); }
     std::unique_lock<std::mutex> lk(m_);
@@ -67,6 +73,10 @@ bool BgzfReader::next_chunk(std::vector<uint8_t>& out, std::string& err)
     cv_.notify_all();
     lk.unlock();
     out.swap(it.data);
+    if (it.data.capacity()) { // the caller's previous buffer goes back to the read-ahead thread
+        std::lock_guard<std::mutex> lk2(m_);
+        if (spare_.size() < 4) spare_.emplace_back(std::move(it.data));
+    }
     if (!it.ok) { err = it.err; out.clear(); return false; }
     return true;
 }
@@ -80,11 +90,11 @@ bool BgzfReader::open(const char* path, std::string& err, unsigned threads)
     return true;
 }
 
-bool BgzfReader::next_chunk_sync(std::vector<uint8_t>& out, std::string& err)
+bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
 {
     out.clear();
     if (eof_) return false;
-    const size_t want = (size_t)threads_ * 16 * kMaxBlock; // compressed bytes per round
+    const size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
     // keep the tail of the previous round (a partial block) at the front of raw_
     size_t have = raw_.size();
     raw_.resize(have + want);
@@ -120,19 +130,12 @@ bool BgzfReader::next_chunk_sync(std::vector<uint8_t>& out, std::string& err)
     parallel_for(blocks.size(), threads_, [&](size_t i) {
         const BlockRef& b = blocks[i];
         if (b.usize == 0) return;
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
-        zs.next_in = raw_.data() + b.off; zs.avail_in = (uInt)b.csize;
-        zs.next_out = out.data() + b.uoff; zs.avail_out = (uInt)b.usize;
-        const int rc = inflate(&zs, Z_FINISH);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) bad = true;
-        else {
-            const uint8_t* t = raw_.data() + b.off + b.csize;
-            const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-            if (crc32(crc32(0L, Z_NULL, 0), out.data() + b.uoff, (uInt)b.usize) != crc) bad = true;
-        }
-        inflateEnd(&zs);
+        static thread_local Inflater inf;
+        // (the 8 bytes after the deflate data, which the decoder may load but not use, are the block's CRC32 / ISIZE)
+        if (!inf.run(raw_.data() + b.off, b.csize, out.data() + b.uoff, b.usize)) { bad = true; return; }
+        const uint8_t* t = raw_.data() + b.off + b.csize;
+        const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (bqc_crc32_fast(out.data() + b.uoff, b.usize) != crc) bad = true;
     });
     if (bad) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
     raw_.erase(raw_.begin(), raw_.begin() + p);

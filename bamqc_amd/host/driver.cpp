@@ -19,6 +19,8 @@
 
 #include "../../include/bamqc_host.h"
 #include "bam_io.h"
+#include "crc32_fast.h"
+#include "inflate_fast.h"
 #include "host_tools.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -120,6 +122,12 @@ extern "C" int bqc_bam_open(const char* path, bqc_bam** out)
     *out = b;
     return 0;
 }
+extern "C" int bqc_inflate_raw(const uint8_t* in, uint64_t in_n, uint8_t* out, uint64_t out_n)
+{
+    static thread_local Inflater inf;
+    return inf.run(in, (size_t)in_n, out, (size_t)out_n) ? 1 : 0;
+}
+extern "C" uint32_t bqc_crc32(const uint8_t* p, uint64_t n) { return bqc_crc32_fast(p, (size_t)n); }
 extern "C" void bqc_bam_close(bqc_bam* b) { delete b; }
 extern "C" const char* bqc_bam_error(const bqc_bam* b) { return b ? b->err.c_str() : ""; }
 extern "C" uint32_t bqc_bam_n_refs(const bqc_bam* b) { return (uint32_t)b->hdr().ref_names.size(); }

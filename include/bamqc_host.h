@@ -61,6 +61,13 @@ int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, const bqc_b
 int bqc_fasta_load(const char* path, uint32_t* n_records, char*** names, uint8_t*** codes, uint64_t** lens);
 void bqc_fasta_free(uint32_t n_records, char** names, uint8_t** codes, uint64_t* lens);
 
+/* The BGZF reader's DEFLATE decoder on one raw deflate stream (host/inflate_fast.h; exposed for its tests): 1 when the
+ * stream is valid, ends within in_n bytes and yields exactly out_n bytes, else 0.  The 8 bytes after in + in_n must be
+ * readable (in a BGZF block: the CRC32 / ISIZE trailer). */
+int bqc_inflate_raw(const uint8_t* in, uint64_t in_n, uint8_t* out, uint64_t out_n);
+/* The reader's CRC-32 (gzip polynomial; host/crc32_fast.h), as zlib's crc32(0, p, n). */
+uint32_t bqc_crc32(const uint8_t* p, uint64_t n);
+
 /* Profiling aid: stream `bytes` of device memory `repeat` times with 4-byte-per-lane loads (kernel k_calib_read4),
  * used to calibrate the rocprofv3 FETCH_SIZE counter on a known byte count. */
 int bqc_calib_read4(uint64_t bytes, int repeat);
