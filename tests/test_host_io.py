@@ -71,6 +71,31 @@ def test_truncated_bam_is_an_error(synth_files, tmp_path):
         list(hostio.BamFile(bad).batches())
 
 
+def test_damaged_blocks_are_errors_not_crashes(synth_files, tmp_path):
+    """Bit flips in the deflate data, the CRC32 or the ISIZE of a BGZF block: the reader reports an error (its own inflate
+    rejects the stream, or the block checksum does), whatever the damage; an undamaged copy still reads."""
+    import random
+    bam, _ = synth_files
+    data = bytearray(open(bam, "rb").read())
+    rng = random.Random(11)
+    bsize = struct.unpack_from("<H", data, 16)[0] + 1          # first block
+    spots = [18 + rng.randrange(bsize - 26) for _ in range(12)] + [bsize - 8, bsize - 5, bsize - 4, bsize - 1]
+    n_err = 0
+    for k, pos in enumerate(spots):
+        bad = bytearray(data)
+        bad[pos] ^= 1 << rng.randrange(8)
+        p = str(tmp_path / ("bad%d.bam" % k))
+        open(p, "wb").write(bad)
+        try:
+            list(hostio.BamFile(p).batches())
+        except IOError:
+            n_err += 1
+    assert n_err == len(spots)
+    ok = str(tmp_path / "ok.bam")
+    open(ok, "wb").write(data)
+    assert sum(len(b["flag"]) for b in hostio.BamFile(ok).batches()) > 0
+
+
 def test_not_a_bam(tmp_path):
     p = str(tmp_path / "x.bam")
     open(p, "wb").write(b"hello world, definitely not gzip")
