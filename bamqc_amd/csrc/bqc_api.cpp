@@ -28,12 +28,12 @@ void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
-void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t t8_lane, hipStream_t);
+void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t);
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
 uint32_t bqc_short_parts();
-void bqc_launch_t8_reduce(uint32_t* t8rows, uint32_t n_rows, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
+void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
 }
 
 static thread_local char g_create_err[512];
@@ -75,9 +75,13 @@ struct bqc_ctx {
     uint32_t n_cu = 256;
     uint64_t* d_state = nullptr;
     uint32_t* d_err = nullptr;
-    uint32_t* d_t8rows = nullptr; // [n_cu][65536] per-workgroup 8-mer rows of k_short: counts of read group t8_rows_lane that are
-                                  // not yet in d_state (folded in by fold_t8 before the state is read, or another group needs the rows)
-    bool t8_dirty = false;
+    // 8-mer scratch rows of k_short: every workgroup of a launch owns a slot of BQC_T8_SPW rows (64 KiB images of its packed LDS
+    // counters, written with plain stores); d_t8used[slot] = rows written.  The slots of up to kT8Launches launches pile up
+    // and are summed into d_state by fold_t8: before the state is read, when the table is full, or when another read group
+    // needs it.  (kT8Slots * BQC_T8_SPW * 64 KiB = 512 MiB of the 288 GB.)
+    uint32_t* d_t8rows = nullptr;
+    uint32_t* d_t8used = nullptr;
+    uint32_t t8_slots_used = 0, t8_slots_cap = 0;
     uint32_t t8_rows_lane = 0;
     std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
@@ -191,8 +195,9 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(bqc_short_init());
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err, 64));
-    CCHK(hipMalloc(&c->d_t8rows, (size_t)c->n_cu * 65536 * 4));
-    CCHK(hipMemsetAsync(c->d_t8rows, 0, (size_t)c->n_cu * 65536 * 4, c->stream));
+    c->t8_slots_cap = std::max(1024u, 4u * c->n_cu);
+    CCHK(hipMalloc(&c->d_t8rows, (size_t)c->t8_slots_cap * BQC_T8_SPW * 65536));
+    CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * 4));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
     CCHK(hipMalloc(&c->d_parity, (size_t)opt->n_lanes * 4));
     CCHK(hipMalloc(&c->d_started, opt->n_lanes));
@@ -232,7 +237,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
     for (auto& pb : c->pool) (void)hipFree(pb.first);
-    (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
+    (void)hipFree(c->d_state); (void)hipFree(c->d_err); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_t8used); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
     (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -773,9 +778,9 @@ static void tick(bqc_ctx* c, const char* name)
 
 static void fold_t8(bqc_ctx* c)
 {
-    if (!c->t8_dirty) return;
-    bqc_launch_t8_reduce(c->d_t8rows, c->n_cu, c->sl, c->d_state, c->t8_rows_lane, c->stream);
-    c->t8_dirty = false;
+    if (!c->t8_slots_used) return;
+    bqc_launch_t8_fold(c->d_t8rows, c->d_t8used, c->t8_slots_used, c->sl, c->d_state, c->t8_rows_lane, c->stream);
+    c->t8_slots_used = 0;
 }
 
 extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
@@ -800,9 +805,11 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
             bqc_launch_reads_chunks(fr, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->stream);
             tick(c, "k_reads");
         }
-        if (c->t8_rows_lane != db->t8_lane) { fold_t8(c); c->t8_rows_lane = db->t8_lane; }
-        bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, c->n_cu, c->d_t8rows, db->t8_lane, c->stream);
-        c->t8_dirty = true;
+        const uint32_t grid = std::min(c->n_cu, db->d.n_chunks_fast); // one workgroup per CU; every workgroup owns a slot of scratch rows
+        if (c->t8_rows_lane != db->t8_lane || c->t8_slots_used + grid > c->t8_slots_cap) { fold_t8(c); c->t8_rows_lane = db->t8_lane; }
+        bqc_launch_short(db->d, c->sl, c->d_state, refs, c->d_err, grid, c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u,
+                         c->d_t8used + c->t8_slots_used, db->t8_lane, c->stream);
+        c->t8_slots_used += grid;
         tick(c, "k_short");
     }
     if (slow.n_chunks) {
@@ -847,7 +854,7 @@ extern "C" int bqc_reset(bqc_ctx* c)
 {
     if (!c) return BQC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    fold_t8(c); // (leaves the scratch rows zero)
+    fold_t8(c);
     HIPCHK(c, hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_carry, 0, (size_t)c->opt.n_lanes * 2 * 2000 * 4, c->stream));

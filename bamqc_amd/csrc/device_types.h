@@ -13,6 +13,7 @@
 #define BQC_CHUNK_BASES 262144   // base budget per generic chunk (load balance only; a chunk always holds at least one read)
 #define BQC_FAST_WAVES 16        // waves per workgroup of k_short = tiles per fast chunk (host chunk layout and kernel must agree)
 #define BQC_FAST_NH 2            // 8-cycle halves a lane of k_short owns (2: 16 cycles, 4: 32 cycles); also the pad dwords of the nibble tables
+#define BQC_T8_SPW 8             // rows (64 KiB images of the packed 8-mer counters) a workgroup of k_short can write per launch
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)

@@ -133,31 +133,33 @@ __device__ __noinline__ void t8_check(uint64_t* __restrict__ em, uint32_t c32, u
     }
 }
 
-// The packed 8-mer counters of this workgroup go to its own row of a global scratch table (plain read-modify-write of 16 B
-// per thread, no atomics; k_t8_reduce folds the rows into the state vector), or with global atomics when the read group is
-// not the one the scratch table is collecting in this launch.  Called workgroup-uniformly between barriers.
-__device__ __forceinline__ void t8_flush(uint32_t* lds, uint64_t* __restrict__ em, uint4* __restrict__ row /* nullptr: atomics */)
+// The packed 8-mer counters of this workgroup are emptied into the next free row of its slot of a global scratch table: plain
+// 16-byte stores of the LDS image, nothing to wait for (k_t8_fold unpacks and sums the rows into the state vector later);
+// or with global atomics when the read group is not the one the scratch table is collecting in this launch, or the slot is
+// full.  Called workgroup-uniformly between barriers; returns true when a row was written.
+__device__ __forceinline__ bool t8_flush(uint32_t* lds, uint64_t* __restrict__ em, uint4* __restrict__ slot /* nullptr: atomics */, uint32_t n_rows_used)
 {
+    if (slot && n_rows_used < BQC_T8_SPW) {
+        uint4* row = slot + (size_t)n_rows_used * 4096u;
+        uint4* src = (uint4*)(lds + KS_T8);
+        for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) { row[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
+        return true;
+    }
     for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) {
         const uint32_t v = lds[KS_T8 + i];
         if (!v) continue;
         lds[KS_T8 + i] = 0;
-        if (row) { // row[i] = counts of the dword's bytes 0..3, i.e. of bins 4i + (0, 3, 2, 1)
-            uint4 x = row[i];
-            x.x += v & 0xFFu; x.y += (v >> 8) & 0xFFu; x.z += (v >> 16) & 0xFFu; x.w += v >> 24;
-            row[i] = x;
-        } else {
 #pragma unroll
-            for (uint32_t b = 0; b < 4; ++b)
-                if ((v >> (8u * b)) & 0xFFu) gadd(em + 4u * i + ((4u - b) & 3u), (v >> (8u * b)) & 0xFFu);
-        }
+        for (uint32_t b = 0; b < 4; ++b)
+            if ((v >> (8u * b)) & 0xFFu) gadd(em + 4u * i + ((4u - b) & 3u), (v >> (8u * b)) & 0xFFu);
     }
+    return false;
 }
 
-__device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint4* __restrict__ row)
+__device__ __forceinline__ bool ks_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint4* __restrict__ slot, uint32_t n_rows_used)
 {
     const uint64_t lb = sl.lane_base(lane);
-    t8_flush(lds, state + lb + sl.o_eightmer, row);
+    const bool wrote_row = t8_flush(lds, state + lb + sl.o_eightmer, slot, n_rows_used);
     for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) { // bin = c(j-1) r(j) c(j) r(j+1) of group i >> 8, in cycle space
         const uint32_t v = lds[KS_TRIP + i];
         if (!v) continue;
@@ -194,6 +196,7 @@ __device__ __forceinline__ void ks_flush(uint32_t* lds, const StateLayout& sl, u
         if (v) gadd(state + mb + sl.m_avgceil + (i & 255), v);
         lds[KS_AC + i] = 0;
     }
+    return wrote_row;
 }
 
 // Per-cycle accumulators of one lane (its KS_NB cycles), for the reads of ONE mate.
@@ -335,11 +338,11 @@ __device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, cons
 
 __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
                                                          uint32_t* __restrict__ err, uint32_t parts, uint4* __restrict__ t8rows,
-                                                         uint32_t t8_lane, uint32_t t8_period)
+                                                         uint32_t* __restrict__ t8_used, uint32_t t8_lane, uint32_t t8_period)
 {
     extern __shared__ uint32_t lds[];
     if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KS_T8 at LDS address 0)
-        if (threadIdx.x == 0) atomicOr(err, BQC_DEVERR_INTERNAL);
+        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[blockIdx.x] = 0; }
         return;
     }
     for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     const uint32_t mate = slot < (rpw + 1u) / 2u ? 0u : 1u;
     uint32_t n1 = 0, n2 = 0; // groups since the last counter spill / quality flush (wave-uniform)
     uint32_t cur_lane = 0xFFFFFFFFu, since_t8 = 0;
+    uint4* const t8_slot = t8rows + (size_t)blockIdx.x * BQC_T8_SPW * 4096u; // this workgroup's rows of the scratch table
+    uint32_t t8_n = 0;                                                          // rows written so far
 
     const uint8_t* g_seq = b.seq - KS_BIAS;
     const uint8_t* g_qual = b.qual - KS_BIAS;
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 if (lane_used) { cyc_spill(A, lds, mate, w); cyc_qflush(A, lds, mate, w); }
                 n1 = n2 = 0;
                 block_sync();
-                ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
+                t8_n += ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8_slot : nullptr, t8_n) ? 1u : 0u;
                 rs_flush(lds + KS_RS, sl, state, cur_lane);
             }
             cur_lane = ch.lane;
@@ -398,10 +403,25 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         }
         if (done) break;
         if (++since_t8 > t8_period) { // keep the packed u8 counters small, so that the wrap check below stays on its fast path
+            // No barrier: every wave empties ITS sixteenth of the table with atomic exchanges, whenever it gets here; increments
+            // the other waves are still making for earlier chunks simply land in a later row.  All waves walk the same chunk
+            // sequence, so they agree on the row index.
             since_t8 = 1;
-            block_sync();
-            t8_flush(lds, state + sl.lane_base(cur_lane) + sl.o_eightmer, cur_lane == t8_lane ? t8rows + (size_t)blockIdx.x * 16384u : nullptr);
-            block_sync();
+            const bool to_row = cur_lane == t8_lane && t8_n < BQC_T8_SPW;
+            uint32_t* row = (uint32_t*)(t8_slot + (size_t)t8_n * 4096u);
+            uint64_t* emf = state + sl.lane_base(cur_lane) + sl.o_eightmer;
+#pragma unroll 4
+            for (uint32_t k = 0; k < 16384u / (KS_WAVES * 64u); ++k) {
+                const uint32_t i = (wave * (16384u / (KS_WAVES * 64u)) + k) * 64u + ln;
+                const uint32_t v = atomicExch(&lds[KS_T8 + i], 0u);
+                if (to_row) row[i] = v;
+                else if (v) {
+#pragma unroll
+                    for (uint32_t b8 = 0; b8 < 4; ++b8)
+                        if ((v >> (8u * b8)) & 0xFFu) gadd(emf + 4u * i + ((4u - b8) & 3u), (v >> (8u * b8)) & 0xFFu);
+                }
+            }
+            t8_n += to_row ? 1u : 0u;
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
@@ -700,6 +720,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         __builtin_amdgcn_wave_barrier();
         } // tiles
     }
+    if (threadIdx.x == 0) t8_used[blockIdx.x] = t8_n; // rows of this workgroup's slot that k_t8_fold has to read
 }
 
 
@@ -742,16 +763,21 @@ extern "C" hipError_t bqc_short_init()
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_short), hipFuncAttributeMaxDynamicSharedMemorySize, KS_WORDS * 4);
 }
 
-// Fold the per-workgroup 8-mer rows into the state vector and clear them: thread per LDS dword (4 bins) and slice of 16 rows.
-__global__ __launch_bounds__(256) void k_t8_reduce(uint4* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ em)
+// Sum the packed rows the workgroups of one or more k_short launches have written (slot s: rows s * BQC_T8_SPW .. + used[s]) into
+// the 8-mer counters of the state vector: thread per LDS dword (4 bins) and slice of 32 slots.  Rows are read once and not
+// written: the next launches overwrite them.
+__global__ __launch_bounds__(256) void k_t8_fold(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ used, uint32_t n_slots,
+                                                    uint64_t* __restrict__ em)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // < 16384
-    uint64_t A = 0, B = 0, C = 0, D = 0;
-    const uint32_t r0 = blockIdx.y * 16u, r1 = min(n_rows, r0 + 16u);
-    for (uint32_t r = r0; r < r1; ++r) {
-        const uint4 x = rows[(size_t)r * 16384u + i];
-        if (x.x | x.y | x.z | x.w) rows[(size_t)r * 16384u + i] = make_uint4(0, 0, 0, 0);
-        A += x.x; B += x.y; C += x.z; D += x.w;
+    uint32_t A = 0, B = 0, C = 0, D = 0; // bytes 0..3 of the dword = bins 4i + (0, 3, 2, 1); at most 32 * BQC_T8_SPW * 255 each
+    const uint32_t s0 = blockIdx.y * 32u, s1 = min(n_slots, s0 + 32u);
+    for (uint32_t sidx = s0; sidx < s1; ++sidx) {
+        const uint32_t n = min(used[sidx], (uint32_t)BQC_T8_SPW);
+        for (uint32_t f = 0; f < n; ++f) {
+            const uint32_t v = rows[((size_t)sidx * BQC_T8_SPW + f) * 16384u + i];
+            A += v & 0xFFu; B += (v >> 8) & 0xFFu; C += (v >> 16) & 0xFFu; D += v >> 24;
+        }
     }
     if (A) gadd(em + 4u * i + 0u, A);
     if (B) gadd(em + 4u * i + 3u, B);
@@ -760,17 +786,24 @@ __global__ __launch_bounds__(256) void k_t8_reduce(uint4* __restrict__ rows, uin
 }
 
 extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                 uint32_t grid, uint32_t* t8rows, uint32_t t8_lane, hipStream_t s)
+                                 uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t s)
 {
-    if (b.n_chunks_fast == 0) return;
-    if (grid > b.n_chunks_fast) grid = b.n_chunks_fast;
-    static uint32_t period = 0;
-    if (!period) { const char* e = getenv("BQC_T8_PERIOD"); period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : KS_T8_PERIOD; } // tuning knob
-    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_lane, period);
+    if (b.n_chunks_fast == 0 || grid == 0) return;
+    static uint32_t env_period = 0xFFFFFFFFu;
+    if (env_period == 0xFFFFFFFFu) { const char* e = getenv("BQC_T8_PERIOD"); env_period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0u; } // tuning knob
+    // chunks between two flushes of the packed 8-mer counters: as small as the rows of a workgroup's slot allow (the last row
+    // is for the final flush; beyond the slot the kernel falls back to global atomics)
+    const uint32_t cpw = (b.n_chunks_fast + grid - 1) / grid;
+    uint32_t period = env_period ? env_period : KS_T8_PERIOD;
+    period = std::max(period, (cpw + BQC_T8_SPW - 2) / (BQC_T8_SPW - 1));
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_used, t8_lane,
+                       period);
 }
 
-// fold the scratch rows into the 8-mer counters of `lane` (the rows are zero afterwards)
-extern "C" void bqc_launch_t8_reduce(uint32_t* t8rows, uint32_t n_rows, const StateLayout& sl, uint64_t* state, uint32_t lane, hipStream_t s)
+// sum the rows of `n_slots` workgroup slots into the 8-mer counters of `lane`
+extern "C" void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout& sl, uint64_t* state, uint32_t lane,
+                                   hipStream_t s)
 {
-    hipLaunchKernelGGL(k_t8_reduce, dim3(64, (n_rows + 15) / 16), dim3(256), 0, s, (uint4*)t8rows, n_rows, state + sl.lane_base(lane) + sl.o_eightmer);
+    if (!n_slots) return;
+    hipLaunchKernelGGL(k_t8_fold, dim3(64, (n_slots + 31) / 32), dim3(256), 0, s, t8rows, t8_used, n_slots, state + sl.lane_base(lane) + sl.o_eightmer);
 }
