@@ -389,7 +389,7 @@ static void countBasesInTriplets(tripletcounts* counts, const rec* r, const uint
         int base = dna5_of_char(r->seq[readPos]);
         if (base == 4 || r->seq[readPos - 1] == 'N' || r->seq[readPos + 1] == 'N') continue;
         /* DEFINED: context outside the chromosome is skipped (infix() reads out of bounds). */
-        if (chromPos < 1 || chromPos + 1 >= chromLen) continue;
+        if (chromPos < 1 || chromLen < 2 || chromPos > chromLen - 2) continue; /* (no chromPos + 1: it wraps for beginPos <= -2) */
         int c0 = chrom[chromPos - 1] & 3, c1 = chrom[chromPos] & 3, c2 = chrom[chromPos + 1] & 3; /* Dna5->Dna: N->A */
         if (dna_of_char(r->seq[readPos - 1]) != c0) continue; /* char compared as Dna */
         if (dna_of_char(r->seq[readPos + 1]) != c2) continue;

@@ -132,6 +132,19 @@ def test_triplet_kat_and_index_pin():
     assert [PINS["triplet_seq"].index(x) for x in ("ACG", "CGT", "GTA", "TAC")] == [6, 27, 44, 49]
 
 
+def test_triplet_read_starting_before_the_contig():
+    # DEFINED (the reference's size_t chromPos wraps and infix() reads out of bounds): contexts that are not completely
+    # inside the contig are skipped, also for beginPos <= -2.  Read = 3 arbitrary bases + reference[0:9], beginPos = -3:
+    # read position i sits on contig position i - 3, so positions 4 .. 10 have their context inside.
+    ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
+    for pos, lead, n in ((-3, "TTT", 7), (-2, "TT", 7), (-1, "T", 7)):
+        seq = lead + "ACGTACGTA"
+        cols = synth.single_read(seq, [40] * len(seq), [(len(seq), "M")], F_PAIRED | F_PROPER | F_FIRST | MATE_MAIN,
+                                 pos=pos, mapq=60, as_=100)
+        rc, c = run(cols, refs=[ref])
+        assert rc == 0 and int(c["triplet"].sum()) == n, (pos, int(c["triplet"].sum()))
+
+
 def test_triplet_filters():
     ref = np.array([0, 1, 2, 3] * 50, dtype=np.uint8)
     base = dict(pos=0, mapq=60, as_=100)
