@@ -107,3 +107,10 @@ def test_wild_records(seed):
 def test_wild_records_in_small_batches_and_short_only():
     cols, refs = wild_batch(7, 3000, max_len=255)
     assert_parity(split(cols, [1, 2, 700, 701, 1500, 2999]), refs, n_lanes=3, max_read_len=1024, isize=2000)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_wild_records_with_the_kmer_sketch(seed):
+    # the sketch walks every read that passes the flag filter, whatever its CIGAR / position says; qualities around the cutoffs
+    cols, refs = wild_batch(300 + seed, 2000)
+    assert_parity(split(cols, [700]), refs, n_lanes=3, max_read_len=1024, isize=2000, klist=[5, 32], qlist=[17])
