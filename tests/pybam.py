@@ -99,3 +99,36 @@ def read_fasta(path):
     if name is not None:
         out.append((name, "".join(seq)))
     return out
+
+
+def _bgzf_block(payload, level=6):
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = c.compress(payload) + c.flush()
+    bsize = 18 + len(comp) + 8
+    assert bsize <= 65536
+    return (bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", bsize - 1) + comp +
+            struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def write_bam(path, header_text, refs, records, block=40000, rng=None):
+    """Independent BAM writer for tests.  records: dicts with rid pos mapq flag rnext pnext tlen name (str), cigar (uint32
+    words), seq (packed nibbles), qual (bytes), l_seq, tags (bytes, already encoded).  BGZF blocks are cut at arbitrary
+    byte offsets (records straddle them), with varying block sizes when `rng` is given."""
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs)))
+    for name, ln in refs:
+        out += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    for r in records:
+        name = r["name"].encode() + b"\0"
+        cig = np.asarray(r["cigar"], dtype="<u4").tobytes()
+        body = struct.pack("<iiBBHHHiiii", r["rid"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]), r["flag"], r["l_seq"],
+                           r["rnext"], r.get("pnext", -1), r["tlen"])
+        body += name + cig + bytes(r["seq"]) + bytes(r["qual"]) + r["tags"]
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        p = 0
+        while p < len(out):
+            n = block if rng is None else int(rng.integers(1, block + 1))
+            f.write(_bgzf_block(bytes(out[p:p + n]), level=6 if rng is None else int(rng.integers(0, 10))))
+            p += n
+        f.write(_bgzf_block(b""))

@@ -71,3 +71,23 @@ def test_sam_from_stdin_matches_the_bam_run(tmp_path):
     q = subprocess.run([EXE, "-r", fa, "-o", out_s, "-c", "chr1,chr2", "-"], input=sam, capture_output=True)
     assert q.returncode == 0, q.stderr
     assert filecmp.cmp(out_b, out_s, shallow=False)
+
+
+def test_wild_bam_end_to_end(tmp_path):
+    """Records no aligner would write (tests/test_gpu_fuzz.py), as a BAM with junk tags and oddly cut BGZF blocks, through the
+    program: the `.bamqc` text equals the oracle's byte for byte."""
+    import numpy as np
+    from tests.test_host_io import _wild_bam
+    from tests.test_gpu_fuzz import wild_batch
+    bam, fa = str(tmp_path / "w.bam"), str(tmp_path / "w.fa")
+    _wild_bam(bam, 33, 4000)
+    _, refs = wild_batch(33, 1)  # (the contigs depend on the seed only)
+    with open(fa, "w") as f:
+        for i, r in enumerate(refs):
+            s = "".join("ACGTN"[c] for c in r)
+            f.write(">chr%d some description\n" % (i + 1) + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n")
+    got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
+    r = run_cli("-r", fa, "-o", got, "-i", "2000", "--batch-reads", "1500", "-k", "8,32", "-q", "17", bam)
+    assert r.returncode == 0, r.stderr
+    assert oracle_bamqualcheck(bam, fa, want, isize=2000, klist=(8, 32), qlist=(17,), batch_reads=999) == 0
+    assert filecmp.cmp(got, want, shallow=False)

@@ -177,3 +177,78 @@ def test_sam_text_decodes_to_the_same_batches(synth_files, tmp_path):
     assert set(gb) == set(gs)
     for k in gb:
         assert np.array_equal(gb[k], gs[k]), k
+
+
+def _wild_bam(path, seed, n_reads):
+    """Wild records (tests/test_gpu_fuzz.py) as a BAM with every tag type around the three tags the decoder looks for."""
+    from tests.test_gpu_fuzz import wild_batch
+    from tests import pybam
+    rng = np.random.default_rng(seed)
+    cols, refs = wild_batch(seed, n_reads)
+    n_refs = len(refs)
+    rg = ["lane%d" % i for i in range(3)]
+    text = "@HD\tVN:1.6\n" + "".join("@SQ\tSN:chr%d\tLN:%d\n" % (i + 1, len(r)) for i, r in enumerate(refs))
+    text += "".join("@RG\tID:%s\tSM:S\n" % x for x in rg)
+
+    def int_tag(key, v):
+        fits = [t for t, lo, hi in (("c", -128, 127), ("C", 0, 255), ("s", -32768, 32767), ("S", 0, 65535), ("i", -2 ** 31, 2 ** 31 - 1),
+                                    ("I", 0, 2 ** 32 - 1)) if lo <= v <= hi]
+        t = fits[int(rng.integers(0, len(fits)))]
+        return key + t.encode() + struct.pack({"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[t], v)
+
+    def junk():
+        k = int(rng.integers(0, 6))
+        if k == 0: return b"XAZ" + bytes(rng.integers(33, 127, size=int(rng.integers(0, 40))).astype(np.uint8)) + b"\0"
+        if k == 1: return b"XBBs" + struct.pack("<i", 3) + struct.pack("<hhh", -1, 2, 3)
+        if k == 2: return b"XFf" + struct.pack("<f", 1.5)
+        if k == 3: return b"XHH" + b"1AE301\0"
+        if k == 4: return b"XCA" + b"Q"
+        return b"NMZ" + b"7\0"  # an NM that is not an integer: ignored (QualityCheck.hpp:201-209)
+
+    recs, so, qo, co = [], 0, 0, 0
+    exp_nm, exp_extra = [], []
+    for i in range(n_reads):
+        L, nc = int(cols["l_seq"][i]), int(cols["n_cigar"][i])
+        tags = [b"RGZ" + rg[int(cols["lane"][i])].encode() + b"\0", int_tag(b"AS", int(cols["as_"][i]))]
+        nm = int(cols["nm"][i])
+        if nm >= 0:
+            tags.append(int_tag(b"NM", nm))
+            if rng.random() < 0.05:  # a second NM tag: reported as an extra value
+                tags.append(int_tag(b"NM", nm + 1))
+                exp_extra.append((i, nm + 1))
+        for _ in range(int(rng.integers(0, 4))):
+            tags.insert(int(rng.integers(0, len(tags) + 1)), junk())
+        # the first integer NM in tag order is the read's value
+        recs.append(dict(rid=int(cols["rid"][i]), pos=int(cols["pos"][i]), mapq=int(cols["mapq"][i]), flag=int(cols["flag"][i]) & 0xFFF,
+                         rnext=0 if int(cols["flag"][i]) & 0x1000 else -1, tlen=int(cols["tlen"][i]), name="r%d" % i,
+                         cigar=cols["cigar"][co:co + nc], seq=cols["seq"][so:so + (L + 1) // 2], qual=cols["qual"][qo:qo + L], l_seq=L,
+                         tags=b"".join(tags)))
+        so += (L + 1) // 2; qo += L; co += nc
+    pybam.write_bam(path, text, [("chr%d" % (i + 1), len(r)) for i, r in enumerate(refs)], recs, rng=rng)
+    return cols, exp_extra
+
+
+def test_wild_records_and_tags_decode(tmp_path):
+    """Python-written BAM (records straddling BGZF blocks of random size and compression level, every tag type, repeated
+    and non-integer NM tags) through the C++ reader: every column as written."""
+    p = str(tmp_path / "wild.bam")
+    cols, exp_extra = _wild_bam(p, 21, 3000)
+    f = hostio.BamFile(p)
+    f.set_main_chrom(np.ones(3, np.uint8))
+    got = list(f.batches(max_reads=777))
+    cat = {k: np.concatenate([b[k] for b in got]) for k in cols}
+    noq = np.zeros(len(cols["flag"]), bool)
+    qo = 0
+    for i, L in enumerate(cols["l_seq"]):
+        noq[i] = L > 0 and cols["qual"][qo] == 0xFF
+        qo += int(L)
+    want_flag = (cols["flag"] & 0x1FFF) | np.where(noq, 0x8000, 0).astype(np.uint16)
+    assert np.array_equal(cat["flag"], want_flag)
+    for k in ("mapq", "lane", "rid", "pos", "tlen", "nm", "as_", "l_seq", "n_cigar", "seq", "qual", "cigar"):
+        assert np.array_equal(cat[k], cols[k]), k
+    extra, base = [], 0
+    for b in got:
+        if "nm_extra_read" in b:
+            extra += [(int(r) + base, int(v)) for r, v in zip(b["nm_extra_read"], b["nm_extra_val"])]
+        base += len(b["flag"])
+    assert extra == exp_extra
