@@ -764,20 +764,22 @@ extern "C" hipError_t bqc_short_init()
 }
 
 // Sum the packed rows the workgroups of one or more k_short launches have written (slot s: rows s * BQC_T8_SPW .. + used[s]) into
-// the 8-mer counters of the state vector: thread per LDS dword (4 bins) and slice of 32 slots.  Rows are read once and not
+// the 8-mer counters of the state vector: thread per LDS dword (4 bins) and slice of 64 slots.  Rows are read once and not
 // written: the next launches overwrite them.
 __global__ __launch_bounds__(256) void k_t8_fold(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ used, uint32_t n_slots,
                                                     uint64_t* __restrict__ em)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // < 16384
-    uint32_t A = 0, B = 0, C = 0, D = 0; // bytes 0..3 of the dword = bins 4i + (0, 3, 2, 1); at most 32 * BQC_T8_SPW * 255 each
-    const uint32_t s0 = blockIdx.y * 32u, s1 = min(n_slots, s0 + 32u);
+    uint32_t A = 0, B = 0, C = 0, D = 0; // bytes 0..3 of the dword = bins 4i + (0, 3, 2, 1); at most 64 * BQC_T8_SPW * 255 each
+    const uint32_t s0 = blockIdx.y * 64u, s1 = min(n_slots, s0 + 64u); // (few slices: every slice ends in 65 536 x 4 global atomics)
     for (uint32_t sidx = s0; sidx < s1; ++sidx) {
         const uint32_t n = min(used[sidx], (uint32_t)BQC_T8_SPW);
-        for (uint32_t f = 0; f < n; ++f) {
-            const uint32_t v = rows[((size_t)sidx * BQC_T8_SPW + f) * 16384u + i];
-            A += v & 0xFFu; B += (v >> 8) & 0xFFu; C += (v >> 16) & 0xFFu; D += v >> 24;
-        }
+        const uint32_t* slot = rows + (size_t)sidx * BQC_T8_SPW * 16384u + i;
+        uint32_t v[BQC_T8_SPW];
+#pragma unroll
+        for (uint32_t f = 0; f < BQC_T8_SPW; ++f) v[f] = f < n ? slot[(size_t)f * 16384u] : 0u; // independent loads, issued together
+#pragma unroll
+        for (uint32_t f = 0; f < BQC_T8_SPW; ++f) { A += v[f] & 0xFFu; B += (v[f] >> 8) & 0xFFu; C += (v[f] >> 16) & 0xFFu; D += v[f] >> 24; }
     }
     if (A) gadd(em + 4u * i + 0u, A);
     if (B) gadd(em + 4u * i + 3u, B);
@@ -805,5 +807,5 @@ extern "C" void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_us
                                    hipStream_t s)
 {
     if (!n_slots) return;
-    hipLaunchKernelGGL(k_t8_fold, dim3(64, (n_slots + 31) / 32), dim3(256), 0, s, t8rows, t8_used, n_slots, state + sl.lane_base(lane) + sl.o_eightmer);
+    hipLaunchKernelGGL(k_t8_fold, dim3(64, (n_slots + 63) / 64), dim3(256), 0, s, t8rows, t8_used, n_slots, state + sl.lane_base(lane) + sl.o_eightmer);
 }
