@@ -49,7 +49,11 @@ bool BamReader::fill(size_t need, std::string& err)
         if (buf_.capacity() < buf_.size() + chunk_.size()) { // grow rarely and far: reallocation copies the whole batch read so far
             try { buf_.reserve(std::max<size_t>(768u << 20, 2 * (buf_.size() + chunk_.size()))); } catch (const std::bad_alloc&) {}
         }
-        buf_.insert(buf_.end(), chunk_.begin(), chunk_.end());
+        { // append the run: a plain copy of ~100 MB, split over a few threads (one thread manages ~10 GB/s)
+            const size_t at = buf_.size(), n = chunk_.size();
+            buf_.resize(at + n);
+            parallel_ranges(n, std::min(4u, bg_.threads()), 8u << 20, [&](unsigned, size_t lo, size_t hi) { memcpy(buf_.data() + at + lo, chunk_.data() + lo, hi - lo); });
+        }
         t_copy_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
     }
     return true;

@@ -363,6 +363,7 @@ struct BatchQueue { // decode thread -> submit thread
     std::mutex m;
     std::condition_variable cv;
     std::deque<std::unique_ptr<HostBatch>> q;
+    std::vector<std::unique_ptr<HostBatch>> spare; // submitted batches go back to the decoder: their ~300 MB of columns are reused
     bool done = false;
     int err_code = 0;
     std::string err;
@@ -452,7 +453,12 @@ extern "C" int bqc_main(int argc, const char** argv)
     BatchQueue Q;
     std::thread dec([&]() {
         for (;;) {
-            auto hb = std::make_unique<HostBatch>();
+            std::unique_ptr<HostBatch> hb;
+            {
+                std::lock_guard<std::mutex> lk(Q.m);
+                if (!Q.spare.empty()) { hb = std::move(Q.spare.back()); Q.spare.pop_back(); }
+            }
+            if (!hb) hb = std::make_unique<HostBatch>();
             int code = 0;
             std::string e;
             const auto d0 = clk::now();
@@ -492,6 +498,10 @@ extern "C" int bqc_main(int argc, const char** argv)
         n_total += v.n_reads;
         if ((rc = bqc_submit(ctx, &v))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
         t_submit += secs(s0, clk::now());
+        { // (bqc_submit has copied the batch to the device)
+            std::lock_guard<std::mutex> lk(Q.m);
+            if (Q.spare.size() < 4) Q.spare.push_back(std::move(hb));
+        }
     }
     dec.join();
     if (timing)
