@@ -114,3 +114,29 @@ def test_wild_records_with_the_kmer_sketch(seed):
     # the sketch walks every read that passes the flag filter, whatever its CIGAR / position says; qualities around the cutoffs
     cols, refs = wild_batch(300 + seed, 2000)
     assert_parity(split(cols, [700]), refs, n_lanes=3, max_read_len=1024, isize=2000, klist=[5, 32], qlist=[17])
+
+
+@pytest.mark.parametrize("n_lanes", [1, 2])
+def test_hot_8mers_wrap_the_packed_counters(n_lanes):
+    """Low-complexity reads: a few 8-mers receive millions of counts, so k_short's packed u8 LDS counters wrap thousands of
+    times between two flushes (exact carry accounting), in the read group that uses the scratch rows and, with two read
+    groups, in the one that flushes with global atomics; k_long (reads of 300) wraps its own table."""
+    rng = np.random.default_rng(5)
+    n = 240_000
+    L = np.where(rng.random(n) < 0.97, 150, 300).astype(np.uint32)
+    kind = rng.integers(0, 10, size=n)
+    seqs, quals = [], []
+    pat = {0: [1], 1: [1], 2: [1], 3: [1], 4: [1], 5: [8], 6: [1, 2], 7: [4, 4, 8], 8: None, 9: None}  # A.., T.., AC.., GGT.., random
+    for i in range(n):
+        p = pat[int(kind[i])]
+        li = int(L[i])
+        nib = np.resize(np.array(p, np.uint8), li) if p else synth.NIB[rng.integers(0, 4, size=li)]
+        seqs.append(synth.pack_nibbles(nib))
+        quals.append(np.full(li, 30, np.uint8))
+    flag = (0x1 | 0x4 | 0x8 | np.where(np.arange(n) % 2 == 0, 0x40, 0x80) | np.where(rng.random(n) < 0.5, 0x10, 0)).astype(np.uint16)
+    cols = dict(flag=flag, mapq=np.zeros(n, np.uint8), lane=rng.integers(0, n_lanes, size=n).astype(np.uint8) if n_lanes > 1 else np.zeros(n, np.uint8),
+                rid=np.full(n, -1, np.int32), pos=np.full(n, -1, np.int32), tlen=np.zeros(n, np.int32), nm=np.full(n, -1, np.int32),
+                as_=np.full(n, synth.BQC_AS_ABSENT, np.int32), l_seq=L, n_cigar=np.zeros(n, np.uint16),
+                seq=np.concatenate(seqs), qual=np.concatenate(quals), cigar=np.zeros(0, np.uint32))
+    co, cg, _, _ = assert_parity(cols, [np.zeros(1000, np.uint8)], n_lanes=n_lanes, max_read_len=1024)
+    assert int(co[0]["eightmer"][0]) > 5_000_000 // n_lanes  # AAAAAAAA
