@@ -140,3 +140,9 @@ def test_hot_8mers_wrap_the_packed_counters(n_lanes):
                 seq=np.concatenate(seqs), qual=np.concatenate(quals), cigar=np.zeros(0, np.uint32))
     co, cg, _, _ = assert_parity(cols, [np.zeros(1000, np.uint8)], n_lanes=n_lanes, max_read_len=1024)
     assert int(co[0]["eightmer"][0]) > 5_000_000 // n_lanes  # AAAAAAAA
+
+
+def test_wild_records_many_read_groups():
+    # 40 read groups interleaved at random: most chunks of a lane hold a handful of reads, every lane is flushed on its own
+    cols, refs = wild_batch(77, 6000, n_lanes=40)
+    assert_parity(split(cols, [2500]), refs, n_lanes=40, max_read_len=1024, isize=2000)
