@@ -105,15 +105,20 @@ struct SketchDevice {
 // ---------------------------------------------------------------------------------------------------
 // device
 // ---------------------------------------------------------------------------------------------------
+// 128-bit rotation by one bit as four 32-bit funnel shifts (v_alignbit_b32) instead of 64-bit shifts and ORs
 __device__ __forceinline__ void rotl1_128(uint64_t& hi, uint64_t& lo)
 {
-    const uint64_t nh = (hi << 1) | (lo >> 63), nl = (lo << 1) | (hi >> 63);
-    hi = nh; lo = nl;
+    const uint32_t w3 = (uint32_t)(hi >> 32), w2 = (uint32_t)hi, w1 = (uint32_t)(lo >> 32), w0 = (uint32_t)lo;
+    const uint32_t n3 = __builtin_amdgcn_alignbit(w3, w2, 31), n2 = __builtin_amdgcn_alignbit(w2, w1, 31);
+    const uint32_t n1 = __builtin_amdgcn_alignbit(w1, w0, 31), n0 = __builtin_amdgcn_alignbit(w0, w3, 31);
+    hi = ((uint64_t)n3 << 32) | n2; lo = ((uint64_t)n1 << 32) | n0;
 }
 __device__ __forceinline__ void rotr1_128(uint64_t& hi, uint64_t& lo)
 {
-    const uint64_t nh = (hi >> 1) | (lo << 63), nl = (lo >> 1) | (hi << 63);
-    hi = nh; lo = nl;
+    const uint32_t w3 = (uint32_t)(hi >> 32), w2 = (uint32_t)hi, w1 = (uint32_t)(lo >> 32), w0 = (uint32_t)lo;
+    const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, 1), n1 = __builtin_amdgcn_alignbit(w2, w1, 1);
+    const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, 1), n3 = __builtin_amdgcn_alignbit(w0, w3, 1);
+    hi = ((uint64_t)n3 << 32) | n2; lo = ((uint64_t)n1 << 32) | n0;
 }
 __device__ __forceinline__ void rotl_128(uint64_t& hi, uint64_t& lo, uint32_t t) // 0 <= t < 64
 {
@@ -128,6 +133,8 @@ typedef u32x3 __attribute__((aligned(1))) u32x3_u;
 typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 
 #define SK_F2 32768
+#define SK_PT (SK_F2 + 256 + 64 + 16)                 // pair tables behind the small tables (16-byte aligned)
+#define SK_WORDS (SK_PT + 2 * 512 * 4)            // + [2 strands][256 (out, in) nibble pairs] x 2 tables x 16 B
 #define SK_THREADS 1024
 
 __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps,
@@ -145,6 +152,20 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) hv[i] = hv_all[pair * 128 + i];
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) lm[i] = 0;
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) ix[i] = idx_tab[i];
+    block_sync();
+    // RepHash::update(out, in) XORs two table values into each strand's state; with 16 x 16 nibble pairs per strand of the
+    // read the two are one 16-byte LDS read:  pf[s][out][in] = rotl_k(hvals[out]) ^ hvals[in],
+    // pt[s][out][in] = hvals[twin[out]] ^ rotl_k(hvals[twin[in]])   (s: reverse reads look bases up complemented)
+    uint4* pf = (uint4*)(lds + SK_PT);
+    uint4* pt = pf + 512;
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) {
+        const uint8_t* nx = ix + ((i >> 8) ? 16 : 0);
+        const uint32_t co = nx[(i >> 4) & 15u], c = nx[i & 15u], tco = ix[32 + co], tc = ix[32 + c];
+        const uint64_t fh = hv[64 + 2 * co] ^ hv[2 * c], fl = hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
+        const uint64_t th_ = hv[2 * tco] ^ hv[64 + 2 * tc], tl_ = hv[2 * tco + 1] ^ hv[64 + 2 * tc + 1];
+        pf[i] = make_uint4((uint32_t)fl, (uint32_t)(fl >> 32), (uint32_t)fh, (uint32_t)(fh >> 32));
+        pt[i] = make_uint4((uint32_t)tl_, (uint32_t)(tl_ >> 32), (uint32_t)th_, (uint32_t)(th_ >> 32));
+    }
     block_sync();
     const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_perm, lo_r + per_block);
     uint32_t blane = 0xFFFFFFFFu;
@@ -223,10 +244,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                     outs = kr == 0 ? lo : (hi << (64u - 4u * kr)) | (lo >> (4u * kr));
                 }
                 const uint32_t nb = min(16u, L - cb);
-                for (uint32_t jj = 0; jj < nb; ++jj) {
+                auto step = [&](const uint32_t jj) __attribute__((always_inline)) {
                     const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
                     const int32_t qc = (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u);
-                    if (nib == 15u || qc < P.q_thr) { t = 0; continue; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
+                    if (nib == 15u || qc < P.q_thr) { t = 0; return; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
                     const uint32_t c = nidx[nib];
                     if (t < P.k) { // RepHash::init(const char*) built incrementally, :85-97
                         if (t == 0) { hh = hl = th = tl = 0; }
@@ -236,14 +257,13 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                         rotl_128(xh, xl, t); // reverse-strand hash: sum_u rotl^u(hvals[twin[s_u]])
                         th ^= xh; tl ^= xl;
                         ++t;
-                        if (t < P.k) continue;
+                        if (t < P.k) return;
                     } else { // RepHash::update(out, in), :99-113
-                        const uint32_t co = nidx[(uint32_t)(outs >> (60 - 4 * jj)) & 15u];
+                        const uint32_t pi = (rc ? 256u : 0u) | (((uint32_t)(outs >> (60 - 4 * jj)) & 15u) << 4) | nib;
+                        const uint4 a = pf[pi], bt = pt[pi];
                         rotl1_128(hh, hl);
-                        hh ^= hv[64 + 2 * co] ^ hv[2 * c];         // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
-                        hl ^= hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
-                        th ^= hv[2 * tw[co]] ^ hv[64 + 2 * tw[c]]; // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
-                        tl ^= hv[2 * tw[co] + 1] ^ hv[64 + 2 * tw[c] + 1];
+                        hl ^= (uint64_t)a.x | ((uint64_t)a.y << 32); hh ^= (uint64_t)a.z | ((uint64_t)a.w << 32);   // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
+                        tl ^= (uint64_t)bt.x | ((uint64_t)bt.y << 32); th ^= (uint64_t)bt.z | ((uint64_t)bt.w << 32); // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
                         rotr1_128(th, tl);
                     }
                     // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
@@ -253,12 +273,15 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                     else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
                     uint32_t w = hash ? (uint32_t)__ffsll((unsigned long long)hash) - 1u : 63u; // bitScanForward (lsb.cpp:26-29)
                     if (w >= P.levels) w = P.levels - 1;
-                    if (mine && ((sat_mask >> w) & 1ull)) continue; // M[w] == size*countsPerLong*maxVal: every counter is 15
+                    if (mine && ((sat_mask >> w) & 1ull)) return; // M[w] == size*countsPerLong*maxVal: every counter is 15
                     const uint64_t index = (hash >> (w + 1)) & (uint64_t)P.ctr_mask;
                     // fire and forget: the counter's value is min(15, raw); k_sketch_levels clamps the raw counts after every
                     // batch and finds the levels in which every counter has reached 15
                     atomicAdd(D.counters + (uint64_t)w * P.ctr_per_level + index, 1u);
-                }
+                };
+#pragma unroll
+                for (uint32_t jj = 0; jj < 16u; ++jj) // unrolled: the nibble / quality / leaving-base extractions get constant shifts
+                    if (jj < nb) step(jj);
             }
             if (mine) atomicAdd(&lm[32], n_hash); else if (n_hash) gadd(D.misc, n_hash);
         }
@@ -405,7 +428,7 @@ SketchDevice* sketch_create(const bqc_sketch_options& so, uint32_t n_lanes, hipS
     ok = ok && hipMemcpy(sk->d_ds, sk->ds.data(), sizeof(DevSketch) * n, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(sk->d_pp, sk->pp.data(), sizeof(PairParams) * sk->n_pairs, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sketch), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (SK_F2 + 256 + 64 + 16) * 4) == hipSuccess;
+                                   SK_WORDS * 4) == hipSuccess;
     if (!ok) { err = "sketch table upload failed"; sketch_destroy(sk); return nullptr; }
     return sk;
 }
@@ -430,7 +453,7 @@ void sketch_process(SketchDevice* sk, const DevBatch& b, hipStream_t s)
     uint32_t per = (b.n_perm + grid - 1) / grid;
     per = ((per + SK_THREADS - 1) / SK_THREADS) * SK_THREADS;
     grid = (b.n_perm + per - 1) / per;
-    hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), (SK_F2 + 256 + 64 + 16) * 4, s, b, sk->d_ds, sk->d_pp,
+    hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), SK_WORDS * 4, s, b, sk->d_ds, sk->d_pp,
                        (const uint64_t*)sk->d_hv, sk->d_idx, sk->n_pairs, per);
     const uint32_t n = sk->n_lanes * sk->n_pairs;
     hipLaunchKernelGGL(k_sketch_levels, dim3(n, 32, (uint32_t)((sk->ctr_per_level + SK_SLICE - 1) / SK_SLICE)), dim3(256), 0, s, sk->d_ds, sk->d_pp, sk->n_pairs);
