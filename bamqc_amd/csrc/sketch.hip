@@ -120,13 +120,6 @@ __device__ __forceinline__ void rotr1_128(uint64_t& hi, uint64_t& lo)
     const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, 1), n3 = __builtin_amdgcn_alignbit(w0, w3, 1);
     hi = ((uint64_t)n3 << 32) | n2; lo = ((uint64_t)n1 << 32) | n0;
 }
-__device__ __forceinline__ void rotl_128(uint64_t& hi, uint64_t& lo, uint32_t t) // 0 <= t < 64
-{
-    if (t == 0) return;
-    const uint64_t nh = (hi << t) | (lo >> (64 - t)), nl = (lo << t) | (hi >> (64 - t));
-    hi = nh; lo = nl;
-}
-
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x3 __attribute__((aligned(1))) u32x3_u;
@@ -134,7 +127,8 @@ typedef u32x4 __attribute__((aligned(1))) u32x4_u;
 
 #define SK_F2 32768
 #define SK_PT (SK_F2 + 256 + 64 + 16)                 // pair tables behind the small tables (16-byte aligned)
-#define SK_WORDS (SK_PT + 2 * 512 * 4)            // + [2 strands][256 (out, in) nibble pairs] x 2 tables x 16 B
+#define SK_PAIRS (2 * 17 * 16)                     // [2 strands][16 leaving nibbles + none][16 entering nibbles]
+#define SK_WORDS (SK_PT + 2 * SK_PAIRS * 4)          // two tables of 16-byte entries
 #define SK_THREADS 1024
 
 __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSketch* __restrict__ dsk, const PairParams* __restrict__ pps,
@@ -155,14 +149,22 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     block_sync();
     // RepHash::update(out, in) XORs two table values into each strand's state; with 16 x 16 nibble pairs per strand of the
     // read the two are one 16-byte LDS read:  pf[s][out][in] = rotl_k(hvals[out]) ^ hvals[in],
-    // pt[s][out][in] = hvals[twin[out]] ^ rotl_k(hvals[twin[in]])   (s: reverse reads look bases up complemented)
+    // pt[s][out][in] = hvals[twin[out]] ^ rotl_k(hvals[twin[in]])   (s: reverse reads look bases up complemented).
+    // Row out = 16 ("nothing leaves") holds hvals[in] and rotl_k(hvals[twin[in]]): with it the first k bases of a k-mer
+    // take the same step as the rolling update.  For the forward strand that is RepHash::init literally (:85-97); for the
+    // twin, init's sum_u rotl^u(x_u) equals k steps of  ht = rotr1(ht ^ rotl_k(x_u))  once all k bases are in, and no
+    // hash is emitted before that.
     uint4* pf = (uint4*)(lds + SK_PT);
-    uint4* pt = pf + 512;
-    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) {
-        const uint8_t* nx = ix + ((i >> 8) ? 16 : 0);
-        const uint32_t co = nx[(i >> 4) & 15u], c = nx[i & 15u], tco = ix[32 + co], tc = ix[32 + c];
-        const uint64_t fh = hv[64 + 2 * co] ^ hv[2 * c], fl = hv[64 + 2 * co + 1] ^ hv[2 * c + 1];
-        const uint64_t th_ = hv[2 * tco] ^ hv[64 + 2 * tc], tl_ = hv[2 * tco + 1] ^ hv[64 + 2 * tc + 1];
+    uint4* pt = pf + SK_PAIRS;
+    for (uint32_t i = threadIdx.x; i < SK_PAIRS; i += blockDim.x) {
+        const uint8_t* nx = ix + (i >= 272u ? 16 : 0);
+        const uint32_t o = (i % 272u) >> 4, c = nx[i & 15u], tc = ix[32 + c];
+        uint64_t fh = hv[2 * c], fl = hv[2 * c + 1], th_ = hv[64 + 2 * tc], tl_ = hv[64 + 2 * tc + 1];
+        if (o < 16u) {
+            const uint32_t co = nx[o], tco = ix[32 + co];
+            fh ^= hv[64 + 2 * co]; fl ^= hv[64 + 2 * co + 1];
+            th_ ^= hv[2 * tco]; tl_ ^= hv[2 * tco + 1];
+        }
         pf[i] = make_uint4((uint32_t)fl, (uint32_t)(fl >> 32), (uint32_t)fh, (uint32_t)(fh >> 32));
         pt[i] = make_uint4((uint32_t)tl_, (uint32_t)(tl_ >> 32), (uint32_t)th_, (uint32_t)(th_ >> 32));
     }
@@ -201,8 +203,6 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
             const bool rc = flag & 0x10;
             const uint8_t* __restrict__ sq = b.seq + b.seq_off[r];
             const uint8_t* __restrict__ ql = b.qual + b.qual_off[r];
-            const uint8_t* nidx = ix + (rc ? 16 : 0);
-            const uint8_t* tw = ix + 32;
             uint64_t hh = 0, hl = 0, th = 0, tl = 0;
             uint32_t t = 0; // number of consecutive valid bases ending at the current one
             uint32_t n_hash = 0;
@@ -248,24 +248,17 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                     const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
                     const int32_t qc = (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u);
                     if (nib == 15u || qc < P.q_thr) { t = 0; return; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
-                    const uint32_t c = nidx[nib];
-                    if (t < P.k) { // RepHash::init(const char*) built incrementally, :85-97
-                        if (t == 0) { hh = hl = th = tl = 0; }
-                        rotl1_128(hh, hl);
-                        hh ^= hv[2 * c]; hl ^= hv[2 * c + 1];
-                        uint64_t xh = hv[2 * tw[c]], xl = hv[2 * tw[c] + 1];
-                        rotl_128(xh, xl, t); // reverse-strand hash: sum_u rotl^u(hvals[twin[s_u]])
-                        th ^= xh; tl ^= xl;
-                        ++t;
-                        if (t < P.k) return;
-                    } else { // RepHash::update(out, in), :99-113
-                        const uint32_t pi = (rc ? 256u : 0u) | (((uint32_t)(outs >> (60 - 4 * jj)) & 15u) << 4) | nib;
-                        const uint4 a = pf[pi], bt = pt[pi];
-                        rotl1_128(hh, hl);
-                        hl ^= (uint64_t)a.x | ((uint64_t)a.y << 32); hh ^= (uint64_t)a.z | ((uint64_t)a.w << 32);   // z = rotl_k(hvals[out]); h ^= z ^ hvals[in]
-                        tl ^= (uint64_t)bt.x | ((uint64_t)bt.y << 32); th ^= (uint64_t)bt.z | ((uint64_t)bt.w << 32); // ht ^= hvals[twin[out]] ^ rotl_k(hvals[twin[in]])
-                        rotr1_128(th, tl);
-                    }
+                    if (t == 0) { hh = hl = th = tl = 0; }
+                    // RepHash::init built incrementally (:85-97) and RepHash::update(out, in) (:99-113) as one step: nothing
+                    // leaves the k-mer while it is still filling
+                    const uint32_t outn = t < P.k ? 16u : (uint32_t)(outs >> (60 - 4 * jj)) & 15u;
+                    const uint32_t pi = (rc ? 272u : 0u) + (outn << 4) + nib;
+                    const uint4 a = pf[pi], bt = pt[pi];
+                    rotl1_128(hh, hl);
+                    hl ^= (uint64_t)a.x | ((uint64_t)a.y << 32); hh ^= (uint64_t)a.z | ((uint64_t)a.w << 32);   // h = rotl1(h) ^ rotl_k(hvals[out]) ^ hvals[in]
+                    tl ^= (uint64_t)bt.x | ((uint64_t)bt.y << 32); th ^= (uint64_t)bt.z | ((uint64_t)bt.w << 32); // ht = rotr1(ht ^ hvals[twin[out]] ^ rotl_k(hvals[twin[in]]))
+                    rotr1_128(th, tl);
+                    if (t < P.k && ++t < P.k) return;
                     // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
                     const uint64_t hash = hl ^ tl;
                     ++n_hash;
