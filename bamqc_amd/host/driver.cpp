@@ -3,6 +3,7 @@
 // record loop's body replaced by the GPU aggregation of include/bamqc.h.  Also: FASTA loader
 // (replaces Genome / SequenceStream, src/TripletCounting.hpp:60-104) and the C wrappers of
 // include/bamqc_host.h around the BAM reader.
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -47,6 +48,13 @@ static bool load_fasta(const char* path, const std::vector<std::string>* want, s
     if (!f) { err = std::string("ERROR: Could not open fasta file ") + path; return false; }
     gzbuffer(f, 1 << 20);
     std::vector<char> buf(1 << 22);
+    // An uncompressed file bounds every contig by the bytes that are left: reserving that much (address space only) saves
+    // growing a multi-hundred-megabyte vector through a dozen reallocations, each faulting in fresh pages.
+    uint64_t file_size = 0, consumed = 0, reserve_hint = 0; // (consumed: bytes of the buffers before the current one)
+    {
+        struct stat st;
+        if (gzdirect(f) && stat(path, &st) == 0 && st.st_size > 0) file_size = (uint64_t)st.st_size;
+    }
     FastaRecord* cur = nullptr;
     bool keep = false, in_header = false;
     std::string hdr;
@@ -63,21 +71,44 @@ static bool load_fasta(const char* path, const std::vector<std::string>* want, s
             keep = false;
             for (const auto& w : *want) if (w == name) { keep = true; break; }
         }
+        if (keep && reserve_hint) { try { cur->codes.reserve((size_t)reserve_hint); } catch (const std::bad_alloc&) {} }
         hdr.clear();
     };
     int n;
     while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
-        for (int i = 0; i < n; ++i) {
-            const char c = buf[i];
+        // Same rules as a byte-at-a-time scan ('>' anywhere outside a header line starts one; '\n' and '\r' are dropped from
+        // sequence), but header lines and runs of sequence are handled in bulk: a whole genome is a few GB of text.
+        const char* p = buf.data();
+        const char* const end = p + n;
+        while (p < end) {
             if (in_header) {
-                if (c == '\n') { in_header = false; finish_header(); }
-                else hdr.push_back(c);
-            } else if (c == '>') {
-                in_header = true;
-            } else if (c != '\n' && c != '\r' && cur && keep) {
-                cur->codes.push_back(lut[(uint8_t)c]);
+                const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+                if (!nl) { hdr.append(p, (size_t)(end - p)); break; }
+                hdr.append(p, (size_t)(nl - p));
+                in_header = false;
+                { const uint64_t at = consumed + (uint64_t)(nl - buf.data()); reserve_hint = file_size > at ? file_size - at : 0; }
+                finish_header();
+                p = nl + 1;
+                continue;
             }
+            const char* gt = (const char*)memchr(p, '>', (size_t)(end - p));
+            const char* stop = gt ? gt : end;
+            if (cur && keep && stop > p) {
+                std::vector<uint8_t>& codes = cur->codes;
+                const size_t at = codes.size();
+                codes.resize(at + (size_t)(stop - p));
+                uint8_t* w = codes.data() + at;
+                for (const char* q = p; q < stop; ++q) {
+                    const char c = *q;
+                    *w = lut[(uint8_t)c];
+                    w += (c != '\n') & (c != '\r');
+                }
+                codes.resize((size_t)(w - codes.data()));
+            }
+            p = stop;
+            if (gt) { in_header = true; ++p; }
         }
+        consumed += (uint64_t)n;
     }
     if (in_header) finish_header();
     gzclose(f);
