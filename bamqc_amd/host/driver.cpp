@@ -395,7 +395,7 @@ struct BatchQueue { // decode thread -> submit thread
     std::condition_variable cv;
     std::deque<std::unique_ptr<HostBatch>> q;
     std::vector<std::unique_ptr<HostBatch>> spare; // submitted batches go back to the decoder: their ~300 MB of columns are reused
-    bool done = false;
+    bool done = false, stop = false;
     int err_code = 0;
     std::string err;
 };
@@ -436,6 +436,44 @@ extern "C" int bqc_main(int argc, const char** argv)
         }
     }
     rd.set_main_chrom(main_chrom);
+    // BQC_TIMING=1: where the wall time of a run goes (stderr)
+    const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    double t_wait = 0, t_submit = 0, t_decode = 0;
+    uint64_t n_total = 0;
+    // decode thread feeds batches; this thread submits them.  It starts right away: the first batches are inflated and
+    // decoded while the FASTA file is read and the device is set up.
+    BatchQueue Q;
+    std::thread dec;
+    auto stop_decoder = [&]() {
+        if (!dec.joinable()) return;
+        { std::lock_guard<std::mutex> lk(Q.m); Q.stop = true; }
+        Q.cv.notify_all();
+        dec.join();
+    };
+    if (H.lane_count != 0) dec = std::thread([&]() {
+        for (;;) {
+            std::unique_ptr<HostBatch> hb;
+            {
+                std::lock_guard<std::mutex> lk(Q.m);
+                if (!Q.spare.empty()) { hb = std::move(Q.spare.back()); Q.spare.pop_back(); }
+            }
+            if (!hb) hb = std::make_unique<HostBatch>();
+            int code = 0;
+            std::string e;
+            const auto d0 = clk::now();
+            const int r = rd.next_batch(*hb, opt.batch_reads, 256ull << 20, e, code);
+            t_decode += secs(d0, clk::now());
+            std::unique_lock<std::mutex> lk(Q.m);
+            if (r < 0) { Q.err = e; Q.err_code = code; Q.done = true; Q.cv.notify_all(); return; }
+            if (r == 0) { Q.done = true; Q.cv.notify_all(); return; }
+            Q.cv.wait(lk, [&] { return Q.q.size() < 3 || Q.stop; });
+            if (Q.stop) return;
+            Q.q.push_back(std::move(hb));
+            Q.cv.notify_all();
+        }
+    });
     // reference genome: all contigs that are BAM references, FASTA order kept for the cursor rule
     std::vector<FastaRecord> fa;
     std::string ferr;
@@ -464,45 +502,16 @@ extern "C" int bqc_main(int argc, const char** argv)
     }
     bqc_ctx* ctx = nullptr;
     int rc = bqc_create(&bo, &ctx);
-    if (rc) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(nullptr)); return 1; }
+    if (rc) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(nullptr)); stop_decoder(); return 1; }
     for (uint32_t r = 0; r < n_refs; ++r)
         if (fasta_index[r] >= 0) {
             const auto& c = fa[fasta_index[r]].codes;
-            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
+            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return 1; }
         }
     fa.clear();
     fa.shrink_to_fit();
-
-    // BQC_TIMING=1: where the wall time of a run goes (stderr)
-    const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
-    using clk = std::chrono::steady_clock;
-    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t_setup = clk::now();
-    double t_wait = 0, t_submit = 0, t_decode = 0;
-    uint64_t n_total = 0;
-    // decode thread feeds batches; this thread submits them
-    BatchQueue Q;
-    std::thread dec([&]() {
-        for (;;) {
-            std::unique_ptr<HostBatch> hb;
-            {
-                std::lock_guard<std::mutex> lk(Q.m);
-                if (!Q.spare.empty()) { hb = std::move(Q.spare.back()); Q.spare.pop_back(); }
-            }
-            if (!hb) hb = std::make_unique<HostBatch>();
-            int code = 0;
-            std::string e;
-            const auto d0 = clk::now();
-            const int r = rd.next_batch(*hb, opt.batch_reads, 256ull << 20, e, code);
-            t_decode += secs(d0, clk::now());
-            std::unique_lock<std::mutex> lk(Q.m);
-            if (r < 0) { Q.err = e; Q.err_code = code; Q.done = true; Q.cv.notify_all(); return; }
-            if (r == 0) { Q.done = true; Q.cv.notify_all(); return; }
-            Q.cv.wait(lk, [&] { return Q.q.size() < 3; });
-            Q.q.push_back(std::move(hb));
-            Q.cv.notify_all();
-        }
-    });
+
     int status = 0;
     bool warned_qual = false;
     for (;;) {
