@@ -11,7 +11,7 @@
 //                into the reverse complement (k_ref_nibbles).
 //   cycles       four one-hot planes are added into 4-bit vertical counters in registers (one add per plane and 8
 //                cycles), spilled to the LDS cycle tile every 15 groups; quality sums as packed 16-bit fields;
-//                per-read sums (quality | N << 16 | GC << 24) by one DPP prefix scan (QualityCheck.hpp:122-166).
+//                per-read sums (quality | N << 16 | GC << 24) added into the read's LDS record (QualityCheck.hpp:122-166).
 //   8-mers       2-bit codes of the lane's 16 cycles in one register (+ the next lane's by DPP); the 16 windows are
 //                funnel shifts; counters are 65 536 packed u8 fields in 64 KiB of LDS, incremented by returning
 //                atomics whose increment 1 << 8*byte comes from v_alignbyte_b32(1, 1, h); a wrapping field is
@@ -270,8 +270,8 @@ __device__ __forceinline__ lds_u32* lds_at(uint32_t byte_addr) { return (lds_u32
 #define KM_TRIP   0x20000u   // triplets are evaluated for the position range in word 5 (needs a loaded reference)
 #define KM_SEG    0x40000u   // triplet-segment entry: the read's bases / qualities for triplets only (no KM_PRIM)
 // word 0: BAM flag (low 16 bits) | KM_* | L << 20 (L = 0 unless KM_PRIM)
-//      1: seq byte offset of the window of lane w = 0 (+ KS_BIAS)      -> after the group was computed: packed sums before the read
-//      2: qual byte offset of the window of lane w = 0 (+ KS_BIAS)     ->                               packed sums after the read
+//      1: seq byte offset of the window of lane w = 0 (+ KS_BIAS)      -> after the group was computed: the read's packed sums
+//      2: qual byte offset of the window of lane w = 0 (+ KS_BIAS)
 //      3: reference nibble index of that window, minus one (pos + o0 + NB - 1; the table has NB = 8 * BQC_FAST_NH pad nibbles in front)
 //      4: last loadable dword index of the contig's table     5: ja | jb << 8 | seq funnel shift << 16
 //      6-7: pointer to the contig's nibble table
@@ -576,8 +576,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                         while (o) { const uint32_t bit = (uint32_t)__ffs((int)o) - 1u; o &= o - 1u; atomicAdd(ob + KS_CSTRIDE * (8u * h + 7u - (bit >> 2)), 1u); }
                     }
                 }
-                // per-read sums: quality | N << 16 | GC << 24 (L <= 255), one wave-wide prefix scan; the lane at the start of
-                // a slot leaves the running sum before its read in record word 1 and, for the previous slot, after it in word 2
+                // per-read sums: quality | N << 16 | GC << 24 (L <= 255), added up in word 1 of the read's record
                 uint32_t v = 0, vn = 0, vgc = 0;
 #pragma unroll
                 for (int d = 0; d < KS_ND; ++d) v = __builtin_amdgcn_sad_u8(Q[d], 0u, v);
@@ -585,13 +584,10 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 for (int h = 0; h < KS_NH; ++h) { vn += (uint32_t)__popc(P[h].n); vgc += (uint32_t)__popc(P[h].c | P[h].g); }
                 v |= vn << 16;
                 v += vgc << 24;
-                const uint32_t si = wave_scan_incl(v);
-                const uint32_t bs = lane_prev(si);
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)si, 63);
-                if (lane_used && w == 0u) {
-                    WM[k * KS_MW + 1] = bs;
-                    if (slot) WM[(k - 1u) * KS_MW + 2] = bs;
-                    if (slot + 1u == rpw) WM[k * KS_MW + 2] = tot; // lanes behind the last slot hold only zeros
+                if (lane_used) { // (the DS operations of a wave execute in order: the store precedes the adds)
+                    uint32_t* sw = WM + k * KS_MW + 1;
+                    if (w == 0u) *sw = 0u;
+                    atomicAdd(sw, v);
                 }
             }
             // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
@@ -706,7 +702,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         if ((parts & 1u) && ln < tn) {
             const uint32_t m0 = WM[ln * KS_MW];
             if (m0 & KM_PRIM) {
-                const uint32_t L = (m0 >> 20) & 0xFFu, sum = WM[ln * KS_MW + 2] - WM[ln * KS_MW + 1];
+                const uint32_t L = (m0 >> 20) & 0xFFu, sum = WM[ln * KS_MW + 1];
                 const uint32_t qs = sum & 0xFFFFu, nN = (sum >> 16) & 0xFFu, nGC = sum >> 24, rm = (m0 & 0x40u) ? 0u : 1u;
                 atomicAdd(&lds[KS_NC + rm * (KS_CT + 1) + nN], 1u);
                 atomicAdd(&lds[KS_GC + rm * (KS_CT + 1) + nGC], 1u);
