@@ -9,14 +9,17 @@
 // truncated at (win+2)*1000 (CovEntry, 8 B).  Depth is then order-free: +1 / -1 into an LDS difference array per interval,
 // prefix scan, clamp-100 histogram.  One workgroup per tile of 4 windows; the intervals of the NEXT tile are loaded (two
 // per thread, coalesced) while the current tile is scanned.
+#define KC_AT(p) ((p) + (((p) >> 6) << 2))
 __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_t* __restrict__ state,
                                                 uint32_t* __restrict__ carry /* [lane][2][2000] */, const uint32_t* __restrict__ parity)
 {
-    __shared__ __attribute__((aligned(16))) int32_t diff[4096]; // 256 threads x 16 positions >= BQC_COV_TILE + 1
+    // 256 threads x 16 positions >= BQC_COV_TILE + 1; position p lives at KC_AT(p): 4 words of padding after every 64, so that the
+    // 16-byte accesses of the scan (thread t: words 16 t ..) of 16 neighbouring threads fall on 64 different banks
+    __shared__ __attribute__((aligned(16))) int32_t diff[4096 + 256];
     __shared__ uint32_t hist[BQC_COVSIZE + 1];
     __shared__ uint32_t wsum[4];
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
-    for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) diff[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 4096 + 256; i += blockDim.x) diff[i] = 0;
     uint32_t cur_lane = 0xFFFFFFFFu;
     CovTile t{};
     t.lane = 0xFFFFFFFFu;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
             int64_t a = (int64_t)e.win * BQC_VSIZE + (e.off_len & 0xFFFFu) - lo, z = a + len;
             if (a < 0) a = 0;
             if (z > BQC_COV_TILE) z = BQC_COV_TILE;
-            if (a < z) { atomicAdd(&diff[a], 1); atomicAdd(&diff[z], -1); }
+            if (a < z) { atomicAdd(&diff[KC_AT((uint32_t)a)], 1); atomicAdd(&diff[KC_AT((uint32_t)z)], -1); }
         };
         add(e0); add(e1);
         for (uint32_t e = t.list_begin + 2 * blockDim.x + threadIdx.x; e < t.list_end; e += blockDim.x) add(b.cov_list[e]); // (rare: > 512 intervals)
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         int32_t d[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int4 v = *(const int4*)&diff[s0 + 4 * q];
+            const int4 v = *(const int4*)&diff[KC_AT(s0) + 4 * q];
             d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
         }
         int32_t loc = 0;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         block_sync();
         // this thread's 16 entries are in registers: zero them for the next tile (its atomics come after the barrier on top)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(int4*)&diff[s0 + 4 * q] = make_int4(0, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) *(int4*)&diff[KC_AT(s0) + 4 * q] = make_int4(0, 0, 0, 0);
         int32_t off = inc - loc;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
         const uint32_t par = parity[tc.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
