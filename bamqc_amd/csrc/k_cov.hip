@@ -90,6 +90,17 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         uint32_t* cout = carry + ((uint64_t)tc.lane * 2 + (par ^ 1u)) * 2000;
         int32_t run = off;
         uint32_t run_bin = 0xFFFFFFFFu, run_n = 0; // consecutive positions mostly share a depth: one LDS atomic per run
+        if (lo >= 2 * BQC_VSIZE && tc.win_lo + BQC_COV_TILE_WINDOWS <= tc.win_final) {
+            // (block-uniform) the common tile: nothing carried in, every window complete — no per-position window arithmetic
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (s0 + j >= BQC_COV_TILE) continue;
+                run += d[j];
+                const uint32_t bin = min((uint32_t)run, (uint32_t)BQC_COVSIZE);
+                if (bin == run_bin) ++run_n;
+                else { if (run_n) atomicAdd(&hist[run_bin], run_n); run_bin = bin; run_n = 1; }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t p = s0 + j;
