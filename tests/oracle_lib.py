@@ -19,11 +19,13 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    # BQC_ORACLE_ASAN=1 (tools/asan_oracle.sh): the address / UB-sanitized build; needs LD_PRELOAD of libasan
+    asan = os.environ.get("BQC_ORACLE_ASAN") == "1"
+    path = os.path.join(ROOT, "oracle", "liboracle_asan.so" if asan else "liboracle.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("bamqc_oracle.c", "sketch_oracle.c", "bamqc_oracle.h")]
     srcs.append(os.path.join(ROOT, "include", "bamqc.h"))
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.basename(path)], stdout=subprocess.DEVNULL)
     L = C.CDLL(path)
     L.orc_create.argtypes = [C.POINTER(_abi.Options), C.POINTER(C.c_void_p)]
     L.orc_set_reference.argtypes = [C.c_void_p, C.c_int32, _abi.u8p, C.c_uint64]
