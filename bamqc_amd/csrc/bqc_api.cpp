@@ -23,8 +23,8 @@ extern "C" {
 void bqc_launch_reads_chunks(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t n_cu, hipStream_t);
 void bqc_launch_nm_extra(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
 void bqc_launch_long(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t* rsum, uint32_t max_len, uint32_t n_cu, hipStream_t);
-void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, const uint32_t* parity, hipStream_t);
-void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t);
+void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, uint32_t* parity, const uint8_t* lane_mask, uint8_t* started,
+                    const uint8_t* started_after, uint32_t n_lanes, hipStream_t);
 void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
@@ -85,7 +85,7 @@ struct bqc_ctx {
     uint32_t t8_rows_lane = 0;
     std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
-    uint32_t* d_parity = nullptr; // [lane]
+    uint32_t* d_parity = nullptr; // [lane], then the count of finished workgroups of the running k_cov
     uint8_t* d_started = nullptr; // [lane]
     // references
     std::vector<uint8_t*> d_ref;
@@ -199,7 +199,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMalloc(&c->d_t8rows, (size_t)c->t8_slots_cap * BQC_T8_SPW * 65536));
     CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * 4));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
-    CCHK(hipMalloc(&c->d_parity, (size_t)opt->n_lanes * 4));
+    CCHK(hipMalloc(&c->d_parity, ((size_t)opt->n_lanes + 1) * 4));
     CCHK(hipMalloc(&c->d_started, opt->n_lanes));
     CCHK(hipMalloc(&c->d_ref_ptrs, sizeof(uint8_t*) * nr));
     CCHK(hipMalloc(&c->d_ref_len, sizeof(uint64_t) * nr));
@@ -209,7 +209,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
     CCHK(hipMemsetAsync(c->d_err, 0, 64, c->stream));
     CCHK(hipMemsetAsync(c->d_carry, 0, (size_t)opt->n_lanes * 2 * 2000 * 4, c->stream));
-    CCHK(hipMemsetAsync(c->d_parity, 0, (size_t)opt->n_lanes * 4, c->stream));
+    CCHK(hipMemsetAsync(c->d_parity, 0, ((size_t)opt->n_lanes + 1) * 4, c->stream));
     CCHK(hipMemsetAsync(c->d_started, 0, opt->n_lanes, c->stream));
     CCHK(hipStreamSynchronize(c->stream));
     if (upload_ref_tables(c)) { snprintf(g_create_err, sizeof g_create_err, "%s", c->err.c_str()); bqc_destroy(c); return BQC_ERR_DEVICE; }
@@ -795,7 +795,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
         c->fasta_cursor = db->fasta_cursor_after;
         c->state_seq = db->seq;
     }
-    bqc_launch_or_bytes(c->d_started, db->d_started_after, c->opt.n_lanes, c->stream);
+    if (!db->d.n_cov_tiles) bqc_launch_or_bytes(c->d_started, db->d_started_after, c->opt.n_lanes, c->stream); // (else: k_cov's epilogue)
     if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
     DevBatch slow = db->d; // generic kernels see only the reads that are not on the fast path
     if (db->d.n_chunks_fast) {
@@ -821,8 +821,7 @@ extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
     }
     if (db->d.n_nm_extra) bqc_launch_nm_extra(db->d, c->sl, c->d_state, refs, c->d_err, c->stream);
     if (db->d.n_cov_tiles) {
-        bqc_launch_cov(db->d, c->sl, c->d_state, c->d_carry, c->d_parity, c->stream);
-        bqc_launch_cov_flip(c->d_parity, db->d_lane_mask, c->opt.n_lanes, c->stream);
+        bqc_launch_cov(db->d, c->sl, c->d_state, c->d_carry, c->d_parity, db->d_lane_mask, c->d_started, db->d_started_after, c->opt.n_lanes, c->stream);
     }
     bqc_launch_add_words(c->d_state, db->d_add_idx, db->d_add_val, (uint32_t)db->add_idx.size(), c->stream);
     tick(c, "k_cov");
@@ -858,7 +857,7 @@ extern "C" int bqc_reset(bqc_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_carry, 0, (size_t)c->opt.n_lanes * 2 * 2000 * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_parity, 0, (size_t)c->opt.n_lanes * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_parity, 0, ((size_t)c->opt.n_lanes + 1) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_started, 0, c->opt.n_lanes, c->stream));
     if (c->sketch) sketch_reset(c->sketch, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -11,7 +11,9 @@
 // per thread, coalesced) while the current tile is scanned.
 #define KC_AT(p) ((p) + (((p) >> 6) << 2))
 __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_t* __restrict__ state,
-                                                uint32_t* __restrict__ carry /* [lane][2][2000] */, const uint32_t* __restrict__ parity)
+                                                uint32_t* __restrict__ carry /* [lane][2][2000] */, uint32_t* parity /* [n_lanes], then a counter */,
+                                                const uint8_t* __restrict__ lane_mask, uint8_t* __restrict__ started,
+                                                const uint8_t* __restrict__ started_after, uint32_t n_lanes)
 {
     // 256 threads x 16 positions >= BQC_COV_TILE + 1; position p lives at KC_AT(p): 4 words of padding after every 64, so that the
     // 16-byte accesses of the scan (thread t: words 16 t ..) of 16 neighbouring threads fall on 64 different banks
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         for (int q = 0; q < 4; ++q) *(int4*)&diff[KC_AT(s0) + 4 * q] = make_int4(0, 0, 0, 0);
         int32_t off = inc - loc;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += (int32_t)wsum[w];
-        const uint32_t par = parity[tc.lane] & 1u; // flipped by k_cov_flip after every batch that owns tiles of this lane
+        const uint32_t par = parity[tc.lane] & 1u; // flipped by the kernel's epilogue after every batch that owns tiles of this lane
         const uint32_t* cin = carry + ((uint64_t)tc.lane * 2 + par) * 2000;
         uint32_t* cout = carry + ((uint64_t)tc.lane * 2 + (par ^ 1u)) * 2000;
         int32_t run = off;
@@ -118,6 +120,20 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
         }
         if (run_n) atomicAdd(&hist[run_bin], run_n);
     }
+    // Batch epilogue by the workgroup that finishes last (every other one has read its parities by then): the lanes that own
+    // tiles of this batch switch to the other half of the carry array, and the lanes that have seen a coverage read so far
+    // are remembered for the final flush — two tiny kernels less per batch.  (No fence: a workgroup's parity loads have returned
+    // their values before it gets here, and what it wrote is for the next kernel.)
+    block_sync();
+    if (threadIdx.x == 0) wsum[0] = atomicAdd(parity + n_lanes, 1u) == gridDim.x - 1u ? 1u : 0u;
+    block_sync();
+    if (wsum[0]) {
+        for (uint32_t l = threadIdx.x; l < n_lanes; l += blockDim.x) {
+            if (lane_mask[l]) parity[l] ^= 1u;
+            if (started_after[l]) started[l] = 1;
+        }
+        if (threadIdx.x == 0) parity[n_lanes] = 0u;
+    }
 }
 
 // end of stream: histogram the two live windows of every started lane (bamqualcheck.cpp:447-453)
@@ -140,12 +156,6 @@ __global__ __launch_bounds__(256) void k_cov_final(StateLayout sl, uint64_t* __r
     if (threadIdx.x == 0) gadd(state + sl.lane_base(lane) + sl.o_covstart, 1);
 }
 
-__global__ void k_cov_flip(uint32_t* __restrict__ parity, const uint8_t* __restrict__ lane_mask, uint32_t n_lanes)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n_lanes && lane_mask[l]) parity[l] ^= 1u;
-}
-
 __global__ void k_or_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,17 +168,12 @@ __global__ void k_add_words(uint64_t* __restrict__ state, const uint64_t* __rest
     if (i < n) gadd(state + idx[i], val[i]);
 }
 
-extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_t* state, uint32_t* carry, const uint32_t* parity,
-                               hipStream_t s)
+extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_t* state, uint32_t* carry, uint32_t* parity, const uint8_t* lane_mask,
+                               uint8_t* started, const uint8_t* started_after, uint32_t n_lanes, hipStream_t s)
 {
     if (b.n_cov_tiles == 0) return;
     const uint32_t grid = b.n_cov_tiles < 2048u ? b.n_cov_tiles : 2048u; // persistent workgroups, ~8 per CU
-    hipLaunchKernelGGL(k_cov, dim3(grid), dim3(256), 0, s, b, sl, state, carry, parity);
-}
-
-extern "C" void bqc_launch_cov_flip(uint32_t* parity, const uint8_t* lane_mask, uint32_t n_lanes, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_cov_flip, dim3((n_lanes + 255) / 256), dim3(256), 0, s, parity, lane_mask, n_lanes);
+    hipLaunchKernelGGL(k_cov, dim3(grid), dim3(256), 0, s, b, sl, state, carry, parity, lane_mask, started, started_after, n_lanes);
 }
 
 extern "C" void bqc_launch_cov_final(const StateLayout& sl, uint64_t* state, const uint32_t* carry, const uint32_t* parity,
