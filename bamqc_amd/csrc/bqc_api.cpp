@@ -85,6 +85,7 @@ struct bqc_ctx {
     uint32_t t8_rows_lane = 0;
     std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
+    void* prep_cache = nullptr;   // Prep of the last upload: its vectors are reused (bqc_upload)
     uint32_t* d_parity = nullptr; // [lane], then the count of finished workgroups of the running k_cov
     uint8_t* d_started = nullptr; // [lane]
     // references
@@ -227,8 +228,10 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     return 0;
 }
 
+static void free_prep_cache(void* p);
 extern "C" void bqc_destroy(bqc_ctx* c)
 {
+    if (c) { free_prep_cache(c->prep_cache); c->prep_cache = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -281,8 +284,27 @@ struct Prep {
     uint64_t seq_bytes = 0, qual_bytes = 0, cigar_words = 0;
     bool identity = true;
     uint32_t long_max_len = 0;
+    // scratch of the pre-pass (kept with the context from batch to batch: ~100 MB that would otherwise be mapped, faulted in
+    // and unmapped for every batch)
+    std::vector<int8_t> elig;
+    std::vector<uint8_t> cand;
+    std::vector<uint32_t> run_c, np;
+    std::vector<uint64_t> run_len;
+    std::vector<std::vector<CovEntry>> lane_list;
+    std::vector<std::vector<uint32_t>> lane_win, lane_ewin;
+    void reset()
+    {
+        flag.clear(); seq_off.clear(); qual_off.clear(); cigar_off.clear(); perm.clear(); cov_list.clear(); chunks.clear(); chunks_fast.clear();
+        segs.clear(); tiles.clear(); lane_mask.clear(); add_idx.clear(); add_val.clear();
+        fast_w = 10; seq_bytes = qual_bytes = cigar_words = 0; identity = true; long_max_len = 0;
+        np.clear();
+        for (auto& v : lane_list) v.clear();
+        for (auto& v : lane_win) v.clear();
+        for (auto& v : lane_ewin) v.clear();
+    }
 };
 }
+static void free_prep_cache(void* p) { delete (Prep*)p; }
 
 // checkFlagsAndQuality (TripletCounting.hpp:136-168): 1 eligible, 0 not, -1 fatal
 static int triplet_eligible(uint32_t flag, uint32_t mapq, int32_t as, const uint32_t* cg, uint32_t ncig)
@@ -309,8 +331,10 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
     P.seq_off.resize(n); P.qual_off.resize(n); P.cigar_off.resize(n);
     P.lane_mask.assign(nl, 0);
     uint64_t so = 0, qo = 0, co = 0;
-    std::vector<std::vector<CovEntry>> lane_list(nl); // covered intervals, in stream order (windows never decrease)
-    std::vector<std::vector<uint32_t>> lane_win(nl), lane_ewin(nl); // first live window per coverage read / per interval
+    auto& lane_list = P.lane_list; // covered intervals, in stream order (windows never decrease)
+    auto& lane_win = P.lane_win;   // first live window per coverage read
+    auto& lane_ewin = P.lane_ewin; // ... per interval
+    lane_list.resize(nl); lane_win.resize(nl); lane_ewin.resize(nl);
     std::vector<uint8_t> started_before(nl);
     for (uint32_t l = 0; l < nl; ++l) {
         started_before[l] = !c->cov[l].first;
@@ -340,10 +364,11 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
     bool multi_lane = false;
     for (unsigned t = 0; t < nt; ++t) multi_lane |= tmulti[t] != 0;
     const bool offsets_fit = so <= 0xFFFFFFFFull && qo <= 0xFFFFFFFFull && co <= 0xFFFFFFFFull; // (else: found in read order below)
-    std::vector<int8_t> elig(n);          // triplet_eligible
-    std::vector<uint8_t> cand(n);         // 1: enters coverage, one covered run; 2: several runs (walked again in pass 2)
-    std::vector<uint32_t> run_c(n);       // value of `c` at the start of the covered run
-    std::vector<uint64_t> run_len(n);     // its length
+    auto& elig = P.elig;       // triplet_eligible (every element is written by pass 1)
+    auto& cand = P.cand;       // 1: enters coverage, one covered run; 2: several runs (walked again in pass 2)
+    auto& run_c = P.run_c;     // value of `c` at the start of the covered run (valid where cand != 0)
+    auto& run_len = P.run_len; // its length
+    elig.resize(n); cand.resize(n); run_c.resize(n); run_len.resize(n);
     std::vector<PErr> perr(nt);
     parallel_ranges(n, nt, 1, [&](unsigned t, size_t lo, size_t hi) { // (same ranges as pass 0: nt threads, n items)
         uint64_t so_ = tso[t], qo_ = tqo[t], co_ = tco[t];
@@ -507,7 +532,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         const uint32_t rpw = 64u / P.fast_w;           // reads a wave handles at once
         const uint32_t h0 = (rpw + 1) / 2, h1 = rpw / 2; // slots per mate
         const uint32_t groups_cap = BQC_FAST_WAVES * (64u / rpw); // groups per chunk: one tile of whole groups per wave of k_short
-        std::vector<uint32_t> np;
+        auto& np = P.np;
         np.reserve(n + n / 4);
         std::vector<uint32_t> q[2];    // reads of the current fast chunk per mate, in stream order
         std::vector<uint32_t> win_seg; // their triplet segments (indices into P.segs)
@@ -658,7 +683,9 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     if (c->poisoned) return fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
     if (c->flushed) return fail(c, BQC_ERR_STATE, "bqc_upload after bqc_flush/bqc_finalize (call bqc_reset first)");
     HIPCHK(c, hipSetDevice(c->device));
-    Prep P;
+    if (!c->prep_cache) c->prep_cache = new Prep();
+    Prep& P = *(Prep*)c->prep_cache;
+    P.reset();
     const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '2';
     const auto t0 = std::chrono::steady_clock::now();
     int rc = prepass(c, b, P);
