@@ -34,7 +34,7 @@ static inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] <
 bool BamReader::fill(size_t need, std::string& err)
 {
     while (buf_.size() - cur_ < need) {
-        if (eof_) return false;
+        if (eof_) { if (!sticky_err_.empty()) err = sticky_err_; return false; }
         if (cur_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + cur_); cur_ = 0; }
         std::string e;
         const auto w0 = std::chrono::steady_clock::now();
@@ -43,7 +43,7 @@ bool BamReader::fill(size_t need, std::string& err)
         t_wait_ += std::chrono::duration<double>(w1 - w0).count();
         if (!got) {
             eof_ = true;
-            if (!e.empty()) { err = e; return false; }
+            if (!e.empty()) { sticky_err_ = e; err = e; return false; }
             continue;
         }
         if (buf_.capacity() < buf_.size() + chunk_.size()) { // grow rarely and far: reallocation copies the whole batch read so far
@@ -119,6 +119,113 @@ struct RecErr { size_t index = SIZE_MAX; std::string msg; int code = 0; };
 
 } // namespace
 
+// ---- parallel record walk ---------------------------------------------------------------------------------------------
+// The block_size chain is a dependent walk (~45 ns per record: one cache miss each).  With the batch's bytes already in the
+// buffer it is split into segments walked by several threads: every thread but the first has to GUESS where a record
+// starts in its segment (the first offset at which three records in a row look like records) — a guess that is only used
+// if the walk of the previous segment ends exactly there; otherwise that segment is walked again from the known position.
+// The result is the serial walk's, whatever the data.
+static inline bool plausible_record(const uint8_t* base, size_t avail, size_t p, int32_t n_ref, size_t& next)
+{
+    if (p + 36 > avail) return false;
+    const uint32_t bs = rd32(base + p);
+    if (bs < 32 || bs > (1u << 28)) return false;
+    const uint8_t* r = base + p + 4;
+    const int32_t rid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4), rnext = (int32_t)rd32(r + 20), pnext = (int32_t)rd32(r + 24);
+    if (rid < -1 || rid >= n_ref || rnext < -1 || rnext >= n_ref || pos < -1 || pnext < -1) return false;
+    const uint32_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+    if (l_name == 0 || l_seq > (1u << 28)) return false;
+    const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+    if (var > bs) return false;
+    if (p + 4 + 32 + l_name <= avail && r[32 + l_name - 1] != 0) return false; // read name is NUL-terminated
+    next = p + 4 + (size_t)bs;
+    return true;
+}
+
+void BamReader::walk_segment(const uint8_t* base, size_t avail, size_t a, size_t b, bool exact_start, WalkSeg& out) const
+{
+    out.recs.clear();
+    out.n_all = 0;
+    size_t p = a;
+    if (!exact_start) {
+        const int32_t n_ref = (int32_t)hdr_.ref_names.size();
+        for (; p < b; ++p) {
+            size_t q1, q2, q3;
+            if (plausible_record(base, avail, p, n_ref, q1) && plausible_record(base, avail, q1, n_ref, q2) && plausible_record(base, avail, q2, n_ref, q3)) break;
+        }
+        static const bool skew = getenv("BQC_TEST_WALK_SKEW") != nullptr; // tests: make every guess wrong (start at the second record found)
+        if (skew && p < b) { size_t q; if (plausible_record(base, avail, p, n_ref, q)) p = q; }
+        if (p >= b) { out.first = out.end = SIZE_MAX; return; }
+    }
+    out.first = p;
+    while (p < b) {
+        if (p + 36 > avail) break;
+        const uint32_t bs = rd32(base + p);
+        if (bs < 32) break; // (the serial walk reports it when it gets here)
+        const uint8_t* r = base + p + 4;
+        const int32_t rid = (int32_t)rd32(r);
+        const uint32_t l_name = r[8], n_cig = rd16(r + 12), l_seq = rd32(r + 16);
+        const size_t var = 32 + (size_t)l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq;
+        if (var > bs || p + 4 + (size_t)bs > avail) break;
+        bool keep = true;
+        if (filter_) keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
+        if (keep) out.recs.push_back(Rec{p, bs, l_seq, n_cig, 0, 0, 0, out.n_all});
+        ++out.n_all;
+        p += 4 + (size_t)bs;
+    }
+    out.end = p;
+}
+
+void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel, size_t& bases, size_t& so, size_t& qo, size_t& co)
+{
+    const unsigned T = std::min(16u, bg_.threads());
+    if (avg_rec_bytes_ <= 0 || T < 2 || max_reads < 65536) return;
+    {
+        const double want = std::min((double)max_reads * avg_rec_bytes_ * 1.02, 3.0e9);
+        std::string e;
+        (void)fill((size_t)want, e); // best effort: at the end of the file (or a damaged block) less is there
+    }
+    const size_t avail = buf_.size() - cur_;
+    if (avail < ((size_t)T << 22)) return;
+    const uint8_t* base = buf_.data() + cur_;
+    if (segs_.size() < T) segs_.resize(T);
+    const size_t step = avail / T;
+    parallel_ranges(T, T, 1, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; ++t) walk_segment(base, avail, t * step, t + 1 == T ? avail : (t + 1) * step, t == 0, segs_[t]);
+    });
+    std::vector<Rec>& recs = recs_;
+    size_t pos = 0;
+    uint64_t n_all = 0;
+    for (unsigned t = 0; t < T; ++t) {
+        const size_t b = t + 1 == T ? avail : (t + 1) * step;
+        WalkSeg& S = segs_[t];
+        if (S.first != pos) { // the guess was not where the chain arrives: this segment again, from the known position
+            if (pos < b) walk_segment(base, avail, pos, b, true, S);
+            else { S.recs.clear(); S.n_all = 0; S.first = S.end = pos; }
+        }
+        for (const Rec& r : S.recs) { recs.push_back(r); recs.back().nrec = nrec_ + n_all + r.nrec; }
+        n_all += S.n_all;
+        pos = S.end;
+        if (pos < b) break; // an incomplete or invalid record: the serial walk continues (and reports) from here
+    }
+    // the batch's limits and the payload offsets, in record order
+    size_t n_take = 0;
+    for (; n_take < recs.size() && n_take < max_reads && bases < max_bases; ++n_take) {
+        Rec& r = recs[n_take];
+        r.so = so; r.qo = qo; r.co = co;
+        so += (r.l_seq + 1) / 2; qo += r.l_seq; co += r.n_cig;
+        bases += r.l_seq;
+    }
+    if (n_take < recs.size()) { // a limit was reached inside the window: the rest is walked again by the next batch
+        recs.resize(n_take);
+        rel = n_take ? recs.back().off + 4 + (size_t)recs.back().bs : 0;
+        nrec_ = n_take ? recs.back().nrec + 1 : nrec_;
+    } else {
+        rel = pos;
+        nrec_ += n_all;
+    }
+}
+
 // Decoding is done in two steps so that it can use every host core: (1) a serial walk over the block_size chain that
 // finds the record boundaries and fixes where every record's seq / qual / CIGAR goes in the batch (prefix sums);
 // (2) the records are decoded into the columns in parallel (tag scan, copies).  Unknown RG ids (std::map::operator[]
@@ -129,12 +236,14 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     err_code = 0;
     static const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '3';
     const auto t0 = std::chrono::steady_clock::now();
-    struct Rec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; }; // off: relative to cur_
-    std::vector<Rec> recs;
+    std::vector<Rec>& recs = recs_;
+    recs.clear();
     recs.reserve(std::min<size_t>(max_reads, 1u << 20));
     size_t bases = 0, so = 0, qo = 0, co = 0;
     size_t rel = 0; // bytes of this batch walked so far; cur_ stays at the batch start, so fill() never drops them
     bool io_error = false;
+    const uint64_t nrec_at_start = nrec_;
+    parallel_prewalk(max_reads, max_bases, rel, bases, so, qo, co); // (does nothing for the first batch: record size unknown)
     while (recs.size() < max_reads && bases < max_bases) {
         // fast path: the whole record is already in the buffer (fill() is only called when it is not)
         size_t avail = buf_.size() - cur_;
@@ -164,6 +273,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         rel += 4 + (size_t)bs;
         ++nrec_;
     }
+    if (nrec_ > nrec_at_start) avg_rec_bytes_ = (double)rel / (double)(nrec_ - nrec_at_start);
     const auto t1 = std::chrono::steady_clock::now();
     const size_t n = recs.size();
     o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);

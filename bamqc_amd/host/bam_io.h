@@ -67,6 +67,14 @@ private:
     BgzfReader bg_;
     BamHeader hdr_;
     raw_vector<uint8_t> buf_, chunk_;
+    struct Rec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; }; // a record found by the walk; off: relative to cur_
+    std::vector<Rec> recs_; // (kept from batch to batch: 64 MB per million records)
+    struct WalkSeg { size_t first = 0, end = 0; uint64_t n_all = 0; std::vector<Rec> recs; };
+    std::vector<WalkSeg> segs_;
+    void walk_segment(const uint8_t* base, size_t avail, size_t a, size_t b, bool exact_start, WalkSeg& out) const;
+    void parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel, size_t& bases, size_t& so, size_t& qo, size_t& co);
+    double avg_rec_bytes_ = 0;  // bytes per record of the previous batch (0: unknown)
+    std::string sticky_err_;    // error of the inflating reader, reported whenever more data is asked for
     size_t cur_ = 0;
     bool eof_ = false;
     std::vector<uint8_t> main_, keep_;

@@ -252,3 +252,32 @@ def test_wild_records_and_tags_decode(tmp_path):
             extra += [(int(r) + base, int(v)) for r, v in zip(b["nm_extra_read"], b["nm_extra_val"])]
         base += len(b["flag"])
     assert extra == exp_extra
+
+
+def test_parallel_record_walk_equals_the_serial_walk(tmp_path):
+    """Batches of a 120 MB stream read with one thread (serial block_size walk), with several (segments walked in parallel from
+    guessed record starts) and with every guess forced wrong (each segment walked again from the position the chain
+    arrives at): same batch sizes, same bytes in every column, with and without a contig filter."""
+    import hashlib, subprocess, sys, textwrap
+    bam, fa = str(tmp_path / "p.bam"), str(tmp_path / "p.fa")
+    hostio.synth_write(bam, fa, seed=11, n_reads=400_000, ref_names=["chr1", "chr2", "chr3"], ref_lens=[900_000, 600_000, 300_000], n_lanes=2)
+    prog = textwrap.dedent("""
+        import sys, hashlib, numpy as np
+        sys.path.insert(0, %r)
+        from bamqc_amd import hostio
+        for filt in (False, True):
+            f = hostio.BamFile(%r)
+            f.set_main_chrom(np.ones(3, np.uint8))
+            if filt: f.set_rid_filter(np.array([1, 0, 1], np.uint8), False)
+            h, sizes = hashlib.sha256(), []
+            for b in f.batches(max_reads=100_000):
+                sizes.append(len(b["flag"]))
+                for k in sorted(b): h.update(np.ascontiguousarray(b[k]).tobytes())
+            print(sizes, h.hexdigest())
+        """) % (ROOT, bam)
+    outs = []
+    for env in ({"BQC_IO_THREADS": "1"}, {"BQC_IO_THREADS": "4"}, {"BQC_IO_THREADS": "4", "BQC_TEST_WALK_SKEW": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and "[100000, 100000, 100000, 100000]" in outs[0]

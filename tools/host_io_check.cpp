@@ -10,7 +10,7 @@ int main(int argc, char** argv)
         if (!rd.open(argv[a], err)) { printf("%s: open failed: %s\n", argv[a], err.c_str()); continue; }
         rd.set_main_chrom(std::vector<uint8_t>(rd.header().ref_names.size(), 1));
         HostBatch hb; size_t n = 0; int code = 0, rc;
-        while ((rc = rd.next_batch(hb, 50000, 1 << 26, err, code)) > 0) n += hb.n();
+        while ((rc = rd.next_batch(hb, 100000, 1 << 26, err, code)) > 0) n += hb.n();
         printf("%s: %zu records rc %d %s\n", argv[a], n, rc, rc < 0 ? err.c_str() : "");
     }
 }
