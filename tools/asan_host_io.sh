@@ -14,6 +14,7 @@ from tests import pybam
 from tests.test_host_io import _wild_bam
 T = sys.argv[1]
 hostio.synth_write(T + "/a.bam", T + "/a.fa", 3, 60000, ["chr1", "chr2"], [300000, 200000], n_lanes=2)
+hostio.synth_write(T + "/big.bam", T + "/big.fa", 4, 400000, ["chr1", "chr2"], [900000, 600000], n_lanes=2)  # large enough for the parallel record walk
 _wild_bam(T + "/w.bam", 5, 3000)
 rng = random.Random(1)
 data = open(T + "/a.bam", "rb").read()
@@ -40,6 +41,7 @@ for k in range(80):  # damaged records behind valid blocks
             p += n
         f.write(pybam._bgzf_block(b""))
 PY
+BQC_IO_THREADS=4 $T/check $T/big.bam > $T/big1.txt 2>&1 && BQC_IO_THREADS=4 BQC_TEST_WALK_SKEW=1 $T/check $T/big.bam > $T/big2.txt 2>&1 && grep -q "400000 records rc 0" $T/big1.txt && grep -q "400000 records rc 0" $T/big2.txt || { cat $T/big1.txt $T/big2.txt | tail -30; echo "FAILED (parallel record walk)"; exit 1; }
 BQC_IO_THREADS=4 $T/check $T/a.bam $T/w.bam $T/c*.bam $T/r*.bam > $T/out.txt 2>&1 || { cat $T/out.txt | tail -40; echo "FAILED (sanitizer report or crash)"; exit 1; }
 if grep -q "runtime error\|AddressSanitizer" $T/out.txt; then grep -n "runtime error\|AddressSanitizer" $T/out.txt | head; echo FAILED; exit 1; fi
 echo "ok: $(grep -c 'records rc 0' $T/out.txt) files read completely, $(grep -c -v 'records rc 0' $T/out.txt) rejected with an error, no sanitizer report"
