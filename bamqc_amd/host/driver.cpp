@@ -436,6 +436,7 @@ extern "C" int bqc_main(int argc, const char** argv)
         }
     }
     rd.set_main_chrom(main_chrom);
+    const auto t_begin = std::chrono::steady_clock::now(); // (BQC_TIMING=1 also reports the phases around the record loop)
     // BQC_TIMING=1: where the wall time of a run goes (stderr)
     const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
     using clk = std::chrono::steady_clock;
@@ -500,8 +501,10 @@ extern "C" int bqc_main(int argc, const char** argv)
         bo.sketch.n_q = (uint32_t)opt.q_cutoff.size(); bo.sketch.qlist = opt.q_cutoff.data();
         bo.sketch.e = opt.e; bo.sketch.seed = opt.seed;
     }
+    const auto t_fasta = clk::now();
     bqc_ctx* ctx = nullptr;
     int rc = bqc_create(&bo, &ctx);
+    const auto t_create = clk::now();
     if (rc) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(nullptr)); stop_decoder(); return 1; }
     for (uint32_t r = 0; r < n_refs; ++r)
         if (fasta_index[r] >= 0) {
@@ -554,7 +557,9 @@ extern "C" int bqc_main(int argc, const char** argv)
     }
     if (status) { bqc_destroy(ctx); return 1; }
     const bqc_counts* counts = nullptr;
+    const auto t_loop_end = clk::now();
     if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
+    const auto t_final = clk::now();
     // writeOutput iterates laneNames (std::map: lexicographic), including IDs inserted by getLane
     std::vector<const char*> names;
     std::vector<uint32_t> idx;
@@ -565,7 +570,12 @@ extern "C" int bqc_main(int argc, const char** argv)
     hi.lane_names = names.data();
     hi.lane_index = idx.data();
     rc = bqc_write_bamqc(counts, &hi, opt.outputFile.c_str());
+    const auto t_write = clk::now();
     bqc_destroy(ctx);
+    if (timing)
+        fprintf(stderr, "[timing] phases: FASTA %.2f s, context %.2f s, references %.2f s, record loop %.2f s, finalize %.2f s, write %.2f s, destroy %.2f s\n",
+                secs(t_begin, t_fasta), secs(t_fasta, t_create), secs(t_create, t_setup), secs(t_setup, t_loop_end), secs(t_loop_end, t_final), secs(t_final, t_write),
+                secs(t_write, clk::now()));
     if (rc) { fprintf(stderr, "ERROR: Could not write output file %s\n", opt.outputFile.c_str()); return 1; }
     return 0;
 }
