@@ -268,6 +268,7 @@ bool Inflater::run(const uint8_t* in0, size_t in_n, uint8_t* out0, size_t out_n)
                     REFILL();
                 }
             }
+            if (__builtin_expect((e & (E_EXC | E_LIT)) != 0, 0)) { // (a length code of the root table, the common case, tests one flag pair)
             if (e & E_EXC) {
                 if (e & E_SUB) {
                     CONSUME(e & E_BITS);
@@ -287,6 +288,7 @@ bool Inflater::run(const uint8_t* in0, size_t in_n, uint8_t* out0, size_t out_n)
                 out += nl;
                 continue;
             }
+            }
             uint64_t saved = bb;
             CONSUME(e & E_BITS);
             const unsigned length = (e >> 16) + (unsigned)((saved & (((uint64_t)1 << (e & E_BITS)) - 1u)) >> ((e >> 8) & 15u));
@@ -300,7 +302,7 @@ bool Inflater::run(const uint8_t* in0, size_t in_n, uint8_t* out0, size_t out_n)
             saved = bb;
             CONSUME(d & E_BITS);
             const size_t dist = (d >> 16) + (size_t)((saved & (((uint64_t)1 << (d & E_BITS)) - 1u)) >> ((d >> 8) & 15u));
-            if (dist > (size_t)(out - out0) || length > (size_t)(out_end - out)) return false;
+            if (dist > (size_t)(out - out0) || (!fast && length > (size_t)(out_end - out))) return false; // (fast: room for any match)
             const uint8_t* src = out - dist;
             if (fast) {
                 REFILL(); // the next symbol's table entry is fetched while the bytes are copied
