@@ -47,7 +47,7 @@ bool BamReader::fill(size_t need, std::string& err)
             continue;
         }
         if (buf_.capacity() < buf_.size() + chunk_.size()) { // grow rarely and far: reallocation copies the whole batch read so far
-            try { buf_.reserve(std::max<size_t>(768u << 20, 2 * (buf_.size() + chunk_.size()))); } catch (const std::bad_alloc&) {}
+            try { buf_.reserve(std::max<size_t>(768u << 20, 2 * (buf_.size() + chunk_.size()))); advise_huge(buf_); } catch (const std::bad_alloc&) {}
         }
         { // append the run: a plain copy of ~100 MB, split over a few threads (one thread manages ~10 GB/s)
             const size_t at = buf_.size(), n = chunk_.size();
@@ -278,7 +278,12 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     const size_t n = recs.size();
     o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);
     o.nm.resize(n); o.as.resize(n); o.l_seq.resize(n); o.n_cigar.resize(n);
-    o.seq.resize(so); o.qual.resize(qo); o.cigar.resize(co);
+    { // (batches are recycled: the capacities settle after the first ones)
+        const size_t c1 = o.seq.capacity(), c2 = o.qual.capacity();
+        o.seq.resize(so); o.qual.resize(qo); o.cigar.resize(co);
+        if (o.seq.capacity() != c1) advise_huge(o.seq);
+        if (o.qual.capacity() != c2) advise_huge(o.qual);
+    }
     const unsigned nt_max = bg_.threads();
     std::vector<RecErr> errs(nt_max);
     std::vector<std::vector<std::pair<uint32_t, int32_t>>> extra(nt_max);          // further NM tags: (read, value)

@@ -125,7 +125,7 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
         p += bsize;
     }
     if (eof_ && p != raw_.size()) { err = "truncated BGZF file"; return false; }
-    out.resize(utotal);
+    { const size_t cap = out.capacity(); out.resize(utotal); if (out.capacity() != cap) advise_huge(out); }
     std::atomic<bool> bad{false};
     parallel_for(blocks.size(), threads_, [&](size_t i) {
         const BlockRef& b = blocks[i];
