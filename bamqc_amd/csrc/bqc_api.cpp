@@ -17,6 +17,7 @@
 #include "../../include/bamqc.h"
 #include "device_types.h"
 #include "../host/parallel.h"
+#include "../host/raw_vector.h"
 #include "sketch.h"
 
 extern "C" {
@@ -327,8 +328,11 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
     const uint32_t nl = c->opt.n_lanes;
     const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '2';
     const auto tp0 = std::chrono::steady_clock::now();
-    P.flag.resize(n);
-    P.seq_off.resize(n); P.qual_off.resize(n); P.cigar_off.resize(n);
+    // (these vectors are kept with the context: when one has to grow it asks for huge pages before it is touched)
+    auto grow = [](auto& v, size_t k) { const size_t cap = v.capacity(); v.resize(k); if (v.capacity() != cap) advise_huge(v); };
+    auto room = [](auto& v, size_t k) { const size_t cap = v.capacity(); v.reserve(k); if (v.capacity() != cap) advise_huge(v); };
+    grow(P.flag, n);
+    grow(P.seq_off, n); grow(P.qual_off, n); grow(P.cigar_off, n);
     P.lane_mask.assign(nl, 0);
     uint64_t so = 0, qo = 0, co = 0;
     auto& lane_list = P.lane_list; // covered intervals, in stream order (windows never decrease)
@@ -368,7 +372,8 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
     auto& cand = P.cand;       // 1: enters coverage, one covered run; 2: several runs (walked again in pass 2)
     auto& run_c = P.run_c;     // value of `c` at the start of the covered run (valid where cand != 0)
     auto& run_len = P.run_len; // its length
-    elig.resize(n); cand.resize(n); run_c.resize(n); run_len.resize(n);
+    grow(elig, n); grow(cand, n); grow(run_c, n); grow(run_len, n);
+    for (uint32_t l = 0; l < nl && nl <= 4; ++l) { room(lane_list[l], n); room(lane_win[l], n); room(lane_ewin[l], n); } // (a few read groups: no regrowth in pass 2)
     std::vector<PErr> perr(nt);
     parallel_ranges(n, nt, 1, [&](unsigned t, size_t lo, size_t hi) { // (same ranges as pass 0: nt threads, n items)
         uint64_t so_ = tso[t], qo_ = tqo[t], co_ = tco[t];
@@ -533,7 +538,7 @@ static int prepass(bqc_ctx* c, const bqc_batch* b, Prep& P)
         const uint32_t h0 = (rpw + 1) / 2, h1 = rpw / 2; // slots per mate
         const uint32_t groups_cap = BQC_FAST_WAVES * (64u / rpw); // groups per chunk: one tile of whole groups per wave of k_short
         auto& np = P.np;
-        np.reserve(n + n / 4);
+        room(np, n + n / 4); room(P.perm, n + n / 4); // (the two swap roles at the end)
         std::vector<uint32_t> q[2];    // reads of the current fast chunk per mate, in stream order
         std::vector<uint32_t> win_seg; // their triplet segments (indices into P.segs)
         uint32_t wlane = 0;
