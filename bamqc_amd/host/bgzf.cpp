@@ -97,7 +97,7 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
     const size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
     // keep the tail of the previous round (a partial block) at the front of raw_
     size_t have = raw_.size();
-    raw_.resize(have + want);
+    { const size_t cap = raw_.capacity(); raw_.resize(have + want); if (raw_.capacity() != cap) advise_huge(raw_); }
     size_t got = fread(raw_.data() + have, 1, want, f_);
     cbytes_ += got;
     raw_.resize(have + got);

@@ -20,6 +20,7 @@
 
 #include "../../include/bamqc_host.h"
 #include "bam_io.h"
+#include "raw_vector.h"
 #include "crc32_fast.h"
 #include "inflate_fast.h"
 #include "host_tools.h"

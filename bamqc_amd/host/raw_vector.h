@@ -17,10 +17,13 @@ template <typename T> using raw_vector = std::vector<T, no_init_alloc<T>>;
 // capacity and before the memory is touched; a no-op for small buffers and elsewhere.
 #include <sys/mman.h>
 #include <cstdint>
+#include <cstdlib>
 template <typename V>
 inline void advise_huge(V& v)
 {
 #if defined(MADV_HUGEPAGE)
+    static const bool off = getenv("BQC_NO_HUGEPAGES") != nullptr; // (on a badly fragmented host a huge-page fault may stall in compaction)
+    if (off) return;
     const size_t bytes = v.capacity() * sizeof(typename V::value_type);
     if (bytes < (8u << 20)) return;
     const uintptr_t a = ((uintptr_t)v.data() + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), z = ((uintptr_t)v.data() + bytes) & ~(uintptr_t)((2u << 20) - 1);
