@@ -181,7 +181,9 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
     const unsigned T = std::min(16u, bg_.threads());
     if (avg_rec_bytes_ <= 0 || T < 2 || max_reads < 65536) return;
     {
-        const double want = std::min((double)max_reads * avg_rec_bytes_ * 1.02, 3.0e9);
+        // records this batch will hold: its read limit or, for long reads, its base limit
+        const double n_exp = std::min((double)max_reads, avg_rec_bases_ > 0 ? (double)max_bases / avg_rec_bases_ + 1.0 : (double)max_reads);
+        const double want = std::min(n_exp * avg_rec_bytes_ * 1.02, 3.0e9);
         std::string e;
         (void)fill((size_t)want, e); // best effort: at the end of the file (or a damaged block) less is there
     }
@@ -273,7 +275,10 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         rel += 4 + (size_t)bs;
         ++nrec_;
     }
-    if (nrec_ > nrec_at_start) avg_rec_bytes_ = (double)rel / (double)(nrec_ - nrec_at_start);
+    if (nrec_ > nrec_at_start) {
+        avg_rec_bytes_ = (double)rel / (double)(nrec_ - nrec_at_start);
+        avg_rec_bases_ = recs.empty() ? 0.0 : (double)bases / (double)recs.size();
+    }
     const auto t1 = std::chrono::steady_clock::now();
     const size_t n = recs.size();
     o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);

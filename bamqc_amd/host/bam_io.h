@@ -73,7 +73,7 @@ private:
     std::vector<WalkSeg> segs_;
     void walk_segment(const uint8_t* base, size_t avail, size_t a, size_t b, bool exact_start, WalkSeg& out) const;
     void parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel, size_t& bases, size_t& so, size_t& qo, size_t& co);
-    double avg_rec_bytes_ = 0;  // bytes per record of the previous batch (0: unknown)
+    double avg_rec_bytes_ = 0, avg_rec_bases_ = 0; // bytes / bases per record of the previous batch (0: unknown)
     std::string sticky_err_;    // error of the inflating reader, reported whenever more data is asked for
     size_t cur_ = 0;
     bool eof_ = false;

@@ -91,3 +91,15 @@ def test_wild_bam_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr
     assert oracle_bamqualcheck(bam, fa, want, isize=2000, klist=(8, 32), qlist=(17,), batch_reads=999) == 0
     assert filecmp.cmp(got, want, shallow=False)
+
+
+def test_long_reads_end_to_end_batches_cut_by_bases(tmp_path):
+    """10 kb reads through the program with a small base limit per batch: batches end on the base limit, the reader's
+    parallel record walk sizes its window from bases per record; output equals the oracle's."""
+    bam, fa = str(tmp_path / "l.bam"), str(tmp_path / "l.fa")
+    hostio.synth_write(bam, fa, seed=5, n_reads=40_000, ref_names=["chr1", "chr2"], ref_lens=[3_000_000, 2_000_000], read_len=10_000, long_reads=True)
+    got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
+    r = run_cli("-r", fa, "-o", got, "-c", "chr1,chr2", "--no-sketch", "--max-read-len", "65536", bam)
+    assert r.returncode == 0, r.stderr
+    assert oracle_bamqualcheck(bam, fa, want, chroms="chr1,chr2", klist=(), qlist=(), batch_reads=5000) == 0
+    assert filecmp.cmp(got, want, shallow=False)
