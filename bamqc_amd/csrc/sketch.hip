@@ -18,6 +18,7 @@
 
 #include "kernels_common.h"
 #include "sketch.h"
+#include <ctime>
 
 namespace {
 struct u128 { uint64_t hi, lo; };
@@ -352,7 +353,6 @@ __global__ void k_sketch_import(DevSketch D, const uint64_t* __restrict__ src, u
 // ---------------------------------------------------------------------------------------------------
 SketchDevice* sketch_create(const bqc_sketch_options& so, uint32_t n_lanes, hipStream_t s, std::string& err)
 {
-    if (so.seed == 0) { err = "seed 0 (time based) is not reproducible; pass -s <nonzero>"; return nullptr; }
     if (!(so.e > 0)) { err = "error rate must be > 0"; return nullptr; }
     auto* sk = new SketchDevice();
     sk->so = so;
@@ -370,7 +370,9 @@ SketchDevice* sketch_create(const bqc_sketch_options& so, uint32_t n_lanes, hipS
     if (sk->f2size != SK_F2) { err = "only error rates with a 32768-entry F2 table (e.g. the default 0.01) are supported on the GPU"; delete sk; return nullptr; }
     // character tables
     std::vector<uint64_t> hv((size_t)sk->n_pairs * 128);
-    MT mt((uint32_t)so.seed);
+    // seed 0: RepHash::seed(0) takes (int)time(NULL) (RepHash.cpp:5-7; ReadQualityHasher.hpp:16-18 leaves the default-constructed,
+    // time-seeded table in place) — the sketch lines then differ from run to run, as the reference's do
+    MT mt((uint32_t)(so.seed != 0 ? so.seed : (int32_t)time(nullptr)));
     u128 base[32];
     for (int i = 0; i < 32; ++i) { // (randInt()<<32)|randInt(): g++ evaluates the left operand first (pinned in tests)
         uint64_t a = mt.rand_int(), b = mt.rand_int(), c = mt.rand_int(), d = mt.rand_int();

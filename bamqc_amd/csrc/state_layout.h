@@ -7,7 +7,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BQC_HD __host__ __device__
 #else
 #define BQC_HD

@@ -636,3 +636,56 @@ bool BamWriter::write_batch(const bqc_batch& b, const std::vector<std::string>& 
     }
     return true;
 }
+
+bool BamWriter::write_batch_parallel(const bqc_batch& b, const std::vector<std::string>& lane_ids, uint64_t first)
+{
+    const size_t n = b.n_reads;
+    // pass 1 (serial, a few ns per read): where every record and its payload start
+    at_.resize(3 * (n + 1));
+    uint64_t* rec_at = at_.data();
+    uint64_t* so_at = rec_at + n + 1;
+    uint64_t* co_at = so_at + n + 1;
+    auto digits = [](uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+    uint64_t at = 0, so = 0, qo = 0, co = 0;
+    std::vector<uint64_t> qo_at(n + 1);
+    for (size_t i = 0; i < n; ++i) {
+        rec_at[i] = at; so_at[i] = so; qo_at[i] = qo; co_at[i] = co;
+        const uint32_t L = b.l_seq[i], nc = b.n_cigar[i];
+        at += 4 + 32 + (1 + digits(first + i) + 1) + 4ull * nc + (L + 1) / 2 + L + (3 + lane_ids[b.lane[i]].size() + 1) +
+              (b.nm[i] != BQC_NM_ABSENT ? 7 : 0) + (b.as[i] != BQC_AS_ABSENT ? 7 : 0);
+        so += (L + 1) / 2; qo += L; co += nc;
+    }
+    rec_at[n] = at;
+    big_.resize(at);
+    parallel_ranges(n, bqc_host_threads(), 4096, [&](unsigned, size_t lo, size_t hi) {
+        auto w32 = [](uint8_t* p, uint32_t x) { p[0] = x & 0xFF; p[1] = (x >> 8) & 0xFF; p[2] = (x >> 16) & 0xFF; p[3] = (x >> 24) & 0xFF; };
+        auto w16 = [](uint8_t* p, uint32_t x) { p[0] = x & 0xFF; p[1] = (x >> 8) & 0xFF; };
+        for (size_t i = lo; i < hi; ++i) {
+            uint8_t* r = big_.data() + rec_at[i];
+            const uint32_t L = b.l_seq[i], nc = b.n_cigar[i];
+            const uint32_t* cg = b.cigar + co_at[i];
+            int64_t reflen = 0;
+            for (uint32_t k = 0; k < nc; ++k) { const uint32_t op = cg[k] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += cg[k] >> 4; }
+            char name[32];
+            const int nl = snprintf(name, sizeof name, "r%llu", (unsigned long long)(first + i)) + 1;
+            w32(r, (uint32_t)(rec_at[i + 1] - rec_at[i] - 4));
+            w32(r + 4, (uint32_t)b.rid[i]); w32(r + 8, (uint32_t)b.pos[i]);
+            r[12] = (uint8_t)nl; r[13] = b.mapq[i];
+            w16(r + 14, b.pos[i] >= 0 ? reg2bin(b.pos[i], b.pos[i] + (reflen ? reflen : 1)) : 4680);
+            w16(r + 16, nc); w16(r + 18, b.flag[i] & 0x0FFFu);
+            w32(r + 20, L); w32(r + 24, (uint32_t)b.rid[i]); w32(r + 28, (uint32_t)b.pos[i]); w32(r + 32, (uint32_t)b.tlen[i]);
+            uint8_t* q = r + 36;
+            memcpy(q, name, (size_t)nl); q += nl;
+            for (uint32_t k = 0; k < nc; ++k, q += 4) w32(q, cg[k]);
+            memcpy(q, b.seq + so_at[i], (L + 1) / 2); q += (L + 1) / 2;
+            memcpy(q, b.qual + qo_at[i], L); q += L;
+            const std::string& rg = lane_ids[b.lane[i]];
+            *q++ = 'R'; *q++ = 'G'; *q++ = 'Z';
+            memcpy(q, rg.data(), rg.size()); q += rg.size();
+            *q++ = 0;
+            if (b.nm[i] != BQC_NM_ABSENT) { *q++ = 'N'; *q++ = 'M'; *q++ = 'i'; w32(q, (uint32_t)b.nm[i]); q += 4; }
+            if (b.as[i] != BQC_AS_ABSENT) { *q++ = 'A'; *q++ = 'S'; *q++ = 'i'; w32(q, (uint32_t)b.as[i]); q += 4; }
+        }
+    });
+    return bg_.write(big_.data(), big_.size());
+}

@@ -111,9 +111,13 @@ public:
               const std::vector<uint32_t>& ref_lens, std::string& err, int level = 1);
     // writes every read of the batch; tags: RG:Z:<lane_ids[lane]>, NM:i (if present), AS:i (if present)
     bool write_batch(const bqc_batch& b, const std::vector<std::string>& lane_ids, uint64_t first_read_index);
+    // the same bytes, with the records serialised by all host threads (for the streaming generator)
+    bool write_batch_parallel(const bqc_batch& b, const std::vector<std::string>& lane_ids, uint64_t first_read_index);
     bool close() { return bg_.close(); }
 
 private:
     BgzfWriter bg_;
     std::vector<uint8_t> rec_;
+    raw_vector<uint8_t> big_;
+    std::vector<uint64_t> at_;
 };

@@ -112,10 +112,12 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
         size_t bsize = 0, x = 12;
         while (x + 4 <= 12 + xlen) {
             const size_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (x + 4 + slen > 12 + xlen) { err = "corrupt BGZF block (extra subfield runs past the extra field)"; return false; }
             if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
             x += 4 + slen;
         }
         if (!bsize) { err = "BGZF block without BC extra field"; return false; }
+        if (bsize < 12 + xlen + 8) { err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; return false; } // (else csize underflows, the trailer lies before the block)
         if (p + bsize > raw_.size()) break;
         const uint8_t* t = raw_.data() + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
@@ -178,26 +180,35 @@ static size_t compress_block(const uint8_t* src, size_t n, uint8_t* dst, int lev
     }
     const size_t bsize = 18 + clen + 8;
     dst[16] = (uint8_t)((bsize - 1) & 0xFF); dst[17] = (uint8_t)((bsize - 1) >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+    const uint32_t crc = bqc_crc32_fast(src, n);
     uint8_t* t = dst + 18 + clen;
     t[0] = crc & 0xFF; t[1] = (crc >> 8) & 0xFF; t[2] = (crc >> 16) & 0xFF; t[3] = (crc >> 24) & 0xFF;
     t[4] = n & 0xFF; t[5] = (n >> 8) & 0xFF; t[6] = (n >> 16) & 0xFF; t[7] = (n >> 24) & 0xFF;
     return bsize;
 }
 
-bool BgzfWriter::flush_pending(bool all)
+// compresses the whole blocks of [p, p + n) (and the last partial one when `all`) in parallel and writes them; returns the bytes consumed
+size_t BgzfWriter::put_blocks(const uint8_t* p, size_t n, bool all)
 {
-    const size_t nblk = all ? (pend_.size() + kWriteBlock - 1) / kWriteBlock : pend_.size() / kWriteBlock;
-    if (!nblk) return true;
-    std::vector<uint8_t> out(nblk * kMaxBlock);
+    const size_t nblk = all ? (n + kWriteBlock - 1) / kWriteBlock : n / kWriteBlock;
+    if (!nblk) return 0;
+    out_.resize(nblk * kMaxBlock);
     std::vector<size_t> sz(nblk);
     parallel_for(nblk, threads_, [&](size_t i) {
-        const size_t off = i * kWriteBlock, n = std::min(kWriteBlock, pend_.size() - off);
-        sz[i] = compress_block(pend_.data() + off, n, out.data() + i * kMaxBlock, level_);
+        const size_t off = i * kWriteBlock, m = std::min(kWriteBlock, n - off);
+        sz[i] = compress_block(p + off, m, out_.data() + i * kMaxBlock, level_);
     });
-    for (size_t i = 0; i < nblk; ++i)
-        if (fwrite(out.data() + i * kMaxBlock, 1, sz[i], f_) != sz[i]) return false;
-    const size_t used = std::min(pend_.size(), nblk * kWriteBlock);
+    // neighbouring blocks are packed together first: one write per run instead of one per block
+    size_t w = 0;
+    for (size_t i = 0; i < nblk; ++i) { if (w != i * kMaxBlock) memmove(out_.data() + w, out_.data() + i * kMaxBlock, sz[i]); w += sz[i]; }
+    if (fwrite(out_.data(), 1, w, f_) != w) { failed_ = true; return 0; }
+    return std::min(n, nblk * kWriteBlock);
+}
+
+bool BgzfWriter::flush_pending(bool all)
+{
+    const size_t used = put_blocks(pend_.data(), pend_.size(), all);
+    if (failed_) return false;
     pend_.erase(pend_.begin(), pend_.begin() + used);
     return true;
 }
@@ -205,6 +216,19 @@ bool BgzfWriter::flush_pending(bool all)
 bool BgzfWriter::write(const void* data, size_t n)
 {
     const uint8_t* p = (const uint8_t*)data;
+    if (n >= (size_t)threads_ * 16 * kWriteBlock) { // a large buffer: top up the pending block, then compress straight from the caller's memory
+        if (!pend_.empty()) {
+            const size_t fill = std::min(n, (kWriteBlock - pend_.size() % kWriteBlock) % kWriteBlock);
+            pend_.insert(pend_.end(), p, p + fill);
+            p += fill; n -= fill;
+            if (!flush_pending(false)) return false;
+        }
+        if (pend_.empty()) {
+            const size_t used = put_blocks(p, n, false);
+            if (failed_) return false;
+            p += used; n -= used;
+        }
+    }
     pend_.insert(pend_.end(), p, p + n);
     if (pend_.size() >= (size_t)threads_ * 16 * kWriteBlock) return flush_pending(false);
     return true;

@@ -49,6 +49,9 @@ public:
 
 private:
     bool flush_pending(bool all);
+    size_t put_blocks(const uint8_t* p, size_t n, bool all);
+    raw_vector<uint8_t> out_;
+    bool failed_ = false;
     FILE* f_ = nullptr;
     int level_ = 1;
     unsigned threads_ = 1;

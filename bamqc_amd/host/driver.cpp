@@ -21,6 +21,7 @@
 #include "../../include/bamqc_host.h"
 #include "bam_io.h"
 #include "raw_vector.h"
+#include "parallel.h"
 #include "crc32_fast.h"
 #include "inflate_fast.h"
 #include "host_tools.h"
@@ -270,6 +271,76 @@ extern "C" int bqc_synth_write(const bqc_synth_params* p, const char* const* ref
     return ok ? 0 : BQC_ERR_IO;
 }
 
+// The plan of bqc_synth_write, streamed: slices of the plan are generated (bqc_synth_slice), serialised into BAM records by
+// all host threads (sizes -> prefix sum -> every thread writes its records in place) and handed to the BGZF writer.
+extern "C" int bqc_synth_stream(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
+                                uint32_t slice_reads, int level)
+{
+    if (!p || !bam_path || !ref_names || p->n_refs == 0) return BQC_ERR_ARG;
+    if (!slice_reads) slice_reads = 1u << 21;
+    std::vector<std::vector<uint8_t>> refs(p->n_refs);
+    std::vector<const uint8_t*> rp(p->n_refs);
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    for (uint32_t c = 0; c < p->n_refs; ++c) {
+        refs[c].resize(p->ref_len[c]);
+        bqc_synth_reference(p->seed, (int32_t)c, p->ref_len[c], refs[c].data());
+        rp[c] = refs[c].data();
+        names.push_back(ref_names[c]);
+        lens.push_back(p->ref_len[c]);
+    }
+    if (fasta_path) {
+        FILE* f = fopen(fasta_path, "wb");
+        if (!f) return BQC_ERR_IO;
+        setvbuf(f, nullptr, _IOFBF, 1 << 22);
+        std::vector<char> text;
+        for (uint32_t c = 0; c < p->n_refs; ++c) {
+            fprintf(f, ">%s synthetic contig %u\n", ref_names[c], c);
+            const std::vector<uint8_t>& r = refs[c];
+            const size_t n = r.size(), lines = (n + 59) / 60;
+            text.resize(n + lines);
+            parallel_ranges(lines, bqc_host_threads(), 1 << 14, [&](unsigned, size_t lo, size_t hi) {
+                for (size_t l = lo; l < hi; ++l) {
+                    const size_t a = l * 60, z = std::min(n, a + 60);
+                    char* w = text.data() + a + l;
+                    for (size_t k = a; k < z; ++k) *w++ = "ACGTN"[r[k]];
+                    *w = '\n';
+                }
+            });
+            if (fwrite(text.data(), 1, text.size(), f) != text.size()) { fclose(f); return BQC_ERR_IO; }
+        }
+        if (fclose(f) != 0) return BQC_ERR_IO;
+    }
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (uint32_t c = 0; c < p->n_refs; ++c) text += "@SQ\tSN:" + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
+    std::vector<std::string> lane_ids;
+    for (uint32_t l = 0; l < std::max(1u, p->n_lanes); ++l) {
+        lane_ids.push_back("L" + std::to_string(l + 1));
+        text += "@RG\tID:" + lane_ids.back() + "\tSM:SYN\tPL:ILLUMINA\n";
+    }
+    BamWriter w;
+    std::string err;
+    if (!w.open(bam_path, text, names, lens, err, level)) return BQC_ERR_IO;
+    const bool timing = getenv("BQC_TIMING") != nullptr;
+    double t_gen = 0, t_write = 0;
+    for (uint64_t lo = 0; lo < p->n_reads; lo += slice_reads) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(slice_reads, p->n_reads - lo);
+        bqc_batch* b = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = bqc_synth_slice(p, lo, cnt, rp.data(), &b);
+        if (rc) return rc;
+        const auto t1 = std::chrono::steady_clock::now();
+        const bool ok = w.write_batch_parallel(*b, lane_ids, p->first_read_index + lo);
+        bqc_synth_batch_free(b);
+        const auto t2 = std::chrono::steady_clock::now();
+        t_gen += std::chrono::duration<double>(t1 - t0).count();
+        t_write += std::chrono::duration<double>(t2 - t1).count();
+        if (!ok) return BQC_ERR_IO;
+    }
+    if (timing) fprintf(stderr, "[timing] synthetic stream of %u reads: generate %.2f s, serialise + compress + write %.2f s\n", p->n_reads, t_gen, t_write);
+    return w.close() ? 0 : BQC_ERR_IO;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // command line (CommandLineParser.hpp:43-149)
 // ---------------------------------------------------------------------------------------------------
@@ -517,7 +588,6 @@ extern "C" int bqc_main(int argc, const char** argv)
     const auto t_setup = clk::now();
 
     int status = 0;
-    bool warned_qual = false;
     for (;;) {
         std::unique_ptr<HostBatch> hb;
         const auto w0 = clk::now();
@@ -530,12 +600,21 @@ extern "C" int bqc_main(int argc, const char** argv)
             Q.cv.notify_all();
         }
         if (status) continue; // drain
-        if (!warned_qual)
-            for (uint16_t f : hb->flag) if ((f & BQC_FLAG_NO_QUAL) && !(f & 0x900)) {
-                fprintf(stderr, "ERROR: length of sequence and quality is not the same\n"); // QualityCheck.hpp:73-77 (return value ignored)
-                warned_qual = true;
-                break;
+        { // check_read_len (QualityCheck.hpp:70-79, called at bamqualcheck.cpp:357,378; return value ignored): one line per primary
+          // record with a first / last flag whose quality string is empty while its sequence is not
+            size_t n_noqual = 0;
+            for (uint16_t f : hb->flag) n_noqual += (f & BQC_FLAG_NO_QUAL) && !(f & 0x900) && (f & 0xC0);
+            if (n_noqual) {
+                static const char msg[] = "ERROR: length of sequence and quality is not the same\n";
+                std::string out;
+                out.reserve(std::min<size_t>(n_noqual, 4096) * (sizeof msg - 1));
+                for (size_t k = 0; k < n_noqual; ++k) {
+                    out.append(msg, sizeof msg - 1);
+                    if (out.size() >= 4096 * (sizeof msg - 1)) { fwrite(out.data(), 1, out.size(), stderr); out.clear(); }
+                }
+                fwrite(out.data(), 1, out.size(), stderr);
             }
+        }
         const bqc_batch v = hb->view();
         const auto s0 = clk::now();
         t_wait += secs(w0, s0);

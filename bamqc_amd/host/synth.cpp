@@ -46,11 +46,25 @@ struct Rng { // xoshiro256** seeded by splitmix64
 
 const uint8_t NIB_OF_CODE[5] = {1, 2, 4, 8, 15};
 
+struct CigarBuf { // a read's CIGAR without a heap allocation per read (long reads: at most 29 events -> 61 operations)
+    uint32_t n = 0;
+    uint32_t v[64];
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    uint32_t& back() { return v[n - 1]; }
+    uint32_t front() const { return v[0]; }
+    uint32_t back() const { return v[n - 1]; }
+    void push_back(uint32_t x) { if (n < 64) v[n++] = x; }
+    const uint32_t* begin() const { return v; }
+    const uint32_t* end() const { return v + n; }
+    const uint32_t* data() const { return v; }
+};
 struct ReadPlan { // everything about one read except its bases
     uint32_t flag = 0, L = 0;
     int32_t rid = -1, pos = -1, tlen = 0, nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
     uint8_t mapq = 0, lane = 0;
-    std::vector<uint32_t> cigar;
+    CigarBuf cigar;
 };
 } // namespace
 
@@ -165,10 +179,11 @@ static void plan_read(const bqc_synth_params& p, uint64_t gi, uint32_t rid, uint
 }
 
 // Fill one read's bases/qualities from the plan and the reference; returns the number of substitutions.
-static uint32_t fill_read(const bqc_synth_params& p, const ReadPlan& o, const uint8_t* ref, uint64_t reflen, Rng& r, uint8_t* seq, uint8_t* qual)
+// `code` is scratch of L bytes; `qthr` the quality thresholds a | b << 8 | c << 16 per cycle (qual_thresholds).
+static uint32_t fill_read(const bqc_synth_params& p, const ReadPlan& o, const uint8_t* ref, uint64_t reflen, Rng& r, uint8_t* seq, uint8_t* qual,
+                          uint8_t* code, const uint32_t* qthr)
 {
     const uint32_t L = o.L;
-    std::vector<uint8_t> code(L);
     uint32_t rp = 0;
     uint64_t cp = o.pos < 0 ? 0 : (uint64_t)o.pos;
     const bool mapped = !(o.flag & 0x4) && ref;
@@ -180,18 +195,23 @@ static uint32_t fill_read(const bqc_synth_params& p, const ReadPlan& o, const ui
     } else {
         for (uint32_t cw : o.cigar) {
             const uint32_t op = cw & 15u, n = cw >> 4;
-            if (op == 0) { for (uint32_t k = 0; k < n && rp < L; ++k, ++rp, ++cp) code[rp] = cp < reflen ? ref[cp] : 0; }
+            if (op == 0) {
+                const uint32_t m = std::min(n, L - rp);
+                if (cp + m <= reflen) { memcpy(code + rp, ref + cp, m); rp += m; cp += m; }
+                else for (uint32_t k = 0; k < m; ++k, ++rp, ++cp) code[rp] = cp < reflen ? ref[cp] : 0;
+            }
             else if (op == 1 || op == 4) { for (uint32_t k = 0; k < n && rp < L; ++k, ++rp) code[rp] = (uint8_t)r.below(4); }
             else if (op == 2) cp += n;
         }
     }
+    static const double kLogSub = std::log(1.0 - 0.005), kLogN = std::log(1.0 - 0.001);
     uint32_t subs = 0;
     if (mapped && !o.cigar.empty()) { // substitutions at 0.5 % on aligned bases via geometric gaps
         uint32_t lead = (o.cigar.front() & 15u) == 4 ? o.cigar.front() >> 4 : 0;
         uint32_t trail = (o.cigar.back() & 15u) == 4 && o.cigar.size() > 1 ? o.cigar.back() >> 4 : 0;
         double i = lead;
         for (;;) {
-            i += std::floor(std::log(1.0 - r.uni()) / std::log(1.0 - 0.005)) + 1;
+            i += std::floor(std::log(1.0 - r.uni()) / kLogSub) + 1;
             if (i >= (double)(L - trail)) break;
             const uint32_t k = (uint32_t)i - 1;
             if (code[k] < 4) { code[k] = (code[k] + 1 + r.below(3)) & 3; ++subs; }
@@ -200,7 +220,7 @@ static uint32_t fill_read(const bqc_synth_params& p, const ReadPlan& o, const ui
     { // read N at 0.1 %
         double i = 0;
         for (;;) {
-            i += std::floor(std::log(1.0 - r.uni()) / std::log(1.0 - 0.001)) + 1;
+            i += std::floor(std::log(1.0 - r.uni()) / kLogN) + 1;
             if (i > (double)L) break;
             code[(uint32_t)i - 1] = 4;
         }
@@ -215,22 +235,37 @@ static uint32_t fill_read(const bqc_synth_params& p, const ReadPlan& o, const ui
     for (uint32_t i = 0; i < L; i += 8) {
         uint64_t w = r.next();
         for (uint32_t k = i; k < std::min(L, i + 8); ++k, w >>= 8) {
-            const uint32_t cyc = rc ? L - 1 - k : k;
-            const uint32_t t = (uint32_t)(((uint64_t)cyc << 8) / L); // 0..255
-            const uint32_t u = w & 255;
-            // thresholds move with the cycle: P(q=37) from 0.80 down to 0.55
-            const uint32_t a = 5 + t / 10, b = a + 10 + t / 10, c = b + 36 + t / 24;
-            qual[k] = QL[u < a ? 0 : (u < b ? 1 : (u < c ? 2 : 3))];
+            const uint32_t th = qthr[rc ? L - 1 - k : k], u = w & 255;
+            qual[k] = QL[(u >= (th & 255u)) + (u >= ((th >> 8) & 255u)) + (u >= (th >> 16))];
         }
     }
     return subs;
 }
 
+// thresholds of the quality draw per cycle: P(q=37) from 0.80 down to 0.55 along the read
+static std::vector<uint32_t> qual_thresholds(uint32_t L)
+{
+    std::vector<uint32_t> v(L);
+    for (uint32_t cyc = 0; cyc < L; ++cyc) {
+        const uint32_t t = (uint32_t)(((uint64_t)cyc << 8) / L); // 0..255
+        const uint32_t a = 5 + t / 10, b = a + 10 + t / 10, c = b + 36 + t / 24;
+        v[cyc] = a | (b << 8) | (c << 16);
+    }
+    return v;
+}
+
 extern "C" int bqc_synth_batch(const bqc_synth_params* pp, const uint8_t* const* refs, bqc_batch** out)
 {
-    if (!pp || !out || pp->n_refs == 0 || !pp->ref_len || pp->read_len < 8) return BQC_ERR_ARG;
+    return pp ? bqc_synth_slice(pp, 0, pp->n_reads, refs, out) : BQC_ERR_ARG;
+}
+
+// Reads [lo, lo + count) of the plan of p.n_reads reads: every read depends on (seed, global index, n_reads) only, so a slice
+// holds exactly the reads the whole plan holds at those indices.
+extern "C" int bqc_synth_slice(const bqc_synth_params* pp, uint64_t lo, uint32_t count, const uint8_t* const* refs, bqc_batch** out)
+{
+    if (!pp || !out || pp->n_refs == 0 || !pp->ref_len || pp->read_len < 8 || lo + count > pp->n_reads) return BQC_ERR_ARG;
     const bqc_synth_params p = *pp;
-    const uint32_t n = p.n_reads, L = p.read_len;
+    const uint32_t n_all = p.n_reads, n = count, L = p.read_len;
     // reads per contig proportional to length
     long double total = 0;
     for (uint32_t c = 0; c < p.n_refs; ++c) total += p.ref_len[c];
@@ -238,9 +273,9 @@ extern "C" int bqc_synth_batch(const bqc_synth_params* pp, const uint8_t* const*
     for (uint32_t c = 0; c < p.n_refs; ++c) {
         long double acc = 0;
         for (uint32_t k = 0; k <= c; ++k) acc += p.ref_len[k];
-        start[c + 1] = (uint64_t)((long double)n * acc / total);
+        start[c + 1] = (uint64_t)((long double)n_all * acc / total);
     }
-    start[p.n_refs] = n;
+    start[p.n_refs] = n_all;
     // pass 1: plans (cigars are variable length)
     std::vector<ReadPlan> plans(n);
     const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -249,7 +284,8 @@ extern "C" int bqc_synth_batch(const bqc_synth_params* pp, const uint8_t* const*
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([&, t]() {
-                for (uint64_t gi = t; gi < n; gi += nt) {
+                for (uint64_t k = (uint64_t)n * t / nt; k < (uint64_t)n * (t + 1) / nt; ++k) {
+                    const uint64_t gi = lo + k; // index in the plan
                     Rng r(p.seed * 0xD6E8FEB86659FD93ull + (p.first_read_index + gi) * 0x9E3779B97F4A7C15ull + 1);
                     const uint32_t c = std::min(contig_of(gi), p.n_refs - 1);
                     const uint64_t nc = start[c + 1] - start[c], j = gi - start[c];
@@ -257,11 +293,12 @@ extern "C" int bqc_synth_batch(const bqc_synth_params* pp, const uint8_t* const*
                     const uint64_t span = p.ref_len[c] > margin ? p.ref_len[c] - margin : 1;
                     const double slot = (double)span / (double)std::max<uint64_t>(nc, 1);
                     const uint32_t pos = (uint32_t)(((double)j + r.uni()) * slot);
-                    plan_read(p, p.first_read_index + gi, c, pos, r, plans[gi]);
+                    plan_read(p, p.first_read_index + gi, c, pos, r, plans[k]);
                 }
             });
         for (auto& t : th) t.join();
     }
+    const std::vector<uint32_t> qthr = qual_thresholds(L);
     std::vector<uint64_t> coff(n + 1, 0);
     for (uint32_t i = 0; i < n; ++i) coff[i + 1] = coff[i] + plans[i].cigar.size();
     const uint64_t sbytes = (uint64_t)n * ((L + 1) / 2), qbytes = (uint64_t)n * L;
@@ -275,11 +312,13 @@ extern "C" int bqc_synth_batch(const bqc_synth_params* pp, const uint8_t* const*
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([&, t]() {
-                for (uint64_t gi = t; gi < n; gi += nt) {
+                std::vector<uint8_t> code(L);
+                for (uint64_t gi = (uint64_t)n * t / nt; gi < (uint64_t)n * (t + 1) / nt; ++gi) { // (gi: index in the slice from here on)
                     ReadPlan& o = plans[gi];
-                    Rng r(p.seed * 0xA0761D6478BD642Full + (p.first_read_index + gi) * 0xE7037ED1A0B428DBull + 7);
+                    Rng r(p.seed * 0xA0761D6478BD642Full + (p.first_read_index + lo + gi) * 0xE7037ED1A0B428DBull + 7);
                     const uint8_t* ref = (o.rid >= 0 && refs) ? refs[o.rid] : nullptr;
-                    const uint32_t subs = fill_read(p, o, ref, o.rid >= 0 ? p.ref_len[o.rid] : 0, r, hb->seq + gi * ((L + 1) / 2), hb->qual + gi * L);
+                    const uint32_t subs = fill_read(p, o, ref, o.rid >= 0 ? p.ref_len[o.rid] : 0, r, hb->seq + gi * ((L + 1) / 2), hb->qual + gi * L,
+                                                    code.data(), qthr.data());
                     if (!(o.flag & 0x4)) {
                         uint32_t indel = (uint32_t)o.nm;
                         o.nm = (int32_t)(indel + subs);

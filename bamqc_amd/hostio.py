@@ -109,6 +109,18 @@ def synth_write(bam_path, fasta_path, seed, n_reads, ref_names, ref_lens, read_l
         raise IOError("bqc_synth_write failed: %d" % rc)
 
 
+def synth_stream(bam_path, fasta_path, seed, n_reads, ref_names, ref_lens, read_len=150, n_lanes=1, isize=1000, long_reads=False,
+                 slice_reads=1 << 21, level=1):
+    """The same BAM as synth_write, generated and written slice by slice (any number of reads; bam_path may be a FIFO)."""
+    lib = _lib.load()
+    rl = np.ascontiguousarray(ref_lens, np.uint32)
+    p = _abi.SynthParams(seed, 0, n_reads, read_len, len(rl), rl.ctypes.data_as(_abi.u32p), n_lanes, isize, 1 if long_reads else 0)
+    names = (C.c_char_p * len(ref_names))(*[s.encode() for s in ref_names])
+    rc = lib.bqc_synth_stream(C.byref(p), names, bam_path.encode(), fasta_path.encode() if fasta_path else None, slice_reads, level)
+    if rc:
+        raise IOError("bqc_synth_stream failed: %d" % rc)
+
+
 def main(argv):
     """Run the bamqualcheck program in-process; returns its exit status."""
     lib = _lib.load()

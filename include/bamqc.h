@@ -82,7 +82,8 @@ typedef struct bqc_sketch_options { /* N1: ReadQualityHasher/StreamCounter (Comm
     uint32_t n_q;
     const uint32_t* qlist; /* -q, default {17}                                   */
     double e;              /* -e, default 0.01                                   */
-    int32_t seed;          /* -s, default 1 (0 = time based in the reference; rejected here) */
+    int32_t seed;          /* -s, default 1; 0 = table seeded from time(NULL), as RepHash.cpp:5-7 (not reproducible;
+                              shards of one run must then be given the same non-zero seed by their driver)   */
 } bqc_sketch_options;
 
 typedef struct bqc_options {

@@ -30,11 +30,20 @@ int bqc_synth_reference(uint64_t seed, int32_t rid, uint64_t len, uint8_t* out);
  * its arrays are owned by the library; release with bqc_synth_batch_free. */
 int bqc_synth_batch(const bqc_synth_params* p, const uint8_t* const* refs, bqc_batch** out);
 void bqc_synth_batch_free(bqc_batch* b);
+/* Reads [lo, lo + count) of the plan bqc_synth_batch would generate for p->n_reads reads (the same reads at the same
+ * indices): lets a generator stream a plan that does not fit in memory.  Release with bqc_synth_batch_free. */
+int bqc_synth_slice(const bqc_synth_params* p, uint64_t lo, uint32_t count, const uint8_t* const* refs, bqc_batch** out);
 
 /* Writes a coordinate-sorted synthetic BAM (+ FASTA when fasta_path != NULL) for the parameters:
  * header with @SQ per contig and one @RG (ID:L<n>, SM:SYN) per lane; tags RG:Z, NM:i, AS:i. */
 int bqc_synth_write(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
                     uint32_t batch_reads);
+
+/* The same BAM, generated and written slice by slice (slice_reads reads in memory at a time; records serialised and BGZF
+ * blocks compressed on all host threads; level 0 = stored blocks): for plans of hundreds of millions of reads.  bam_path
+ * may be a FIFO that a reader drains meanwhile.  The FASTA is written first when fasta_path != NULL. */
+int bqc_synth_stream(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
+                     uint32_t slice_reads, int level);
 
 /* ---- BAM / FASTA input (replaces SeqAn BamStream / SequenceStream) --------- */
 typedef struct bqc_bam bqc_bam;

@@ -5,17 +5,25 @@
 // TEST INFRASTRUCTURE ONLY.  Contains no reference code: it only calls it.
 #include <cstring>   // StreamCounter.hpp uses memset without including it
 #include <cstddef>
-#define private public   // RepHash::hvals is private; the shim only reads it
 #include "RepHash.hpp"
-#undef private
 #include "StreamCounter.hpp"
+
+// RepHash::hvals is private and no public member exposes it.  Access checks do not apply to the arguments of an explicit
+// template instantiation, so the member pointer can be handed out this way without touching the reference's headers
+// (standard C++, no macro redefinition of keywords).
+namespace {
+struct HvalsTag { typedef state_t (RepHash::*type)[32]; friend type hvals_member(HvalsTag); };
+template <typename Tag, typename Tag::type M> struct Expose { friend typename Tag::type hvals_member(Tag) { return M; } };
+template struct Expose<HvalsTag, &RepHash::hvals>;
+}
 
 extern "C" {
 void ref_rephash_table(int seed, uint64_t out[64])
 {
     RepHash h;
     h.seed(seed);
-    for (int i = 0; i < 32; ++i) { out[2 * i] = h.hvals[i].hi; out[2 * i + 1] = h.hvals[i].lo; }
+    const state_t (&hv)[32] = h.*hvals_member(HvalsTag());
+    for (int i = 0; i < 32; ++i) { out[2 * i] = hv[i].hi; out[2 * i + 1] = hv[i].lo; }
 }
 uint32_t ref_rephash_sequence(int seed, int k, const char* s, uint32_t l, uint64_t* out)
 {

@@ -96,6 +96,20 @@ def test_damaged_blocks_are_errors_not_crashes(synth_files, tmp_path):
     assert sum(len(b["flag"]) for b in hostio.BamFile(ok).batches()) > 0
 
 
+def test_bsize_smaller_than_header_and_trailer_is_rejected(synth_files, tmp_path):
+    """BSIZE from the BC subfield is checked against the block's own header + trailer (else the compressed size underflows and
+    the trailer pointer lies before the block), and a subfield may not run past the extra field."""
+    bam, _ = synth_files
+    data = bytearray(open(bam, "rb").read())
+    for k, patch in enumerate([(16, struct.pack("<H", 10)), (16, struct.pack("<H", 24)), (14, struct.pack("<H", 200))]):
+        bad = bytearray(data)
+        bad[patch[0]:patch[0] + 2] = patch[1]
+        p = str(tmp_path / ("bs%d.bam" % k))
+        open(p, "wb").write(bad)
+        with pytest.raises(IOError):
+            list(hostio.BamFile(p).batches())
+
+
 def test_not_a_bam(tmp_path):
     p = str(tmp_path / "x.bam")
     open(p, "wb").write(b"hello world, definitely not gzip")
