@@ -44,6 +44,7 @@ _SIGNATURES = {
     "bqc_synth_write": (C.c_int, [C.POINTER(_abi.SynthParams), C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_uint32]),
     "bqc_synth_slice": (C.c_int, [C.POINTER(_abi.SynthParams), C.c_uint64, C.c_uint32, C.POINTER(_abi.u8p), C.POINTER(C.POINTER(_abi.Batch))]),
     "bqc_synth_stream": (C.c_int, [C.POINTER(_abi.SynthParams), C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
+    "bqc_bam_write": (C.c_int, [C.c_char_p, C.POINTER(_abi.Batch), C.c_uint32, C.POINTER(C.c_char_p), _abi.u32p, C.c_uint32, C.c_uint64, C.c_int]),
     "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bqc_bam_close": (None, [C.c_void_p]),
     "bqc_bam_error": (C.c_char_p, [C.c_void_p]),

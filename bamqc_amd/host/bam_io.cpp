@@ -243,10 +243,14 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     recs.reserve(std::min<size_t>(max_reads, 1u << 20));
     size_t bases = 0, so = 0, qo = 0, co = 0;
     size_t rel = 0; // bytes of this batch walked so far; cur_ stays at the batch start, so fill() never drops them
+    size_t released = 0; // bytes of skipped records given back before the first kept one (refID filter)
     bool io_error = false;
     const uint64_t nrec_at_start = nrec_;
     parallel_prewalk(max_reads, max_bases, rel, bases, so, qo, co); // (does nothing for the first batch: record size unknown)
     while (recs.size() < max_reads && bases < max_bases) {
+        // With a refID filter nothing may have been kept yet: those bytes are released at once (cur_ moves on; fill() drops what
+        // lies before it), otherwise a rank whose chromosomes sit late in the file would hold everything before them in memory.
+        if (recs.empty() && rel > (8u << 20)) { cur_ += rel; released += rel; rel = 0; }
         // fast path: the whole record is already in the buffer (fill() is only called when it is not)
         size_t avail = buf_.size() - cur_;
         if (avail < rel + 4 || avail < rel + 4 + (size_t)rd32(buf_.data() + cur_ + rel)) {
@@ -276,7 +280,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         ++nrec_;
     }
     if (nrec_ > nrec_at_start) {
-        avg_rec_bytes_ = (double)rel / (double)(nrec_ - nrec_at_start);
+        avg_rec_bytes_ = (double)(released + rel) / (double)(nrec_ - nrec_at_start);
         avg_rec_bases_ = recs.empty() ? 0.0 : (double)bases / (double)recs.size();
     }
     const auto t1 = std::chrono::steady_clock::now();

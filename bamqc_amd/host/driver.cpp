@@ -271,6 +271,32 @@ extern "C" int bqc_synth_write(const bqc_synth_params* p, const char* const* ref
     return ok ? 0 : BQC_ERR_IO;
 }
 
+static std::string synth_header_text(const std::vector<std::string>& names, const std::vector<uint32_t>& lens, uint32_t n_lanes, std::vector<std::string>& lane_ids)
+{
+    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (size_t c = 0; c < names.size(); ++c) text += "@SQ\tSN:" + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
+    for (uint32_t l = 0; l < std::max(1u, n_lanes); ++l) {
+        lane_ids.push_back("L" + std::to_string(l + 1));
+        text += "@RG\tID:" + lane_ids.back() + "\tSM:SYN\tPL:ILLUMINA\n";
+    }
+    return text;
+}
+
+extern "C" int bqc_bam_write(const char* path, const bqc_batch* b, uint32_t n_refs, const char* const* ref_names, const uint32_t* ref_lens,
+                             uint32_t n_lanes, uint64_t first_read_index, int level)
+{
+    if (!path || !b || (n_refs && (!ref_names || !ref_lens))) return BQC_ERR_ARG;
+    std::vector<std::string> names, lane_ids;
+    std::vector<uint32_t> lens;
+    for (uint32_t c = 0; c < n_refs; ++c) { names.push_back(ref_names[c]); lens.push_back(ref_lens[c]); }
+    const std::string text = synth_header_text(names, lens, n_lanes, lane_ids);
+    for (uint32_t i = 0; i < b->n_reads; ++i) if (b->lane[i] >= lane_ids.size()) return BQC_ERR_ARG;
+    BamWriter w;
+    std::string err;
+    if (!w.open(path, text, names, lens, err, level)) return BQC_ERR_IO;
+    return w.write_batch_parallel(*b, lane_ids, first_read_index) && w.close() ? 0 : BQC_ERR_IO;
+}
+
 // The plan of bqc_synth_write, streamed: slices of the plan are generated (bqc_synth_slice), serialised into BAM records by
 // all host threads (sizes -> prefix sum -> every thread writes its records in place) and handed to the BGZF writer.
 extern "C" int bqc_synth_stream(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
@@ -311,13 +337,8 @@ extern "C" int bqc_synth_stream(const bqc_synth_params* p, const char* const* re
         }
         if (fclose(f) != 0) return BQC_ERR_IO;
     }
-    std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
-    for (uint32_t c = 0; c < p->n_refs; ++c) text += "@SQ\tSN:" + names[c] + "\tLN:" + std::to_string(lens[c]) + "\n";
     std::vector<std::string> lane_ids;
-    for (uint32_t l = 0; l < std::max(1u, p->n_lanes); ++l) {
-        lane_ids.push_back("L" + std::to_string(l + 1));
-        text += "@RG\tID:" + lane_ids.back() + "\tSM:SYN\tPL:ILLUMINA\n";
-    }
+    const std::string text = synth_header_text(names, lens, p->n_lanes, lane_ids);
     BamWriter w;
     std::string err;
     if (!w.open(bam_path, text, names, lens, err, level)) return BQC_ERR_IO;

@@ -109,6 +109,50 @@ def synth_write(bam_path, fasta_path, seed, n_reads, ref_names, ref_lens, read_l
         raise IOError("bqc_synth_write failed: %d" % rc)
 
 
+def synth_slice(seed, n_total, lo, count, ref_lens, refs=None, read_len=150, n_lanes=1, isize=1000, long_reads=False):
+    """Reads [lo, lo + count) of the plan of n_total reads as a column dict (refs: list of Dna5 arrays or None per contig)."""
+    lib = _lib.load()
+    rl = np.ascontiguousarray(ref_lens, np.uint32)
+    p = _abi.SynthParams(seed, 0, n_total, read_len, len(rl), rl.ctypes.data_as(_abi.u32p), n_lanes, isize, 1 if long_reads else 0)
+    rp = None
+    if refs is not None:
+        rp = (_abi.u8p * len(rl))()
+        for i, r in enumerate(refs):
+            if r is not None:
+                rp[i] = r.ctypes.data_as(_abi.u8p)
+    out = C.POINTER(_abi.Batch)()
+    rc = lib.bqc_synth_slice(C.byref(p), lo, count, rp, C.byref(out))
+    if rc:
+        raise IOError("bqc_synth_slice failed: %d" % rc)
+    cols = batch_to_cols(out.contents)
+    lib.bqc_synth_batch_free(out)
+    return cols
+
+
+def write_bam(path, cols, ref_names, ref_lens, n_lanes=1, first_read_index=0, level=1):
+    """A column dict as a BAM file (header and tags as the synthetic generator writes them)."""
+    lib = _lib.load()
+    b, keep = _abi.make_batch(cols)
+    rl = np.ascontiguousarray(ref_lens, np.uint32)
+    names = (C.c_char_p * len(ref_names))(*[s.encode() for s in ref_names])
+    rc = lib.bqc_bam_write(path.encode(), C.byref(b), len(rl), names, rl.ctypes.data_as(_abi.u32p), n_lanes, first_read_index, level)
+    if rc:
+        raise IOError("bqc_bam_write failed: %d" % rc)
+
+
+def write_fasta(path, names, codes):
+    """Dna5 code arrays as a FASTA file (60 bases per line, like the synthetic generator's)."""
+    with open(path, "wb") as f:
+        for i, (name, c) in enumerate(zip(names, codes)):
+            f.write((">%s synthetic contig %d\n" % (name, i)).encode())
+            txt = np.frombuffer(b"ACGTN", np.uint8)[np.asarray(c, np.uint8)]
+            full = len(txt) // 60 * 60
+            body = np.concatenate([txt[:full].reshape(-1, 60), np.full((full // 60, 1), 10, np.uint8)], axis=1)
+            f.write(body.tobytes())
+            if full < len(txt):
+                f.write(txt[full:].tobytes() + b"\n")
+
+
 def synth_stream(bam_path, fasta_path, seed, n_reads, ref_names, ref_lens, read_len=150, n_lanes=1, isize=1000, long_reads=False,
                  slice_reads=1 << 21, level=1):
     """The same BAM as synth_write, generated and written slice by slice (any number of reads; bam_path may be a FIFO)."""

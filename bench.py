@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the BAM file -> bin/bamqualcheck -> .bamqc leg")
+    ap.add_argument("--e2e-prefix", type=int, default=1_000_000, help="reads of the e2e input checked against the oracle")
     args = ap.parse_args()
 
     import torch
@@ -44,7 +46,10 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:  # (never re-exec: a process that has touched the GPU must not be replaced)
+        sys.exit("bench.py --gpus %d needs one process per GPU; launch it as\n  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                 "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
+                 % (args.gpus, args.gpus, args.gpus, args.steps, args.warmup))
     dev = torch.device("cuda", local)
 
     from bamqc_amd import Aggregator, _abi, synth
@@ -135,6 +140,13 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cols, refs, args, agg, db)
+        if world == 1 and not args.no_e2e:
+            db.free()
+            agg.close()
+            del cols
+            out["e2e"] = e2e_leg(args, refs, out.get("cpu_baseline", {}).get("value"))
+            print(json.dumps(out), flush=True)
+            return
         print(json.dumps(out), flush=True)
     db.free()
     agg.close()
@@ -168,6 +180,65 @@ def cpu_baseline(cols, refs, args, agg, db):
     return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": "first %d reads of the same batch, oracle/liboracle.so (C restatement), 1 thread" % n,
             "gpu_matches_oracle_on_sample": not diffs, "diffs": diffs[:3]}
+
+
+def e2e_leg(args, refs, cpu_kernel_value):
+    """What a user gets: the same workload as a BAM FILE through the program bin/bamqualcheck (default options: k-mer sketch
+    -k 32 -q 17 included) to the `.bamqc` text — BGZF inflate, record decode, pre-pass, H2D, kernels, finalisation, process
+    start and HIP initialisation all inside the wall time.  Checked: the whole output through the size-independent properties
+    of tests/bamqc_text.py; a prefix of the same plan byte for byte against the oracle's `.bamqc`."""
+    import filecmp
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from bamqc_amd import hostio
+    from bamqc_amd.host_info import cpu_limit
+    from tests import bamqc_text
+    from tests.cli_oracle import oracle_bamqualcheck
+    exe = os.path.join(ROOT, "bin", "bamqualcheck")
+    tmp = tempfile.mkdtemp(prefix="bqc_e2e_")
+    try:
+        names, lens = ["chr1", "chr2", "chr3", "chr4"], [25_000_000] * 4
+        bam, fa = os.path.join(tmp, "c2.bam"), os.path.join(tmp, "c2.fa")
+        t0 = time.time()
+        hostio.synth_stream(bam, fa, 1002, args.reads, names, lens, read_len=args.read_len, level=1)
+        t_write = time.time() - t0
+        runs = []
+        for extra in ([], [], ["--no-sketch"]):
+            out = os.path.join(tmp, "o%d.bamqc" % len(runs))
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "-r", fa, "-o", out, "-c", ",".join(names)] + extra + [bam], capture_output=True, text=True,
+                               env=dict(os.environ, BQC_TIMING="1"))
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr[-2000:]
+            m = re.search(r"record loop ([0-9.]+) s", r.stderr)
+            runs.append({"args": extra, "wall_s": dt, "reads_per_s": args.reads / dt, "record_loop_s": float(m.group(1)) if m else None,
+                         "timing": [ln for ln in r.stderr.splitlines() if ln.startswith("[timing]")]})
+        lanes = bamqc_text.parse(os.path.join(tmp, "o1.bamqc"))
+        bamqc_text.check_invariants(lanes["L1"], n_records=args.reads, read_len=args.read_len)
+        # prefix of the same plan: program vs oracle, byte for byte; the oracle run is also the CPU end-to-end baseline
+        npre = min(args.e2e_prefix, args.reads)
+        pbam, pfa = os.path.join(tmp, "p.bam"), fa
+        hostio.write_bam(pbam, hostio.synth_slice(1002, args.reads, 0, npre, lens, refs=refs, read_len=args.read_len), names, lens)
+        got, want = os.path.join(tmp, "p_gpu.bamqc"), os.path.join(tmp, "p_cpu.bamqc")
+        r = subprocess.run([exe, "-r", pfa, "-o", got, "-c", ",".join(names), pbam], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        t0 = time.perf_counter()
+        assert oracle_bamqualcheck(pbam, pfa, want, chroms=",".join(names)) == 0
+        t_cpu = time.perf_counter() - t0
+        best = max(runs[:2], key=lambda x: x["reads_per_s"])
+        return {"what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process"
+                        % (os.path.getsize(bam) / 1e6),
+                "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "host_cpus": cpu_limit(),
+                "runs": runs, "write_input_s": t_write,
+                "matches_oracle": filecmp.cmp(got, want, shallow=False), "oracle_prefix_reads": npre,
+                "cpu_port_e2e_reads_per_s": npre / t_cpu,
+                "cpu_port_e2e_what": "same program flow on the CPU oracle (own reader on all host threads + oracle incl. sketch, 1 thread) on the prefix",
+                "speedup_vs_cpu_port_e2e": best["reads_per_s"] / (npre / t_cpu),
+                "speedup_vs_cpu_port": (best["reads_per_s"] / cpu_kernel_value) if cpu_kernel_value else None}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

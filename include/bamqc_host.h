@@ -45,6 +45,11 @@ int bqc_synth_write(const bqc_synth_params* p, const char* const* ref_names, con
 int bqc_synth_stream(const bqc_synth_params* p, const char* const* ref_names, const char* bam_path, const char* fasta_path,
                      uint32_t slice_reads, int level);
 
+/* Any batch as a BAM file with the header bqc_synth_write uses (@SQ per contig, @RG ID:L<n> SM:SYN per lane; read names
+ * r<first_read_index + i>; tags RG:Z, NM:i, AS:i). */
+int bqc_bam_write(const char* path, const bqc_batch* b, uint32_t n_refs, const char* const* ref_names, const uint32_t* ref_lens,
+                  uint32_t n_lanes, uint64_t first_read_index, int level);
+
 /* ---- BAM / FASTA input (replaces SeqAn BamStream / SequenceStream) --------- */
 typedef struct bqc_bam bqc_bam;
 int bqc_bam_open(const char* path, bqc_bam** out);  /* on failure *out still holds the message */

@@ -295,3 +295,24 @@ def test_parallel_record_walk_equals_the_serial_walk(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and "[100000, 100000, 100000, 100000]" in outs[0]
+
+
+def test_rid_filter_releases_skipped_records(tmp_path):
+    """A rank that keeps only the LAST contig of a coordinate-sorted BAM must not hold the records before it in memory: peak RSS
+    of the filtered read stays near the unfiltered one's (measured in child processes)."""
+    import subprocess, sys
+    bam = str(tmp_path / "f.bam")
+    hostio.synth_stream(bam, None, 21, 1_500_000, ["chr1", "chr2", "chr3"], [3_000_000, 3_000_000, 60_000], level=1)
+    code = ("import sys, resource; sys.path.insert(0, %r)\nfrom bamqc_amd import hostio\nimport numpy as np\n"
+            "f = hostio.BamFile(%r)\n"
+            "if sys.argv[1] == 'last': f.set_rid_filter(np.array([0, 0, 1], np.uint8), False)\n"
+            "n = sum(len(b['flag']) for b in f.batches(max_reads=200000))\n"
+            "print(n, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)\n") % (ROOT, bam)
+    res = {}
+    for mode in ("all", "last"):
+        out = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, env=dict(os.environ, BQC_IO_THREADS="4"))
+        assert out.returncode == 0, out.stderr
+        n, rss = out.stdout.split()
+        res[mode] = (int(n), int(rss))
+    assert res["all"][0] == 1_500_000 and 0 < res["last"][0] < 40_000
+    assert res["last"][1] < res["all"][1] + 100_000, res  # KiB: the inflated file is ~450 MB
