@@ -83,7 +83,8 @@ def test_config3_shaped_stream_24_contigs(tmp_path):
     assert info["triplets"] > 50 * info["primary"]  # most reads are eligible and contribute ~148 positions
     # coverage: chr1..chr22 are scanned window by window; at 30x nearly no position has depth 0
     cov = g["genome_coverage_histogram"]
-    assert int(cov.sum()) >= 1000 * (sum(GRCH38[:22]) // 1000 - 3 * 22) * (1 if n >= 6_000_000 else 0)
+    if n >= 6_000_000:  # (every 1000-position window between a contig's first and last read is histogrammed; a few per contig are not reached)
+        assert 1000 * (sum(GRCH38[:22]) // 1000 - 10 * 22) <= int(cov.sum()) <= sum(GRCH38[:22]) + 2000 * 22
     print("config 3 (scaled): %d reads in %.1f s = %.1f M reads/s end to end (generator on the same cores)\n%s" % (n, wall, n / wall / 1e6, stderr[-600:]))
     # the first million reads of the same plan against the oracle, byte for byte
     prefix_parity(str(tmp_path), 1003, n, min(n, 1_000_000), NAMES24, GRCH38, ["-c", "chr1"], dict(chroms="chr1"))
