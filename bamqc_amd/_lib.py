@@ -20,6 +20,10 @@ _SIGNATURES = {
     "bqc_last_error": (C.c_char_p, [C.c_void_p]),
     "bqc_set_reference": (C.c_int, [C.c_void_p, C.c_int32, _abi.u8p, C.c_uint64]),
     "bqc_submit": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch)]),
+    "bqc_submit_async": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.POINTER(C.c_uint64)]),
+    "bqc_batch_uploaded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "bqc_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "bqc_host_unregister": (C.c_int, [C.c_void_p]),
     "bqc_upload": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.POINTER(C.c_void_p)]),
     "bqc_process": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bqc_dbatch_free": (None, [C.c_void_p, C.c_void_p]),

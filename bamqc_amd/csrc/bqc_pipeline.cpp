@@ -1,0 +1,607 @@
+// bqc_pipeline.cpp — how a batch of decoded records gets to the kernels (include/bamqc.h: bqc_submit, bqc_submit_async,
+// bqc_upload / bqc_process).  Replaces the body of the reference's record loop (src/bamqualcheck.cpp:303-444) together with
+// the kernels; the only per-read work left on the host is the O(1) coverage anchor recurrence
+// (src/OverallNumbers.hpp:84-110) — everything else a read needs before its counters (payload offsets, flag annotation,
+// checkFlagsAndQuality, covered intervals, triplet segments, chunk tables) is computed on the device (k_prep.hip).
+//
+// bqc_submit is a pipeline of three page-locked slots: the host pass of batch i + 1 runs while batch i is copied to the device
+// on the copy stream and batch i - 1 is processed on the compute stream; the call returns when the batch is queued, and what
+// the device finds wrong with a batch (first failing read in stream order, as the reference would have met it) surfaces at
+// a later call.  There is NO CPU fallback: every path below ends in HIP launches.
+#include "bqc_ctx.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+
+#include "../host/parallel.h"
+
+extern "C" {
+void bqc_launch_reads_chunks(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t fast_table, hipStream_t);
+void bqc_launch_nm_extra(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
+void bqc_launch_long(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub,
+                     uint32_t n_cu, hipStream_t);
+void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, uint32_t* parity, const uint8_t* lane_mask, uint8_t* started,
+                    const uint8_t* started_after, uint32_t n_lanes, hipStream_t);
+void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
+void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
+void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t);
+uint32_t bqc_short_parts();
+void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
+void bqc_launch_err_merge(ErrRec* dst, const ErrRec* src, hipStream_t);
+}
+
+using clk = std::chrono::steady_clock;
+static double secs_since(clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); }
+static int timing_level()
+{
+    static const int lv = [] { const char* e = getenv("BQC_TIMING"); return e ? atoi(e) : 0; }();
+    return lv;
+}
+
+void bqc_state_ready(bqc_ctx* c)
+{
+    if (!c->t8_slots_used) return;
+    bqc_launch_t8_fold(c->d_t8rows, c->d_t8used, c->t8_slots_used, c->sl, c->d_state, c->t8_rows_lane, c->stream);
+    c->t8_slots_used = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host pass: sizes, read groups, coverage anchors
+// ---------------------------------------------------------------------------------------------------
+static int host_pass(bqc_ctx* c, const bqc_batch* b, HostPass& H)
+{
+    const uint32_t n = b->n_reads, nl = c->opt.n_lanes;
+    H.n = n;
+    // (a) on the host's cores: payload sizes, reads per read group, reads for the generic kernels
+    const unsigned nt_max = std::min(16u, bqc_host_threads());
+    struct Part { uint64_t s1 = 0, s2 = 0, s3 = 0; uint32_t n_slow = 0, max_slow = 0; std::vector<uint64_t> lanes; };
+    std::vector<Part> part(nt_max);
+    const unsigned nt = parallel_ranges(n, nt_max, 1 << 17, [&](unsigned t, size_t lo, size_t hi) {
+        Part& P = part[t];
+        P.lanes.assign(nl, 0);
+        uint64_t s1 = 0, s2 = 0, s3 = 0;
+        uint32_t ns = 0, ms = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const uint32_t L = b->l_seq[i], lane = b->lane[i];
+            s1 += (L + 1) / 2; s2 += L; s3 += b->n_cigar[i];
+            if (lane < nl) P.lanes[lane]++;
+            if (c->no_fast || L > BQC_FAST_MAXLEN) { ++ns; ms = std::max(ms, L); }
+        }
+        P.s1 = s1; P.s2 = s2; P.s3 = s3; P.n_slow = ns; P.max_slow = ms;
+    });
+    H.seq_bytes = H.qual_bytes = H.cigar_words = 0;
+    H.n_slow = H.max_len_slow = 0;
+    H.lane_count.assign(nl, 0);
+    for (unsigned t = 0; t < nt; ++t) {
+        H.seq_bytes += part[t].s1; H.qual_bytes += part[t].s2; H.cigar_words += part[t].s3;
+        H.n_slow += part[t].n_slow; H.max_len_slow = std::max(H.max_len_slow, part[t].max_slow);
+        for (uint32_t l = 0; l < nl; ++l) H.lane_count[l] += part[t].lanes[l];
+    }
+    uint32_t lanes_present = 0;
+    H.t8_lane = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+        if (H.lane_count[l]) ++lanes_present;
+        if (H.lane_count[l] > H.lane_count[H.t8_lane]) H.t8_lane = l;
+    }
+    uint64_t in_lanes = 0;
+    for (uint32_t l = 0; l < nl; ++l) in_lanes += H.lane_count[l];
+    // (a read whose lane is out of range ends the run on the device — check 2 — and the batch then contributes nothing; such
+    // reads still need a place in the decomposition: they go in front of read group 0)
+    const uint64_t n_bad = n - in_lanes;
+    H.multi_lane = lanes_present > 1 || (n_bad > 0 && in_lanes > 0);
+    // (b) processing order: reads grouped by read group (stable); lane stretches and super-windows
+    H.stretches.clear(); H.sws.clear();
+    auto add_stretch = [&](uint32_t lane, uint32_t begin, uint32_t count) {
+        if (!count) return;
+        Stretch S{lane, (uint32_t)H.sws.size(), 0, 0};
+        for (uint32_t p = 0; p < count; p += BQC_SW_READS)
+            H.sws.push_back(SuperWindow{lane, begin + p, std::min<uint32_t>(BQC_SW_READS, count - p), (uint32_t)H.stretches.size()});
+        S.sw_end = (uint32_t)H.sws.size();
+        H.stretches.push_back(S);
+    };
+    if (!H.multi_lane) {
+        H.order.clear();
+        uint32_t lane = 0;
+        for (uint32_t l = 0; l < nl; ++l) if (H.lane_count[l]) lane = l;
+        add_stretch(lane, 0, n);
+    } else {
+        std::vector<uint64_t> w(nl); // where the next read of each read group goes
+        uint64_t at = n_bad, w_bad = 0;
+        for (uint32_t l = 0; l < nl; ++l) { w[l] = at; at += H.lane_count[l]; }
+        for (uint32_t l = 0; l < nl; ++l) add_stretch(l, (uint32_t)(l == 0 ? 0 : w[l]), (uint32_t)(H.lane_count[l] + (l == 0 ? n_bad : 0)));
+        { const size_t cap = H.order.capacity(); H.order.resize(n); if (H.order.capacity() != cap) advise_huge(H.order); }
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t lane = b->lane[i];
+            if (lane < nl) H.order[w[lane]++] = i; else H.order[w_bad++] = i;
+        }
+    }
+    // (c) the order-dependent part of OverallNumbers::coverage, in stream order: anchors (OverallNumbers.hpp:84-110).  Every
+    // 1000-position window is numbered in flush order ("virtual coordinates"): a reset advances the window index by 2, a slide
+    // by 1.  A read that enters coverage() gets {window, position in it}; the covered interval comes from its CIGAR on the device.
+    { const size_t cap = H.cov.capacity(); H.cov.resize(n); if (H.cov.capacity() != cap) advise_huge(H.cov); }
+    H.lane_mask.assign(nl, 0);
+    H.lane_first.resize(nl);
+    std::vector<uint8_t> started_before(nl);
+    std::vector<uint32_t> last_rel(nl, 0);
+    for (uint32_t l = 0; l < nl; ++l) {
+        started_before[l] = !c->cov[l].first;
+        c->cov[l].batch_base = c->cov[l].win;
+        H.lane_first[l].clear();
+    }
+    const uint32_t n_refs = c->opt.n_refs;
+    const uint8_t* main_chrom = c->main_chrom.data();
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t flag = b->flag[i], lane = b->lane[i];
+        const int32_t rid = b->rid[i];
+        // primary record with a first / last flag, on a main chromosome, mapped, not a duplicate (bamqualcheck.cpp:318-327,392,430-433)
+        const bool cand = !(flag & 0x900u) && (flag & 0xC0u) && !(flag & 0x4u) && !(flag & 0x400u) && rid >= 0 && (uint32_t)rid < n_refs && main_chrom[rid] &&
+                          lane < nl;
+        if (!cand) { H.cov[i] = CovEntry{BQC_COV_NONE, 0}; continue; }
+        LaneCov& s = c->cov[lane];
+        const uint32_t beginpos = (uint32_t)b->pos[i];
+        if (s.first) { s.first = false; s.id = rid; s.shift = (int32_t)beginpos; }
+        if (s.id != rid || (uint32_t)(beginpos - (uint32_t)s.shift) > 2u * BQC_VSIZE) { // reset: two windows flushed
+            s.id = rid; s.win += 2; s.shift = (int32_t)beginpos;
+        }
+        uint32_t pos = beginpos - (uint32_t)s.shift;
+        if (pos > BQC_VSIZE && pos < 2u * BQC_VSIZE) { // slide: one window flushed
+            s.win += 1; s.shift += BQC_VSIZE; pos = beginpos - (uint32_t)s.shift;
+        }
+        const uint64_t rel = s.win - s.batch_base;
+        if (rel > 0xFFFFFFF0ull) return bqc_fail(c, BQC_ERR_ARG, "batch spans too many coverage windows (split the batch)");
+        H.cov[i] = CovEntry{(uint32_t)rel, pos};
+        std::vector<uint32_t>& first = H.lane_first[lane]; // first[k] = first read of the lane whose window is >= k
+        if (first.size() <= rel) first.resize((size_t)rel + 1, i);
+        last_rel[lane] = (uint32_t)rel;
+    }
+    // coverage tiles: the tiles that hold a live window of some read (its first and the next one), the two windows carried in
+    // from the previous batch and the two carried out (W1, W1 + 1 = the last read's)
+    H.tiles.clear(); H.add_idx.clear(); H.add_val.clear();
+    for (uint32_t l = 0; l < nl; ++l) {
+        const std::vector<uint32_t>& first = H.lane_first[l];
+        if (first.empty()) continue;
+        H.lane_mask[l] = 1;
+        const uint32_t W1 = last_rel[l]; // windows < W1 are complete after this batch
+        auto first_at = [&](uint64_t k) { return k < first.size() ? first[k] : n; };
+        uint32_t last_tile = 0xFFFFFFFFu;
+        uint64_t covered_final = 0;
+        auto push_tile = [&](uint32_t w) {
+            const uint32_t t = w / BQC_COV_TILE_WINDOWS;
+            if (last_tile != 0xFFFFFFFFu && t <= last_tile) return;
+            last_tile = t;
+            const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
+            CovTile ct{};
+            ct.lane = l; ct.win_lo = wlo; ct.win_final = W1; ct.mixed = H.multi_lane ? 1u : 0u;
+            ct.list_begin = first_at(wlo == 0 ? 0 : wlo - 1);
+            ct.list_end = first_at((uint64_t)wlo + BQC_COV_TILE_WINDOWS);
+            H.tiles.push_back(ct);
+            const uint64_t hi = std::min<uint64_t>((uint64_t)wlo + BQC_COV_TILE_WINDOWS, W1);
+            if (hi > wlo) covered_final += hi - wlo;
+        };
+        if (started_before[l]) { push_tile(0); push_tile(1); }
+        // a window value w is live for some read iff a read's first window is w: first[w] != first[w + 1] (or w is the last)
+        for (uint64_t w = 0; w < first.size(); ++w) {
+            const bool present = w + 1 == first.size() || first[w] != first[w + 1];
+            if (present) { push_tile((uint32_t)w); push_tile((uint32_t)w + 1); }
+        }
+        if (W1 > covered_final) { // complete windows nobody touched: depth 0 everywhere
+            H.add_idx.push_back(c->sl.lane_base(l) + c->sl.o_poscov + 0);
+            H.add_val.push_back((uint64_t)(W1 - covered_final) * BQC_VSIZE);
+        }
+        c->cov[l].batch_base = c->cov[l].win; // the next batch numbers its windows from this batch's last live window
+    }
+    H.started_after.resize(nl);
+    for (uint32_t l = 0; l < nl; ++l) H.started_after[l] = !c->cov[l].first; // lanes that have seen a coverage read so far
+    for (uint32_t e = 0; e < b->n_nm_extra; ++e)
+        if (b->nm_extra_read[e] >= n) return bqc_fail(c, BQC_ERR_ARG, "nm_extra_read out of range");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device image of a batch
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+}
+
+// carve m.dmem (allocating / growing it) for a batch of the given sizes and fill in the DevBatch / PrepArgs pointers
+static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostPass& H, bool from_pool)
+{
+    const uint64_t n = H.n;
+    const uint32_t nl = c->opt.n_lanes;
+    Carver cv;
+    cv.take(256);
+    m.h2d_begin = cv.off;
+    const size_t cb[13] = {2 * n, n, n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * n, 2 * n, H.seq_bytes, H.qual_bytes, 4 * H.cigar_words};
+    for (int k = 0; k < 13; ++k) { m.col_bytes[k] = cb[k]; m.o_col[k] = cv.take(cb[k] + (k >= 10 ? 512 : 0)); }
+    m.o_xr = cv.take(4ull * b->n_nm_extra); m.o_xv = cv.take(4ull * b->n_nm_extra);
+    m.o_cov_in = cv.take(sizeof(CovEntry) * n);
+    m.o_order = cv.take(H.multi_lane ? 4 * n : 0);
+    m.o_sws = cv.take(sizeof(SuperWindow) * H.sws.size());
+    m.o_stretch = cv.take(sizeof(Stretch) * H.stretches.size());
+    m.o_tiles = cv.take(sizeof(CovTile) * H.tiles.size());
+    m.o_mask = cv.take(nl); m.o_started = cv.take(nl);
+    m.o_aidx = cv.take(8 * H.add_idx.size()); m.o_aval = cv.take(8 * H.add_val.size());
+    m.h2d_end = cv.off;
+    // outputs of the device pre-pass
+    const uint64_t nblk = (n + 1023) / 1024, n_sw = H.sws.size(), n_st = H.stretches.size();
+    const uint64_t perm_cap = 3 * n + H.cigar_words + 128 * (n_sw + n_st + 1);
+    const uint64_t cf_cap = (2 * n + 128 * n_sw) / 256 + H.cigar_words / 256 + 4 * n_st + 16;
+    const uint64_t cs_cap = H.n_slow / BQC_CHUNK_READS + n_st + 4;
+    const uint64_t cx_cap = H.cigar_words / 2 + 1;
+    if (perm_cap > 0xFFFFFFF0ull) return bqc_fail(c, BQC_ERR_ARG, "batch too large (split the batch)");
+    const size_t o_flag2 = cv.take(2 * n), o_soff = cv.take(4 * n), o_qoff = cv.take(4 * n), o_cgoff = cv.take(4 * n), o_cov = cv.take(sizeof(CovEntry) * n),
+                 o_covx = cv.take(sizeof(CovExtra) * cx_cap), o_nseg = cv.take(n), o_segs = cv.take(sizeof(TripSeg) * (H.cigar_words + 1)),
+                 o_perm = cv.take(4 * perm_cap), o_cf = cv.take(sizeof(Chunk) * cf_cap), o_cs = cv.take(sizeof(Chunk) * cs_cap),
+                 o_desc = cv.take(sizeof(BatchDesc)), o_err = cv.take(sizeof(ErrRec)), o_cursave = cv.take(8), o_bsz = cv.take(24 * nblk), o_btgt = cv.take(8 * nblk),
+                 o_bmf = cv.take(8 * nblk), o_swc = cv.take(sizeof(SwCounts) * n_sw), o_swp = cv.take(sizeof(SwPlan) * n_sw),
+                 o_rsum = cv.take(H.n_slow ? 12 * n : 0);
+    const size_t need = cv.off + 256;
+    if (m.dcap < need) {
+        if (m.dmem) { (void)hipFree(m.dmem); m.dmem = nullptr; m.dcap = 0; }
+        if (from_pool)
+            for (size_t k = 0; k < c->pool.size(); ++k)
+                if (c->pool[k].second >= need && c->pool[k].second <= 2 * need + (64u << 20)) { // a freed buffer of a similar size
+                    m.dmem = c->pool[k].first; m.dcap = c->pool[k].second;
+                    c->pool.erase(c->pool.begin() + k);
+                    break;
+                }
+        if (!m.dmem) {
+            const size_t cap = need + need / 8; // a little slack, so that the next batch of about this size fits as well
+            const hipError_t he = hipMalloc(&m.dmem, cap);
+            if (he != hipSuccess) { m.dmem = nullptr; return bqc_fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(he)); }
+            m.dcap = cap;
+        }
+    }
+    char* base = (char*)m.dmem;
+    DevBatch& d = m.d;
+    d = DevBatch{};
+    d.n_reads = (uint32_t)n;
+    d.flag = (const uint16_t*)(base + o_flag2);
+    d.mapq = (const uint8_t*)(base + m.o_col[1]); d.lane = (const uint8_t*)(base + m.o_col[2]);
+    d.rid = (const int32_t*)(base + m.o_col[3]); d.pos = (const int32_t*)(base + m.o_col[4]); d.tlen = (const int32_t*)(base + m.o_col[5]);
+    d.nm = (const int32_t*)(base + m.o_col[6]); d.as_ = (const int32_t*)(base + m.o_col[7]); d.l_seq = (const uint32_t*)(base + m.o_col[8]);
+    d.n_cigar = (const uint16_t*)(base + m.o_col[9]);
+    d.seq = (const uint8_t*)(base + m.o_col[10]); d.qual = (const uint8_t*)(base + m.o_col[11]); d.cigar = (const uint32_t*)(base + m.o_col[12]);
+    d.seq_off = (const uint32_t*)(base + o_soff); d.qual_off = (const uint32_t*)(base + o_qoff); d.cigar_off = (const uint32_t*)(base + o_cgoff);
+    d.order = H.multi_lane ? (const uint32_t*)(base + m.o_order) : nullptr;
+    d.perm = (const uint32_t*)(base + o_perm);
+    d.chunks = (const Chunk*)(base + o_cs); d.chunks_fast = (const Chunk*)(base + o_cf);
+    d.desc = (const BatchDesc*)(base + o_desc);
+    d.nm_extra_read = (const uint32_t*)(base + m.o_xr); d.nm_extra_val = (const int32_t*)(base + m.o_xv); d.n_nm_extra = b->n_nm_extra;
+    d.cov = (const CovEntry*)(base + o_cov); d.cov_extra = (const CovExtra*)(base + o_covx);
+    d.cov_tiles = (const CovTile*)(base + m.o_tiles); d.n_cov_tiles = (uint32_t)H.tiles.size();
+    d.segs = (const TripSeg*)(base + o_segs);
+    PrepArgs& p = m.prep;
+    p = PrepArgs{};
+    p.n = (uint32_t)n; p.n_lanes = nl; p.max_read_len = c->opt.max_read_len; p.no_fast = c->no_fast ? 1u : 0u; p.replay = 0;
+    p.flag_in = (const uint16_t*)(base + m.o_col[0]); p.mapq = d.mapq; p.lane = d.lane; p.rid = d.rid; p.pos = d.pos; p.as_ = d.as_;
+    p.l_seq = d.l_seq; p.n_cigar = d.n_cigar; p.qual = d.qual; p.cigar = d.cigar;
+    p.cov_in = (const CovEntry*)(base + m.o_cov_in); p.order = d.order;
+    p.sws = (const SuperWindow*)(base + m.o_sws); p.n_sw = (uint32_t)n_sw;
+    p.stretches = (const Stretch*)(base + m.o_stretch); p.n_stretch = (uint32_t)n_st;
+    p.fasta_index = c->d_fasta_index;
+    p.flag_out = (uint16_t*)(base + o_flag2); p.seq_off = (uint32_t*)(base + o_soff); p.qual_off = (uint32_t*)(base + o_qoff);
+    p.cigar_off = (uint32_t*)(base + o_cgoff); p.cov_out = (CovEntry*)(base + o_cov); p.cov_extra = (CovExtra*)(base + o_covx);
+    p.cov_extra_cap = (uint32_t)std::min<uint64_t>(cx_cap, 0xFFFFFFFFull); p.nseg = (uint8_t*)(base + o_nseg); p.segs = (TripSeg*)(base + o_segs);
+    p.perm = (uint32_t*)(base + o_perm); p.perm_cap = (uint32_t)perm_cap;
+    p.chunks_fast = (Chunk*)(base + o_cf); p.chunks_fast_cap = (uint32_t)cf_cap;
+    p.chunks_slow = (Chunk*)(base + o_cs); p.chunks_slow_cap = (uint32_t)cs_cap;
+    p.desc = (BatchDesc*)(base + o_desc); p.err = (ErrRec*)(base + o_err);
+    p.cursor = c->d_cursor; p.cursor_save = (int32_t*)(base + o_cursave);
+    p.blk_sizes = (unsigned long long*)(base + o_bsz); p.blk_tgt = (uint32_t*)(base + o_btgt); p.blk_maxfast = (uint32_t*)(base + o_bmf);
+    p.sw_counts = (SwCounts*)(base + o_swc); p.sw_plan = (SwPlan*)(base + o_swp);
+    m.d_lane_mask = (uint8_t*)(base + m.o_mask); m.d_started_after = (uint8_t*)(base + m.o_started);
+    m.d_add_idx = (uint64_t*)(base + m.o_aidx); m.d_add_val = (uint64_t*)(base + m.o_aval); m.n_add = (uint32_t)H.add_idx.size();
+    m.d_rsum = H.n_slow ? (uint32_t*)(base + o_rsum) : nullptr;
+    m.d_err = p.err;
+    m.algo_bytes = 48ull * n + H.seq_bytes + H.qual_bytes + 4 * H.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
+    m.n_slow = H.n_slow; m.max_len_slow = H.max_len_slow; m.n_chunks_slow_ub = (uint32_t)cs_cap; m.t8_lane = H.t8_lane;
+    m.processed = false;
+    return 0;
+}
+
+// the tables of the host pass into the image (host memory laid out like the device buffer from h2d_begin on)
+static void fill_tables(const BatchMem& m, const bqc_batch* b, const HostPass& H, char* img, size_t img_begin /* device offset of img[0]: <= o_xr */)
+{
+    auto at = [&](size_t off) { return img + (off - img_begin); };
+    if (b->n_nm_extra) { memcpy(at(m.o_xr), b->nm_extra_read, 4ull * b->n_nm_extra); memcpy(at(m.o_xv), b->nm_extra_val, 4ull * b->n_nm_extra); }
+    memcpy(at(m.o_cov_in), H.cov.data(), sizeof(CovEntry) * (size_t)H.n);
+    if (H.multi_lane) memcpy(at(m.o_order), H.order.data(), 4ull * H.n);
+    memcpy(at(m.o_sws), H.sws.data(), sizeof(SuperWindow) * H.sws.size());
+    memcpy(at(m.o_stretch), H.stretches.data(), sizeof(Stretch) * H.stretches.size());
+    if (!H.tiles.empty()) memcpy(at(m.o_tiles), H.tiles.data(), sizeof(CovTile) * H.tiles.size());
+    memcpy(at(m.o_mask), H.lane_mask.data(), H.lane_mask.size());
+    memcpy(at(m.o_started), H.started_after.data(), H.started_after.size());
+    if (!H.add_idx.empty()) { memcpy(at(m.o_aidx), H.add_idx.data(), 8 * H.add_idx.size()); memcpy(at(m.o_aval), H.add_val.data(), 8 * H.add_val.size()); }
+}
+
+static const void* column_ptr(const bqc_batch* b, int k)
+{
+    switch (k) {
+    case 0: return b->flag; case 1: return b->mapq; case 2: return b->lane; case 3: return b->rid; case 4: return b->pos; case 5: return b->tlen;
+    case 6: return b->nm; case 7: return b->as; case 8: return b->l_seq; case 9: return b->n_cigar; case 10: return b->seq; case 11: return b->qual;
+    default: return b->cigar;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launches of one batch (compute stream, in batch order)
+// ---------------------------------------------------------------------------------------------------
+static void tick(bqc_ctx* c, const char* name)
+{
+    if (!c->timing || c->n_timed + 1 >= (int)c->ev.size()) return;
+    (void)hipEventRecord(c->ev[c->n_timed + 1], c->stream);
+    c->tnames.push_back(name);
+    c->n_timed++;
+}
+
+static int enqueue_kernels(bqc_ctx* c, BatchMem& m)
+{
+    DevRefs refs{(const uint8_t* const*)c->d_ref_ptrs, c->d_ref_len, c->d_main, c->opt.n_refs, (const uint32_t* const*)c->d_refn_ptrs};
+    uint32_t* err = &m.d_err->flags;
+    const DevBatch& d = m.d;
+    if (d.n_reads == 0) { if (c->timing) { c->n_timed = 0; c->tnames.clear(); } return 0; }
+    if (c->timing) { c->n_timed = 0; c->tnames.clear(); (void)hipEventRecord(c->ev[0], c->stream); }
+    m.prep.replay = m.processed ? 1u : 0u;
+    bqc_launch_prep(m.prep, refs, c->stream);
+    m.processed = true;
+    tick(c, "k_prep");
+    if (!d.n_cov_tiles) bqc_launch_or_bytes(c->d_started, m.d_started_after, c->opt.n_lanes, c->stream); // (else: k_cov's epilogue)
+    if (d.n_reads > m.n_slow) { // reads on the short-read fast path
+        const uint32_t grid = c->n_cu; // one workgroup per CU (the chunk count is on the device); every workgroup owns a slot of scratch rows
+        if (!(bqc_short_parts() & 8u)) { // (profiling only: per-read statistics of the fast chunks as a separate kernel)
+            bqc_launch_reads_chunks(d, c->sl, c->d_state, refs, err, c->n_cu * 8, 1, c->stream);
+            tick(c, "k_reads");
+        }
+        if (c->t8_rows_lane != m.t8_lane || c->t8_slots_used + grid > c->t8_slots_cap) { bqc_state_ready(c); c->t8_rows_lane = m.t8_lane; }
+        bqc_launch_short(d, c->sl, c->d_state, refs, err, grid, c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + c->t8_slots_used,
+                         m.t8_lane, c->stream);
+        c->t8_slots_used += grid;
+        tick(c, "k_short");
+    }
+    if (m.n_slow) {
+        bqc_launch_reads_chunks(d, c->sl, c->d_state, refs, err, std::min(m.n_chunks_slow_ub, c->n_cu * 8), 0, c->stream);
+        tick(c, "k_reads(generic)");
+        HIPCHK(c, hipMemsetAsync(m.d_rsum, 0, 12ull * d.n_reads, c->stream));
+        bqc_launch_long(d, c->sl, c->d_state, refs, err, m.d_rsum, m.max_len_slow, m.n_chunks_slow_ub, c->n_cu, c->stream);
+        tick(c, "k_long");
+    }
+    if (d.n_nm_extra) bqc_launch_nm_extra(d, c->sl, c->d_state, refs, err, c->stream);
+    if (d.n_cov_tiles) bqc_launch_cov(d, c->sl, c->d_state, c->d_carry, c->d_parity, m.d_lane_mask, c->d_started, m.d_started_after, c->opt.n_lanes, c->stream);
+    bqc_launch_add_words(c->d_state, m.d_add_idx, m.d_add_val, m.n_add, c->stream);
+    tick(c, "k_cov");
+    if (c->sketch) { sketch_process(c->sketch, d, c->stream); tick(c, "k_sketch"); }
+    bqc_launch_err_merge(c->d_err0, m.d_err, c->stream); // the first batch with an error defines the stream's error
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// what the device found wrong with a batch -> error code and message (the reference prints a message and exits 1)
+int bqc_report_errors(bqc_ctx* c, const ErrRec& e)
+{
+    if (e.first_key != BQC_ERRKEY_NONE) {
+        const uint32_t i = (uint32_t)(e.first_key >> 3), order = (uint32_t)(e.first_key & 7u);
+        switch (order) {
+        case 1: return bqc_fail(c, BQC_ERR_RANGE, "read %u is %u bases long; max_read_len is %u", i, e.aux0, c->opt.max_read_len);
+        case 2: return bqc_fail(c, BQC_ERR_ARG, "read %u: lane %u out of range", i, e.aux0);
+        case 3: return bqc_fail(c, BQC_ERR_ARG, "batch too large: payload offsets exceed 32 bits (split the batch)");
+        case 4: return bqc_fail(c, BQC_ERR_AS_TAG, "ERROR: read %u has no usable AS tag.", i);
+        case 5: return bqc_fail(c, BQC_ERR_FASTA, "ERROR: Could not read fasta record for reference id %d (read %u)", (int32_t)e.aux0, i);
+        default: return bqc_fail(c, BQC_ERR_NO_MATE_FLAG, "ERROR: No first or second flag in read %u", i);
+        }
+    }
+    if (!e.flags) return 0;
+    if (e.flags & BQC_DEVERR_INTERNAL) return bqc_fail(c, BQC_ERR_DEVICE, "internal error: kernel layout assumption violated");
+    if (e.flags & BQC_DEVERR_MATE) return bqc_fail(c, BQC_ERR_NO_MATE_FLAG, "ERROR: No first or second flag in read");
+    if (e.flags & BQC_DEVERR_RANGE) return bqc_fail(c, BQC_ERR_RANGE, "mismatch/deletion/insertion count exceeds hist_cap (or NM < D+I)");
+    return bqc_fail(c, BQC_ERR_RANGE, "base quality above 222 cannot be represented by the reference (q+33 wraps)");
+}
+static int poison(bqc_ctx* c, int code) { c->poisoned = true; c->poison_code = code; return code; }
+
+// ---------------------------------------------------------------------------------------------------
+// resident batches: bqc_upload / bqc_process (benchmark, tests; everything synchronous on the compute stream)
+// ---------------------------------------------------------------------------------------------------
+extern "C" void bqc_dbatch_free(bqc_ctx* c, bqc_dbatch* db)
+{
+    if (!db) return;
+    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    if (c && db->m.dmem && c->pool.size() < 3) c->pool.emplace_back(db->m.dmem, db->m.dcap);
+    else (void)hipFree(db->m.dmem);
+    delete db;
+}
+extern "C" uint64_t bqc_dbatch_bytes(const bqc_dbatch* db) { return db ? db->m.algo_bytes : 0; }
+
+static int check_batch_args(bqc_ctx* c, const bqc_batch* b, const char* who)
+{
+    if (!c || !b) return bqc_fail(c, BQC_ERR_ARG, "%s: null argument", who);
+    if (c->poisoned) return bqc_fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->flushed) return bqc_fail(c, BQC_ERR_STATE, "%s after bqc_flush/bqc_finalize (call bqc_reset first)", who);
+    if (b->n_reads && (!b->flag || !b->mapq || !b->lane || !b->rid || !b->pos || !b->tlen || !b->nm || !b->as || !b->l_seq || !b->n_cigar))
+        return bqc_fail(c, BQC_ERR_ARG, "%s: null column", who);
+    if (b->n_nm_extra && (!b->nm_extra_read || !b->nm_extra_val)) return bqc_fail(c, BQC_ERR_ARG, "%s: null nm_extra column", who);
+    return 0;
+}
+
+extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
+{
+    if (!out) return bqc_fail(c, BQC_ERR_ARG, "bqc_upload: null argument");
+    int rc = check_batch_args(c, b, "bqc_upload");
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const auto t0 = clk::now();
+    HostPass& H = c->hp;
+    if ((rc = host_pass(c, b, H))) return poison(c, rc);
+    const double t_pass = secs_since(t0);
+    bqc_dbatch* db = new bqc_dbatch();
+    if ((rc = layout_batch(c, db->m, b, H, true))) { delete db; return poison(c, rc); }
+    BatchMem& m = db->m;
+    char* base = (char*)m.dmem;
+    std::vector<char> img(m.h2d_end - m.o_xr);
+    fill_tables(m, b, H, img.data(), m.o_xr);
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < 13 && he == hipSuccess; ++k)
+        if (m.col_bytes[k]) he = hipMemcpyAsync(base + m.o_col[k], column_ptr(b, k), m.col_bytes[k], hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(base + m.o_xr, img.data(), img.size(), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream); // buffers may be reused by the caller on return
+    if (he != hipSuccess) { bqc_dbatch_free(c, db); poison(c, BQC_ERR_DEVICE); return bqc_fail(c, BQC_ERR_DEVICE, "upload failed: %s", hipGetErrorString(he)); }
+    if (timing_level() == 2)
+        fprintf(stderr, "[timing] upload of %u reads: host pass %.4f s, H2D %.4f s (%.1f MB)\n", b->n_reads, t_pass, secs_since(t0) - t_pass, (m.h2d_end - m.h2d_begin) / 1e6);
+    db->cov_after = c->cov;
+    db->seq = ++c->upload_counter;
+    c->state_seq = db->seq;
+    *out = db;
+    return 0;
+}
+
+extern "C" int bqc_process(bqc_ctx* c, bqc_dbatch* db)
+{
+    if (!c || !db) return bqc_fail(c, BQC_ERR_ARG, "bqc_process: null argument");
+    if (c->poisoned) return bqc_fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->flushed) return bqc_fail(c, BQC_ERR_STATE, "bqc_process after bqc_flush (call bqc_reset first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (db->seq > c->state_seq) { // re-processing after bqc_reset: this batch (uploaded on a fresh context) defines the stream state again
+        c->cov = db->cov_after;
+        c->state_seq = db->seq;
+    }
+    return enqueue_kernels(c, db->m);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the submit pipeline
+// ---------------------------------------------------------------------------------------------------
+static int retire_slot(bqc_ctx* c, Slot& s) // wait for the slot's batch and read what the device found
+{
+    if (!s.busy) return 0;
+    HIPCHK(c, hipEventSynchronize(s.ev_done));
+    s.busy = false;
+    if (s.ticket > c->checked_ticket) c->checked_ticket = s.ticket;
+    const int rc = bqc_report_errors(c, *s.h_err);
+    return rc ? poison(c, rc) : 0;
+}
+
+int bqc_drain(bqc_ctx* c)
+{
+    int first = 0;
+    for (uint64_t t = c->checked_ticket + 1; t < c->next_ticket; ++t) { // in submission order: the first failing batch wins
+        Slot& s = c->slots[t % bqc_ctx::kSlots];
+        if (!s.busy || s.ticket != t) continue;
+        if (first) { (void)hipEventSynchronize(s.ev_done); s.busy = false; continue; }
+        const int rc = retire_slot(c, s);
+        if (rc) first = rc;
+    }
+    if (c->next_ticket) c->checked_ticket = c->next_ticket - 1;
+    return first;
+}
+
+void bqc_pipeline_destroy(bqc_ctx* c)
+{
+    for (Slot& s : c->slots) {
+        if (s.busy && s.ev_done) (void)hipEventSynchronize(s.ev_done);
+        if (s.m.dmem) (void)hipFree(s.m.dmem);
+        if (s.hmem) (void)hipHostFree(s.hmem);
+        if (s.h_err) (void)hipHostFree(s.h_err);
+        if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        s = Slot();
+    }
+    for (auto& pb : c->pool) (void)hipFree(pb.first);
+    c->pool.clear();
+}
+
+static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint64_t* ticket_out)
+{
+    int rc = check_batch_args(c, b, "bqc_submit");
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (ticket_out) *ticket_out = 0;
+    if (b->n_reads == 0) return 0;
+    const uint64_t ticket = c->next_ticket;
+    Slot& s = c->slots[ticket % bqc_ctx::kSlots];
+    const auto t0 = clk::now();
+    if ((rc = retire_slot(c, s))) return rc; // the batch submitted kSlots calls ago: its errors surface here
+    const double t_wait = secs_since(t0);
+    if (!s.ev_done) {
+        HIPCHK(c, hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&s.h_err, sizeof(ErrRec), hipHostMallocDefault));
+    }
+    HostPass& H = c->hp;
+    if ((rc = host_pass(c, b, H))) return poison(c, rc);
+    const double t_pass = secs_since(t0) - t_wait;
+    if ((rc = layout_batch(c, s.m, b, H, false))) return poison(c, rc);
+    BatchMem& m = s.m;
+    // page-locked image: the host pass's tables, and the columns too unless the caller's are page-locked already
+    const size_t img_begin = pinned_columns ? m.o_xr : m.h2d_begin, img_bytes = m.h2d_end - img_begin;
+    if (s.hcap < img_bytes) {
+        if (s.hmem) (void)hipHostFree(s.hmem);
+        s.hmem = nullptr; s.hcap = 0;
+        const size_t cap = img_bytes + img_bytes / 8 + 4096;
+        const hipError_t he = hipHostMalloc((void**)&s.hmem, cap, hipHostMallocDefault);
+        if (he != hipSuccess) { poison(c, BQC_ERR_DEVICE); return bqc_fail(c, BQC_ERR_DEVICE, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(he)); }
+        s.hcap = cap;
+    }
+    fill_tables(m, b, H, s.hmem, img_begin);
+    char* base = (char*)m.dmem;
+    hipError_t he = hipSuccess;
+    if (pinned_columns) {
+        for (int k = 0; k < 13 && he == hipSuccess; ++k)
+            if (m.col_bytes[k]) he = hipMemcpyAsync(base + m.o_col[k], column_ptr(b, k), m.col_bytes[k], hipMemcpyHostToDevice, c->copy_stream);
+    } else { // stage the columns: the caller may reuse its buffers on return
+        struct Piece { char* dst; const char* src; size_t n; };
+        Piece pc[13];
+        size_t total = 0;
+        for (int k = 0; k < 13; ++k) { pc[k] = Piece{s.hmem + (m.o_col[k] - m.h2d_begin), (const char*)column_ptr(b, k), m.col_bytes[k]}; total += m.col_bytes[k]; }
+        parallel_ranges(total, std::min(8u, bqc_host_threads()), 16u << 20, [&](unsigned, size_t lo, size_t hi) {
+            size_t at = 0;
+            for (int k = 0; k < 13; ++k) { // the byte range [lo, hi) of the concatenated columns
+                const size_t a = std::max(lo, at), z = std::min(hi, at + pc[k].n);
+                if (a < z) memcpy(pc[k].dst + (a - at), pc[k].src + (a - at), z - a);
+                at += pc[k].n;
+            }
+        });
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(base + img_begin, s.hmem, img_bytes, hipMemcpyHostToDevice, c->copy_stream);
+    if (he == hipSuccess) he = hipEventRecord(s.ev_h2d, c->copy_stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, s.ev_h2d, 0);
+    if (he != hipSuccess) { poison(c, BQC_ERR_DEVICE); return bqc_fail(c, BQC_ERR_DEVICE, "upload failed: %s", hipGetErrorString(he)); }
+    if ((rc = enqueue_kernels(c, m))) return poison(c, rc);
+    HIPCHK(c, hipMemcpyAsync(s.h_err, m.d_err, sizeof(ErrRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
+    s.busy = true;
+    s.ticket = ticket;
+    c->next_ticket = ticket + 1;
+    c->state_seq = ++c->upload_counter;
+    if (ticket_out) *ticket_out = ticket;
+    if (timing_level() == 2)
+        fprintf(stderr, "[timing] submit of %u reads: waited %.4f s for the slot, host pass %.4f s, staging + enqueue %.4f s (%.1f MB to the device)\n", b->n_reads, t_wait,
+                t_pass, secs_since(t0) - t_wait - t_pass, (m.h2d_end - m.h2d_begin) / 1e6);
+    return 0;
+}
+
+extern "C" int bqc_submit(bqc_ctx* c, const bqc_batch* b) { return submit_impl(c, b, false, nullptr); }
+extern "C" int bqc_submit_async(bqc_ctx* c, const bqc_batch* b, uint64_t* ticket) { return submit_impl(c, b, true, ticket); }
+
+extern "C" int bqc_batch_uploaded(bqc_ctx* c, uint64_t ticket, int wait)
+{
+    if (!c) return -BQC_ERR_ARG;
+    if (ticket == 0 || ticket >= c->next_ticket) return 1;
+    Slot& s = c->slots[ticket % bqc_ctx::kSlots];
+    if (!s.busy || s.ticket != ticket) return 1; // retired (or overwritten by a later batch, which waited for it)
+    if (wait) return hipEventSynchronize(s.ev_h2d) == hipSuccess ? 1 : -BQC_ERR_DEVICE;
+    const hipError_t q = hipEventQuery(s.ev_h2d);
+    return q == hipSuccess ? 1 : q == hipErrorNotReady ? 0 : -BQC_ERR_DEVICE;
+}
+
+extern "C" int bqc_host_register(void* p, uint64_t bytes)
+{
+    if (!p || !bytes) return BQC_ERR_ARG;
+    return hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? 0 : BQC_ERR_DEVICE;
+}
+extern "C" int bqc_host_unregister(void* p) { return p && hipHostUnregister(p) == hipSuccess ? 0 : BQC_ERR_DEVICE; }

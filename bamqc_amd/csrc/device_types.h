@@ -41,24 +41,75 @@ struct TripSeg {
 };
 #define BQC_ENTRY_SEG 0x80000000u // perm entry: TripSeg index (0xFFFFFFFF = padding)
 
-struct CovEntry {     // one covered interval: positions [win * 1000 + off, + len) in window coordinates, off + len <= 2000
-    uint32_t win;     // batch-relative index of the read's first live window
-    uint32_t off_len; // off | len << 16
+// Coverage entry of read i (cov[i]).  The host's anchor pass (OverallNumbers.hpp:84-110) writes {win, pos} for every read that
+// enters coverage(): win = batch-relative index of the read's first live window, pos = beginPos - shift in [0, 2000]
+// (BQC_COV_NONE in win for every other read); k_prep_reads walks the CIGAR and rewrites it as the covered interval
+// [win * 1000 + off, + len), off + len <= 2000, len = 0: nothing.
+struct CovEntry {
+    uint32_t win;
+    uint32_t off_len; // host: pos; device: off | len << 16
+};
+#define BQC_COV_NONE 0xFFFFFFFFu
+struct CovExtra {     // second, third ... covered interval of a read whose clips sit between match operations (rare)
+    uint32_t win, off_len, lane, pad;
 };
 
 struct CovTile {      // BQC_COV_TILE_WINDOWS consecutive coverage windows of one lane
     uint32_t lane;
     uint32_t win_lo;      // first window (batch-relative index)
-    uint32_t list_begin;  // candidate intervals: cov_list[list_begin, list_end)
+    uint32_t list_begin;  // candidate reads: cov[list_begin, list_end) (stream order; entries of other lanes are skipped when `mixed`)
     uint32_t list_end;
     uint32_t win_final;   // windows < win_final are complete -> histogram; win_final, win_final+1 -> carry out
-    uint32_t pad0, pad1, pad2;
+    uint32_t mixed;       // the batch holds several read groups: check lane[i] == lane
+    uint32_t pad1, pad2;
 };
+
+// A run of reads of one read group in processing order (`order`, or the stream itself): the unit the chunk builder works on
+// is a super-window = up to BQC_SW_READS consecutive positions of one stretch.
+#define BQC_SW_READS 4096
+struct SuperWindow {
+    uint32_t lane;
+    uint32_t begin, count; // positions [begin, begin + count) of the processing order
+    uint32_t stretch;      // index of the lane stretch (chunks never span two stretches)
+};
+struct SwCounts {          // k_build_count -> k_build_plan
+    uint32_t n0, n1;       // fast reads by mate slot (first mate / everything else)
+    uint32_t n_slow;       // reads for the generic kernels
+    uint32_t n_seg;        // triplet segments of the fast reads
+};
+struct SwPlan {            // k_build_plan -> k_build_scatter
+    uint32_t group_base;   // perm index of the super-window's first read group
+    uint32_t n_groups;
+    uint32_t seg_base;     // perm index of its first segment entry
+    uint32_t slow_base;    // perm index of its first generic-path read
+};
+
+// What only the device knows about a batch (written by k_build_plan, read by every later kernel of the batch).
+struct BatchDesc {
+    uint32_t n_chunks_fast;  // read chunks and segment chunks of k_short
+    uint32_t n_chunks_slow;  // chunks of k_reads / k_long
+    uint32_t fast_w;         // lanes per read of k_short = ceil(longest fast read / (8 * BQC_FAST_NH))
+    uint32_t n_perm;
+    uint32_t long_max_len;   // longest read of the generic path
+    uint32_t n_cov_extra;
+    uint32_t fatal;          // the pre-pass found a read that ends the reference's run: the hot kernels leave the batch alone
+    uint32_t pad1;
+};
+
+// Error record of a batch: the first failing read in stream order (key = read << 3 | order of the check within a read,
+// 1 length, 2 lane, 3 offsets, 4 AS tag, 5 FASTA, 6 mate flag) and the unordered BQC_DEVERR_* flags of the hot kernels.
+struct ErrRec {
+    unsigned long long first_key; // ~0ull: none
+    uint32_t flags;
+    uint32_t aux0, aux1;          // values for the message (read length / lane / reference id)
+    uint32_t pad;
+};
+#define BQC_ERRKEY_NONE (~0ull)
 
 struct DevBatch {
     uint32_t n_reads;
     // fixed columns, 48 B / read
-    const uint16_t* flag;
+    const uint16_t* flag;      // BAM flag | host annotations (0x1000, 0x8000) | device annotations (BQC_FLAG_TRIPLET / _COV, NO_QUAL): k_prep_reads
     const uint8_t* mapq;
     const uint8_t* lane;
     const int32_t* rid;
@@ -68,30 +119,28 @@ struct DevBatch {
     const int32_t* as_;
     const uint32_t* l_seq;
     const uint16_t* n_cigar;
-    const uint32_t* seq_off;
+    const uint32_t* seq_off;   // payload offsets: prefix sums over the reads (k_prep_sizes / _scan / _reads)
     const uint32_t* qual_off;
     const uint32_t* cigar_off;
     // variable-length payload
     const uint8_t* seq;    // 4-bit packed
     const uint8_t* qual;   // raw Phred
     const uint32_t* cigar; // len<<4|op
-    // work decomposition (host pre-pass)
-    const uint32_t* perm;  // processing order: reads grouped by lane (and by mate inside fast chunks); entries with
-                           // the top bit set are not reads (0xFFFFFFFF padding, else TripSeg index); nullptr = identity
-    uint32_t n_perm;       // entries in perm (>= n_reads because of padding), n_reads when perm == nullptr
-    const Chunk* chunks;
-    uint32_t n_chunks;
+    // work decomposition (device: k_build_*)
+    const uint32_t* order; // processing order of the reads: grouped by read group (host, only when the batch holds several); nullptr = stream order
+    const uint32_t* perm;  // entries of the chunks: read ids grouped by mate slot inside fast chunks; entries with
+                           // the top bit set are not reads (0xFFFFFFFF padding, else TripSeg index)
+    const Chunk* chunks;       // generic chunks (k_reads / k_long)
+    const Chunk* chunks_fast;  // k_short: lane-uniform chunks of reads with L <= 8 * BQC_FAST_NH * fast_w, and of their triplet segments
+    const BatchDesc* desc;     // counts of the tables above (device memory)
     const uint32_t* nm_extra_read;
     const int32_t* nm_extra_val;
     uint32_t n_nm_extra;
-    const CovEntry* cov_list; // covered intervals per read group, in stream order (host pre-pass)
+    const CovEntry* cov;       // [n_reads] covered interval per read (k_prep_reads)
+    const CovExtra* cov_extra; // [desc->n_cov_extra]
     const CovTile* cov_tiles;
     uint32_t n_cov_tiles;
-    // short-read fast path (k_short): lane-uniform chunks of reads with L <= 8 * BQC_FAST_NH * fast_w
-    const Chunk* chunks_fast;
-    uint32_t n_chunks_fast;
-    uint32_t fast_w;           // lanes per read = ceil(max fast read length / (8 * BQC_FAST_NH))
-    const TripSeg* segs;       // triplet segments of fast reads with several CIGAR operations
+    const TripSeg* segs;       // triplet segments of fast reads with several CIGAR operations, at cigar_off[r] + j
 };
 
 struct DevRefs {

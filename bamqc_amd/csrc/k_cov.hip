@@ -4,11 +4,12 @@
 // ---------------------------------------------------------------------------------------------------
 // k_cov — coverage depth histogram
 // ---------------------------------------------------------------------------------------------------
-// Virtual coordinates: the host runs the order-dependent anchor recurrence (OverallNumbers.hpp:84-110), numbers every
-// 1000-position window in flush order and turns every read into its covered interval(s) [win*1000 + off, + len), already
-// truncated at (win+2)*1000 (CovEntry, 8 B).  Depth is then order-free: +1 / -1 into an LDS difference array per interval,
-// prefix scan, clamp-100 histogram.  One workgroup per tile of 4 windows; the intervals of the NEXT tile are loaded (two
-// per thread, coalesced) while the current tile is scanned.
+// Virtual coordinates: the host runs the order-dependent anchor recurrence (OverallNumbers.hpp:84-110) and numbers every
+// 1000-position window in flush order; k_prep_reads turns every read into its covered interval [win*1000 + off, + len), already
+// truncated at (win+2)*1000 (cov[i], 8 B per read; len = 0 for reads that do not enter coverage()).  Depth is then order-free:
+// +1 / -1 into an LDS difference array per interval, prefix scan, clamp-100 histogram.  One workgroup per tile of 4 windows; a
+// tile names the range of reads whose first live window can touch it (windows never decrease along the stream of a read group);
+// the entries of the NEXT tile are loaded (two per thread, coalesced) while the current tile is scanned.
 #define KC_AT(p) ((p) + (((p) >> 6) << 2))
 __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_t* __restrict__ state,
                                                 uint32_t* __restrict__ carry /* [lane][2][2000] */, uint32_t* parity /* [n_lanes], then a counter */,
@@ -26,12 +27,18 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
     CovTile t{};
     t.lane = 0xFFFFFFFFu;
     CovEntry e0{0, 0}, e1{0, 0}; // len = 0: nothing
+    auto load = [&](const CovTile& tt, uint32_t i) { // entry i of the tile's read range (another read group's: nothing)
+        CovEntry e = b.cov[i];
+        if (tt.mixed && b.lane[i] != tt.lane) e.off_len = 0;
+        return e;
+    };
     if (blockIdx.x < b.n_cov_tiles) {
         t = b.cov_tiles[blockIdx.x];
         const uint32_t i0 = t.list_begin + threadIdx.x, i1 = i0 + blockDim.x;
-        if (i0 < t.list_end) e0 = b.cov_list[i0];
-        if (i1 < t.list_end) e1 = b.cov_list[i1];
+        if (i0 < t.list_end) e0 = load(t, i0);
+        if (i1 < t.list_end) e1 = load(t, i1);
     }
+    const uint32_t n_extra = b.desc->n_cov_extra;
     // persistent workgroups: the depth histogram stays in LDS across tiles and is flushed once per lane
     for (uint32_t ti = blockIdx.x;; ti += gridDim.x) {
         const bool done = ti >= b.n_cov_tiles;
@@ -55,7 +62,11 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
             if (a < z) { atomicAdd(&diff[KC_AT((uint32_t)a)], 1); atomicAdd(&diff[KC_AT((uint32_t)z)], -1); }
         };
         add(e0); add(e1);
-        for (uint32_t e = t.list_begin + 2 * blockDim.x + threadIdx.x; e < t.list_end; e += blockDim.x) add(b.cov_list[e]); // (rare: > 512 intervals)
+        for (uint32_t e = t.list_begin + 2 * blockDim.x + threadIdx.x; e < t.list_end; e += blockDim.x) add(load(t, e)); // (rare: > 512 reads)
+        for (uint32_t e = threadIdx.x; e < n_extra; e += blockDim.x) { // further intervals of reads with a clip between matches (rare)
+            const CovExtra x = b.cov_extra[e];
+            if (x.lane == t.lane) add(CovEntry{x.win, x.off_len});
+        }
         const CovTile tc = t;
         { // next tile of this workgroup: descriptor and first intervals
             const uint32_t tn = ti + gridDim.x;
@@ -63,8 +74,8 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
             if (tn < b.n_cov_tiles) {
                 t = b.cov_tiles[tn];
                 const uint32_t i0 = t.list_begin + threadIdx.x, i1 = i0 + blockDim.x;
-                if (i0 < t.list_end) e0 = b.cov_list[i0];
-                if (i1 < t.list_end) e1 = b.cov_list[i1];
+                if (i0 < t.list_end) e0 = load(t, i0);
+                if (i1 < t.list_end) e1 = load(t, i1);
             }
         }
         block_sync();
@@ -167,6 +178,13 @@ __global__ void k_add_words(uint64_t* __restrict__ state, const uint64_t* __rest
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) gadd(state + idx[i], val[i]);
 }
+
+// the stream's error record takes over the first batch record that holds an error (batches run in order on one stream)
+__global__ void k_err_merge(ErrRec* __restrict__ dst, const ErrRec* __restrict__ src)
+{
+    if (dst->first_key == BQC_ERRKEY_NONE && dst->flags == 0 && (src->first_key != BQC_ERRKEY_NONE || src->flags != 0)) *dst = *src;
+}
+extern "C" void bqc_launch_err_merge(ErrRec* dst, const ErrRec* src, hipStream_t s) { hipLaunchKernelGGL(k_err_merge, dim3(1), dim3(1), 0, s, dst, src); }
 
 extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_t* state, uint32_t* carry, uint32_t* parity, const uint8_t* lane_mask,
                                uint8_t* started, const uint8_t* started_after, uint32_t n_lanes, hipStream_t s)

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
     const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const uint32_t cyc0 = blockIdx.y * KL_CT;
     uint32_t cur_lane = 0xFFFFFFFFu;
+    const uint32_t n_chunks = b.desc->n_chunks_slow;
+    if (cyc0 >= b.desc->long_max_len) return; // no read of the batch reaches this cycle tile (the grid is sized from an upper bound)
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane
-        const bool done = ci >= b.n_chunks;
+        const bool done = ci >= n_chunks;
         Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
         if (done) break;
         uint64_t* em = state + sl.lane_base(cur_lane) + sl.o_eightmer;
         for (uint32_t k = wave; k < ch.count; k += nwaves) {
-            const uint32_t r = b.perm ? b.perm[ch.first + k] : ch.first + k;
+            const uint32_t r = b.perm[ch.first + k];
             const uint32_t flag = b.flag[r];
             if ((flag & 0x900u) || !(flag & 0xC0u)) continue;  // skipped records; missing mate flag is raised by k_reads / host
             const uint32_t L = b.l_seq[r];
@@ -198,12 +200,13 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
 // per-read histograms from the sums (QualityCheck.hpp:157-165): thread per read of the generic chunks
 __global__ __launch_bounds__(256) void k_long_finish(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, const uint32_t* __restrict__ rsum)
 {
-    for (uint32_t ci = blockIdx.x; ci < b.n_chunks; ci += gridDim.x) {
+    const uint32_t n_chunks = b.desc->n_chunks_slow;
+    for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) {
         const Chunk ch = b.chunks[ci];
         for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
             const uint32_t t = t0 + threadIdx.x;
             const bool live = t < ch.count;
-            const uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            const uint32_t r = live ? b.perm[ch.first + t] : 0;
             const uint32_t flag = live ? b.flag[r] : 0x900u;
             const bool prim = live && !(flag & 0x900u) && (flag & 0xC0u);
             const uint32_t L = prim ? b.l_seq[r] : 0;
@@ -224,14 +227,15 @@ extern "C" hipError_t bqc_long_init()
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_long), hipFuncAttributeMaxDynamicSharedMemorySize, KL_WORDS * 4);
 }
 
+// n_chunks_ub / max_len_ub: host-side upper bounds (the exact values are in the batch descriptor on the device)
 extern "C" void bqc_launch_long(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                uint32_t* rsum, uint32_t max_len, uint32_t n_cu, hipStream_t s)
+                                uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, hipStream_t s)
 {
-    if (b.n_chunks == 0) return;
-    const uint32_t tiles = max_len ? (max_len + KL_CT - 1) / KL_CT : 1u;
+    if (n_chunks_ub == 0) return;
+    const uint32_t tiles = max_len_ub ? (max_len_ub + KL_CT - 1) / KL_CT : 1u;
     uint32_t gx = n_cu / tiles ? n_cu / tiles : 1u; // one workgroup per CU (116 KB of LDS each): gx * tiles <= n_cu where possible
-    if (gx > b.n_chunks) gx = b.n_chunks;
+    if (gx > n_chunks_ub) gx = n_chunks_ub;
     hipLaunchKernelGGL(k_long, dim3(gx, tiles), dim3(1024), KL_WORDS * 4, s, b, sl, state, refs, err, rsum);
-    const uint32_t g2 = b.n_chunks < n_cu * 8 ? b.n_chunks : n_cu * 8;
+    const uint32_t g2 = n_chunks_ub < n_cu * 8 ? n_chunks_ub : n_cu * 8;
     hipLaunchKernelGGL(k_long_finish, dim3(g2), dim3(256), 0, s, b, sl, state, rsum);
 }

@@ -10,14 +10,17 @@
 #include "read_stats.h"
 
 __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                  uint32_t* __restrict__ err)
+                                                  uint32_t* __restrict__ err, uint32_t fast_table)
 {
     __shared__ uint32_t lds[RS_WORDS];
     for (uint32_t i = threadIdx.x; i < RS_WORDS; i += blockDim.x) lds[i] = 0;
     uint32_t blane = 0xFFFFFFFFu;
     block_sync();
-    for (uint32_t ci = blockIdx.x; ci < b.n_chunks; ci += gridDim.x) { // lane-uniform chunks (generic-path reads only)
-        const Chunk ch = b.chunks[ci];
+    // the generic chunks; or (profiling only, BQC_SHORT_PARTS without 8) the fast chunks, whose per-read statistics k_short then leaves out
+    const Chunk* chunks = fast_table ? b.chunks_fast : b.chunks;
+    const uint32_t n_chunks = fast_table ? b.desc->n_chunks_fast : b.desc->n_chunks_slow;
+    for (uint32_t ci = blockIdx.x; ci < n_chunks; ci += gridDim.x) { // lane-uniform chunks
+        const Chunk ch = chunks[ci];
         if (ch.lane != blane) { // block-uniform
             if (blane != 0xFFFFFFFFu) rs_flush(lds, sl, state, blane);
             blane = ch.lane;
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint6
         for (uint32_t t0 = 0; t0 < ch.count; t0 += blockDim.x) {
             const uint32_t t = t0 + threadIdx.x;
             bool live = t < ch.count;
-            uint32_t r = live ? (b.perm ? b.perm[ch.first + t] : ch.first + t) : 0;
+            uint32_t r = live ? b.perm[ch.first + t] : 0;
             if (r & BQC_ENTRY_SEG) { live = false; r = 0; } // padding / triplet-segment entry of a fast chunk
             if (__ballot(live)) read_stats(b, sl, state, refs, err, lds, r, live, live);
         }
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void k_reads(DevBatch b, StateLayout sl, uint6
 __global__ void k_nm_extra(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs, uint32_t* __restrict__ err)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= b.n_nm_extra) return;
+    if (e >= b.n_nm_extra || b.desc->fatal) return;
     const uint32_t r = b.nm_extra_read[e];
     const uint32_t flag = b.flag[r];
     if (flag & 0x900) return;
@@ -57,11 +60,10 @@ __global__ void k_nm_extra(DevBatch b, StateLayout sl, uint64_t* __restrict__ st
 }
 
 extern "C" void bqc_launch_reads_chunks(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                        uint32_t n_cu, hipStream_t s)
+                                        uint32_t grid, uint32_t fast_table, hipStream_t s)
 {
-    if (b.n_chunks == 0) return;
-    const uint32_t grid = b.n_chunks < n_cu * 8 ? b.n_chunks : n_cu * 8;
-    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, b, sl, state, refs, err);
+    if (grid == 0) return;
+    hipLaunchKernelGGL(k_reads, dim3(grid), dim3(256), 0, s, b, sl, state, refs, err, fast_table);
 }
 
 extern "C" void bqc_launch_nm_extra(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err, hipStream_t s)

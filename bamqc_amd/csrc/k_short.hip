@@ -349,7 +349,8 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     block_sync();
     const uint32_t M = 0x11111111u;
     const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t W = b.fast_w, rpw = 64u / W;
+    const BatchDesc desc = *b.desc; // written by the batch's k_build_plan
+    const uint32_t W = desc.fast_w, rpw = 64u / W;
     const uint32_t slot = ln / W, w = ln % W, wnb = KS_NB * w;
     const bool lane_used = slot < rpw;
     const bool last_w = (w + 1u >= W) || ln == 63u;   // the next lane belongs to another read
@@ -385,7 +386,12 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
 
     const uint8_t* g_seq = b.seq - KS_BIAS;
     const uint8_t* g_qual = b.qual - KS_BIAS;
-    const uint32_t n_chunks = b.n_chunks_fast;
+    const uint32_t n_chunks = desc.n_chunks_fast;
+    {   // chunks between two flushes of the packed 8-mer counters: as small as the rows of a workgroup's slot allow (the last row
+        // is for the final flush; beyond the slot the kernel falls back to global atomics)
+        const uint32_t cpw = (n_chunks + gridDim.x - 1) / gridDim.x;
+        t8_period = max(t8_period, (cpw + BQC_T8_SPW - 2) / (BQC_T8_SPW - 1));
+    }
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane (single call site)
         const bool done = ci >= n_chunks;
         Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         bool stat; // this lane's entry is a read (per-read statistics below)
         {
             const uint32_t t = ch.first + p_first + tb + ln;
-            r = ln < tn ? (b.perm ? b.perm[t] : t) : 0xFFFFFFFFu;
+            r = ln < tn ? b.perm[t] : 0xFFFFFFFFu;
             const bool live = r != 0xFFFFFFFFu;                // not a padding entry
             const bool seg = live && (r & BQC_ENTRY_SEG);      // triplet segment of a read (the read itself is another entry)
             stat = live && !seg;
@@ -786,16 +792,11 @@ __global__ __launch_bounds__(256) void k_t8_fold(const uint32_t* __restrict__ ro
 extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
                                  uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t s)
 {
-    if (b.n_chunks_fast == 0 || grid == 0) return;
+    if (grid == 0) return;
     static uint32_t env_period = 0xFFFFFFFFu;
     if (env_period == 0xFFFFFFFFu) { const char* e = getenv("BQC_T8_PERIOD"); env_period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0u; } // tuning knob
-    // chunks between two flushes of the packed 8-mer counters: as small as the rows of a workgroup's slot allow (the last row
-    // is for the final flush; beyond the slot the kernel falls back to global atomics)
-    const uint32_t cpw = (b.n_chunks_fast + grid - 1) / grid;
-    uint32_t period = env_period ? env_period : KS_T8_PERIOD;
-    period = std::max(period, (cpw + BQC_T8_SPW - 2) / (BQC_T8_SPW - 1));
     hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_used, t8_lane,
-                       period);
+                       env_period ? env_period : KS_T8_PERIOD);
 }
 
 // sum the rows of `n_slots` workgroup slots into the 8-mer counters of `lane`

@@ -170,15 +170,15 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
         pt[i] = make_uint4((uint32_t)tl_, (uint32_t)(tl_ >> 32), (uint32_t)th_, (uint32_t)(th_ >> 32));
     }
     block_sync();
-    const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_perm, lo_r + per_block);
+    if (b.desc->fatal) return; // (a batch the pre-pass rejected: its lanes may be out of range)
+    const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_reads, lo_r + per_block); // positions of the processing order (reads grouped by read group)
     uint32_t blane = 0xFFFFFFFFu;
     uint32_t& s_lane = lm[63]; // (no static __shared__: it would mis-align the dynamic LDS base)
     uint64_t sat_mask = 0;
     for (uint32_t base = lo_r; base < hi_r; base += blockDim.x) {
         const uint32_t kk = base + threadIdx.x;
         bool live = kk < hi_r;
-        uint32_t r = live ? (b.perm ? b.perm[kk] : kk) : 0;
-        if (r & BQC_ENTRY_SEG) { live = false; r = 0; } // padding / triplet-segment entry
+        const uint32_t r = live ? (b.order ? b.order[kk] : kk) : 0;
         const uint32_t lane = live ? b.lane[r] : 0;
         if (threadIdx.x == 0) s_lane = lane;
         block_sync();
@@ -443,11 +443,11 @@ void sketch_reset(SketchDevice* sk, hipStream_t s)
 
 void sketch_process(SketchDevice* sk, const DevBatch& b, hipStream_t s)
 {
-    if (b.n_perm == 0) return;
+    if (b.n_reads == 0) return;
     uint32_t grid = 256;
-    uint32_t per = (b.n_perm + grid - 1) / grid;
+    uint32_t per = (b.n_reads + grid - 1) / grid;
     per = ((per + SK_THREADS - 1) / SK_THREADS) * SK_THREADS;
-    grid = (b.n_perm + per - 1) / per;
+    grid = (b.n_reads + per - 1) / per;
     hipLaunchKernelGGL(k_sketch, dim3(grid, sk->n_pairs), dim3(SK_THREADS), SK_WORDS * 4, s, b, sk->d_ds, sk->d_pp,
                        (const uint64_t*)sk->d_hv, sk->d_idx, sk->n_pairs, per);
     const uint32_t n = sk->n_lanes * sk->n_pairs;

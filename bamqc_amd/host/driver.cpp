@@ -16,6 +16,7 @@
 #include <string>
 #include <chrono>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/bamqc_host.h"
@@ -483,6 +484,48 @@ int parse_args(int argc, const char** argv, ProgramOptions& o, std::string& err)
     return 0;
 }
 
+// Page-locked decode buffers: the columns of every HostBatch the decoder fills are registered with the HIP runtime once
+// (hipHostRegister, ~40 ms per GB of touched pages), so that bqc_submit_async copies them to the device without a staging
+// copy; a block that a growing vector frees is released first (bqc_raw_vector_free_hook).
+struct PinRegistry {
+    std::mutex m;
+    std::unordered_map<void*, size_t> blocks;
+    double t_register = 0;
+    void pin(const void* p, size_t bytes)
+    {
+        if (!p || bytes < (1u << 16)) return;
+        std::lock_guard<std::mutex> lk(m);
+        auto it = blocks.find((void*)p);
+        if (it != blocks.end() && it->second >= bytes) return;
+        if (it != blocks.end()) { (void)bqc_host_unregister((void*)p); blocks.erase(it); }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (bqc_host_register((void*)p, bytes) == 0) blocks[(void*)p] = bytes;
+        t_register += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void release(void* p)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = blocks.find(p);
+        if (it == blocks.end()) return;
+        (void)bqc_host_unregister(p);
+        blocks.erase(it);
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto& kv : blocks) (void)bqc_host_unregister(kv.first);
+        blocks.clear();
+    }
+};
+PinRegistry g_pins;
+void pin_free_hook(void* p) { g_pins.release(p); }
+template <typename V> void pin_column(const V& v) { g_pins.pin(v.data(), v.capacity() * sizeof(typename V::value_type)); }
+void pin_batch(const HostBatch& hb)
+{
+    pin_column(hb.flag); pin_column(hb.n_cigar); pin_column(hb.mapq); pin_column(hb.lane); pin_column(hb.seq); pin_column(hb.qual);
+    pin_column(hb.rid); pin_column(hb.pos); pin_column(hb.tlen); pin_column(hb.nm); pin_column(hb.as); pin_column(hb.l_seq); pin_column(hb.cigar);
+}
+
 struct BatchQueue { // decode thread -> submit thread
     std::mutex m;
     std::condition_variable cv;
@@ -609,6 +652,19 @@ extern "C" int bqc_main(int argc, const char** argv)
     const auto t_setup = clk::now();
 
     int status = 0;
+    const bool pinned = !(getenv("BQC_NO_PINNED") && getenv("BQC_NO_PINNED")[0] == '1'); // (1: the staging path of bqc_submit, for comparison)
+    if (pinned) bqc_raw_vector_free_hook = pin_free_hook;
+    struct InFlight { uint64_t ticket; std::unique_ptr<HostBatch> hb; };
+    std::deque<InFlight> inflight; // batches whose columns the device may still be reading
+    auto recycle = [&](bool wait_all) {
+        while (!inflight.empty()) {
+            const int up = bqc_batch_uploaded(ctx, inflight.front().ticket, wait_all || inflight.size() > 3 ? 1 : 0);
+            if (up == 0) break;
+            std::lock_guard<std::mutex> lk(Q.m);
+            if (Q.spare.size() < 4) Q.spare.push_back(std::move(inflight.front().hb));
+            inflight.pop_front();
+        }
+    };
     for (;;) {
         std::unique_ptr<HostBatch> hb;
         const auto w0 = clk::now();
@@ -640,17 +696,25 @@ extern "C" int bqc_main(int argc, const char** argv)
         const auto s0 = clk::now();
         t_wait += secs(w0, s0);
         n_total += v.n_reads;
-        if ((rc = bqc_submit(ctx, &v))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
-        t_submit += secs(s0, clk::now());
-        { // (bqc_submit has copied the batch to the device)
-            std::lock_guard<std::mutex> lk(Q.m);
+        if (pinned) {
+            pin_batch(*hb);
+            uint64_t ticket = 0;
+            if ((rc = bqc_submit_async(ctx, &v, &ticket))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
+            inflight.push_back(InFlight{ticket, std::move(hb)});
+            recycle(false);
+        } else {
+            if ((rc = bqc_submit(ctx, &v))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
+            std::lock_guard<std::mutex> lk(Q.m); // (bqc_submit has staged the batch)
             if (Q.spare.size() < 4) Q.spare.push_back(std::move(hb));
         }
+        t_submit += secs(s0, clk::now());
     }
+    recycle(true);
+    if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
     if (timing)
-        fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit (pre-pass + upload + kernels) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
-                (unsigned long long)n_total, t_decode, t_submit, t_wait, secs(t_setup, clk::now()));
+        fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
+                (unsigned long long)n_total, t_decode, g_pins.t_register, t_submit, t_wait, secs(t_setup, clk::now()));
     if (!status && Q.err_code) {
         if (Q.err_code == BQC_ERR_IO) fprintf(stderr, "ERROR: Could not read record from BAM File %s\n", opt.bamFile.c_str()); // :308
         else fprintf(Q.err == "Read does not have Z" ? stdout : stderr, "%s\n", Q.err.c_str());

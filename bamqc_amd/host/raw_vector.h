@@ -4,9 +4,18 @@
 #include <utility>
 #include <vector>
 
+// Called with every block a raw_vector gives back, before it is freed: the program page-locks the columns it decodes into
+// (driver.cpp) and must release the lock of a block that a growing vector is about to free.
+inline void (*bqc_raw_vector_free_hook)(void*) = nullptr;
+
 template <typename T>
 struct no_init_alloc : std::allocator<T> {
     template <typename U> struct rebind { using other = no_init_alloc<U>; };
+    void deallocate(T* p, std::size_t n)
+    {
+        if (bqc_raw_vector_free_hook) bqc_raw_vector_free_hook((void*)p);
+        std::allocator<T>::deallocate(p, n);
+    }
     template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }
     template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BQC_ABI_VERSION 1
+#define BQC_ABI_VERSION 2
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -188,10 +188,22 @@ const char* bqc_last_error(const bqc_ctx* ctx); /* ctx may be NULL: last create 
  * TripletCounting.hpp:60-104). */
 int bqc_set_reference(bqc_ctx* ctx, int32_t rid, const uint8_t* dna5, uint64_t len);
 
-/* Validate + host pre-pass + upload + launch.  Buffers may be reused on return.
- * The kernels run asynchronously; errors detected on the device surface at the
- * next call. */
+/* One batch of decoded records into the pipeline: host pass (coverage anchors), copy into a page-locked staging slot,
+ * host-to-device copy, device pre-pass and kernels — three batches in flight, the call returns when the batch is queued.
+ * The caller's buffers may be reused on return.  What the device finds wrong with a batch (the first failing read in
+ * stream order, as the reference would have met it) surfaces at a later call: bqc_submit, bqc_sync, bqc_flush, bqc_finalize. */
 int bqc_submit(bqc_ctx* ctx, const bqc_batch* batch);
+
+/* The same without the staging copy, for callers whose columns live in page-locked memory (bqc_host_register, or
+ * hipHostMalloc): the columns are copied to the device straight from the caller's memory and must stay untouched until
+ * bqc_batch_uploaded(ctx, ticket, ...) returns 1. */
+int bqc_submit_async(bqc_ctx* ctx, const bqc_batch* batch, uint64_t* ticket);
+/* 1: the batch's columns have been copied to the device (or the ticket is older than every batch in flight), 0: not yet
+ * (only with wait == 0), < 0: -(BQC_ERR_*). */
+int bqc_batch_uploaded(bqc_ctx* ctx, uint64_t ticket, int wait);
+/* Page-lock / release host memory a caller decodes into (hipHostRegister; ~40 ms per GB once the pages are touched). */
+int bqc_host_register(void* p, uint64_t bytes);
+int bqc_host_unregister(void* p);
 
 /* Same, split: keep the batch resident in HBM and run the hot path over it
  * any number of times (used by the benchmark, and by callers that overlap

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
-    assert lib.bqc_abi_version() == 1
+    assert lib.bqc_abi_version() == 2
     assert ctypes.sizeof(_abi.Options) % 8 == 0
     assert ctypes.sizeof(_abi.LaneCounts) > 0
 
