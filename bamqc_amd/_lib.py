@@ -17,6 +17,8 @@ _SIGNATURES = {
     "bqc_abi_version": (C.c_int, []),
     "bqc_create": (C.c_int, [C.POINTER(_abi.Options), C.POINTER(C.c_void_p)]),
     "bqc_destroy": (None, [C.c_void_p]),
+    "bqc_warmup": (C.c_int, [C.c_int32]),
+    "bqc_set_fasta_index": (C.c_int, [C.c_void_p, _abi.i32p]),
     "bqc_last_error": (C.c_char_p, [C.c_void_p]),
     "bqc_set_reference": (C.c_int, [C.c_void_p, C.c_int32, _abi.u8p, C.c_uint64]),
     "bqc_submit": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch)]),

@@ -147,6 +147,26 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     return 0;
 }
 
+extern "C" int bqc_warmup(int32_t device)
+{
+    if (hipSetDevice(device) != hipSuccess) return BQC_ERR_DEVICE;
+    return hipFree(nullptr) == hipSuccess ? 0 : BQC_ERR_DEVICE;
+}
+
+extern "C" int bqc_set_fasta_index(bqc_ctx* c, const int32_t* idx)
+{
+    if (!c || !idx) return BQC_ERR_ARG;
+    if (c->upload_counter) return bqc_fail(c, BQC_ERR_STATE, "bqc_set_fasta_index after the first batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = c->opt.n_refs ? c->opt.n_refs : 1;
+    c->fasta_index.assign(n, -1);
+    for (uint32_t r = 0; r < c->opt.n_refs; ++r) c->fasta_index[r] = idx[r];
+    c->opt.fasta_index = c->fasta_index.data();
+    if (!c->d_fasta_index) HIPCHK(c, hipMalloc(&c->d_fasta_index, 4 * n));
+    HIPCHK(c, hipMemcpy(c->d_fasta_index, c->fasta_index.data(), 4 * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" void bqc_destroy(bqc_ctx* c)
 {
     if (!c) return;

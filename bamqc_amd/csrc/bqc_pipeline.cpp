@@ -237,7 +237,7 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
     const uint64_t cx_cap = H.cigar_words / 2 + 1;
     if (perm_cap > 0xFFFFFFF0ull) return bqc_fail(c, BQC_ERR_ARG, "batch too large (split the batch)");
     const size_t o_flag2 = cv.take(2 * n), o_soff = cv.take(4 * n), o_qoff = cv.take(4 * n), o_cgoff = cv.take(4 * n), o_cov = cv.take(sizeof(CovEntry) * n),
-                 o_covx = cv.take(sizeof(CovExtra) * cx_cap), o_nseg = cv.take(n), o_segs = cv.take(sizeof(TripSeg) * (H.cigar_words + 1)),
+                 o_covx = cv.take(sizeof(CovExtra) * cx_cap), o_cls = cv.take(2 * n), o_segs = cv.take(sizeof(TripSeg) * (H.cigar_words + 1)),
                  o_perm = cv.take(4 * perm_cap), o_cf = cv.take(sizeof(Chunk) * cf_cap), o_cs = cv.take(sizeof(Chunk) * cs_cap),
                  o_desc = cv.take(sizeof(BatchDesc)), o_err = cv.take(sizeof(ErrRec)), o_cursave = cv.take(8), o_bsz = cv.take(24 * nblk), o_btgt = cv.take(8 * nblk),
                  o_bmf = cv.take(8 * nblk), o_swc = cv.take(sizeof(SwCounts) * n_sw), o_swp = cv.take(sizeof(SwPlan) * n_sw),
@@ -289,7 +289,7 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
     p.fasta_index = c->d_fasta_index;
     p.flag_out = (uint16_t*)(base + o_flag2); p.seq_off = (uint32_t*)(base + o_soff); p.qual_off = (uint32_t*)(base + o_qoff);
     p.cigar_off = (uint32_t*)(base + o_cgoff); p.cov_out = (CovEntry*)(base + o_cov); p.cov_extra = (CovExtra*)(base + o_covx);
-    p.cov_extra_cap = (uint32_t)std::min<uint64_t>(cx_cap, 0xFFFFFFFFull); p.nseg = (uint8_t*)(base + o_nseg); p.segs = (TripSeg*)(base + o_segs);
+    p.cov_extra_cap = (uint32_t)std::min<uint64_t>(cx_cap, 0xFFFFFFFFull); p.cls = (uint16_t*)(base + o_cls); p.segs = (TripSeg*)(base + o_segs);
     p.perm = (uint32_t*)(base + o_perm); p.perm_cap = (uint32_t)perm_cap;
     p.chunks_fast = (Chunk*)(base + o_cf); p.chunks_fast_cap = (uint32_t)cf_cap;
     p.chunks_slow = (Chunk*)(base + o_cs); p.chunks_slow_cap = (uint32_t)cs_cap;

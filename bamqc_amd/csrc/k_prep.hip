@@ -72,6 +72,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_prep_sizes(PrepArgs a)
         a.desc->n_cov_extra = 0;
         if (a.replay) *a.cursor = *a.cursor_save; else *a.cursor_save = *a.cursor;
     }
+    for (uint32_t k = blockIdx.x * PR_THREADS + threadIdx.x; k < a.n_sw; k += gridDim.x * PR_THREADS) a.sw_counts[k] = SwCounts{0, 0, 0, 0};
     const uint32_t b0 = blockIdx.x * PR_BLOCK;
     unsigned long long s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
@@ -141,132 +142,196 @@ __device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, in
     return clipped > 0 ? 0 : 1;
 }
 
+// One read's share of the pre-pass.  Everything but the payload offsets and the cross-read part of the FASTA scan.
+struct ReadIn { uint32_t L, nc, flag, lane, mapq; int32_t rid, pos, as; CovEntry ce; };
+struct ReadOut { uint32_t flag, cls, tgt1; CovEntry ce; };
+__device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& refs, uint32_t i, const ReadIn& in, uint32_t qo, uint32_t co, bool offsets_ok)
+{
+    ReadOut o;
+    uint32_t flag = in.flag & (0x0FFFu | BQC_FLAG_MATE_MAIN | BQC_FLAG_NO_QUAL);
+    const uint32_t L = in.L, lane = in.lane;
+    uint32_t nc = in.nc;
+    o.tgt1 = 0;
+    if (L > a.max_read_len) err_key(a.err, i, 1);
+    else if (lane >= a.n_lanes) err_key(a.err, i, 2);
+    if (offsets_ok && L > 0 && a.qual[qo] == 0xFF) flag |= BQC_FLAG_NO_QUAL;
+    const uint32_t* cg = a.cigar + co;
+    if (!offsets_ok) nc = 0; // (the batch fails: k_prep_scan)
+    const bool fast = !a.no_fast && L <= BQC_FAST_MAXLEN;
+    uint32_t nseg = 0;
+    CovEntry ce = in.ce;
+    if (!(flag & 0x900u)) { // primary record: bamqualcheck.cpp:318-327
+        const bool dup = flag & 0x400u, qcf = flag & 0x200u;
+        if (!dup && !qcf) { // tripletCounting, :338-342
+            const int e = triplet_eligible(flag, in.mapq, in.as, cg, nc);
+            if (e < 0) err_key(a.err, i, 4);
+            if (e > 0) { // Genome: forward-only FASTA scan (TripletCounting.hpp:254-259)
+                const int32_t rid = in.rid;
+                int32_t target = -1;
+                if (rid >= 0 && (uint32_t)rid < refs.n_refs) target = a.fasta_index ? a.fasta_index[rid] : rid;
+                if (target < 0 || refs.ref[rid] == nullptr) err_key(a.err, i, 5);
+                else { o.tgt1 = (uint32_t)target + 1u; flag |= BQC_FLAG_TRIPLET; }
+            }
+        }
+        if (!(flag & 0xC0u)) err_key(a.err, i, 6);
+    }
+    // The read's covered interval(s) relative to its first live window (OverallNumbers.hpp:112-131): `c` runs over the
+    // seq-oriented CIGAR (reversed for reverse reads, bamqualcheck.cpp:349) and advances on S, M and D; M and D add
+    // coverage.  DEFINED: increments at window offset >= 2000 are dropped.  One interval unless a clip sits between
+    // two match operations.  The host decided WHETHER the read enters coverage() and where its window starts.
+    if (ce.win != BQC_COV_NONE) {
+        flag |= BQC_FLAG_COV;
+        const bool rc = flag & 0x10u;
+        const int64_t pos = (int64_t)ce.off_len;
+        uint32_t cc = 0; // `int c` in the reference; wraps identically
+        int64_t run_a = -1, run_z = -1;
+        bool first = true;
+        ce.off_len = 0;
+        auto emit = [&](int64_t lo, int64_t hi) {
+            hi = hi < 2 * BQC_VSIZE ? hi : 2 * BQC_VSIZE;
+            if (lo < 0 || lo >= hi) return;
+            const uint32_t v = (uint32_t)lo | ((uint32_t)(hi - lo) << 16);
+            if (first) { ce.off_len = v; first = false; return; }
+            const uint32_t k = atomicAdd(&a.desc->n_cov_extra, 1u);
+            if (k < a.cov_extra_cap) a.cov_extra[k] = CovExtra{ce.win, v, lane, 0};
+            else atomicOr(&a.err->flags, BQC_DEVERR_INTERNAL); // (capacity = CIGAR words / 2 + 1: cannot happen)
+        };
+        if (nc == 1u) { // (nearly every read: no loop)
+            const uint32_t w = cg[0], op = w & 15u, nn = w >> 4;
+            if (op == 0u || op == 2u) emit(pos, pos + nn);
+        } else {
+            for (uint32_t k = 0; k < nc; ++k) {
+                const uint32_t w = cg[rc ? nc - 1 - k : k], op = w & 15u, nn = w >> 4;
+                if (op == 4u) cc += nn;
+                if (op == 0u || op == 2u) {
+                    const int64_t lo = pos + (int64_t)cc, hi = lo + nn;
+                    if (run_z == lo) run_z = hi;
+                    else { if (run_a >= 0) emit(run_a, run_z); run_a = lo; run_z = hi; }
+                    cc += nn;
+                }
+            }
+            if (run_a >= 0) emit(run_a, run_z);
+        }
+    } else ce.off_len = 0;
+    // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
+    // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
+    if (fast && (flag & BQC_FLAG_TRIPLET) && nc > 1 && L >= 3) {
+        const uint32_t n0 = cg[0] >> 4;
+        if (n0 != 0) { // (n0 == 0: every position counts as inside the first operation, no walk)
+            uint64_t rp = n0;
+            int64_t cpos = (int64_t)in.pos + n0;
+            for (uint32_t k2 = 1; k2 < nc && rp < L; ++k2) {
+                const uint32_t op = cg[k2] & 15u, nn = cg[k2] >> 4;
+                if (op == 2u || op == 3u || op == 5u || op == 6u) cpos += nn;   // D N H P
+                else if (op == 4u || op == 1u) rp += nn;                          // S I
+                else {                                                            // M = X (and unknown)
+                    const uint64_t ia = rp > 1 ? rp : 1, ib = rp + nn < (uint64_t)L - 1 ? rp + nn : (uint64_t)L - 1;
+                    const int64_t posv = cpos - (int64_t)rp;
+                    if (ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2) {
+                        a.segs[co + nseg] = TripSeg{i, (int32_t)posv, (uint32_t)ia | ((uint32_t)ib << 8), 0};
+                        ++nseg;
+                    }
+                    rp += nn; cpos += nn;
+                }
+            }
+        }
+    }
+    o.flag = flag;
+    o.ce = ce;
+    o.cls = ((fast ? ((flag & 0x40u) ? 0u : 1u) : 2u) << 8) | nseg; // mate slot of a fast read (first mate / everything else) or 2 = generic path; segments
+    return o;
+}
+
+// Thread t of a workgroup owns the four consecutive reads b0 + 4t .. + 3: their columns are 8- / 16-byte loads, the payload
+// offsets are a serial prefix inside the thread plus ONE workgroup scan per quantity, and so is the forward-only FASTA scan.
 __global__ __launch_bounds__(PR_THREADS) void k_prep_reads(PrepArgs a, DevRefs refs)
 {
     __shared__ uint32_t sh[2 * (PR_THREADS / 64)];
-    const uint32_t b0 = blockIdx.x * PR_BLOCK;
-    uint32_t base_s = 0, base_q = 0, base_c = 0; // offsets of the block's current round relative to the block base
+    __shared__ uint32_t red[8];
+    const uint32_t i0 = blockIdx.x * PR_BLOCK + 4u * threadIdx.x;
     const unsigned long long gs = a.blk_sizes[3ull * blockIdx.x], gq = a.blk_sizes[3ull * blockIdx.x + 1], gc = a.blk_sizes[3ull * blockIdx.x + 2];
-    uint32_t run_max = 0;                          // FASTA positions + 1 of the eligible reads before this round (0: none)
-    uint32_t blk_min = 0xFFFFFFFFu, maxfast = 0, maxlong = 0;
-    for (int j = 0; j < PR_PER_THREAD; ++j) {      // rounds of 256 consecutive reads: scans run in read order
-        const uint32_t i = b0 + j * PR_THREADS + threadIdx.x;
-        const bool live = i < a.n;
-        uint32_t L = 0, nc = 0, flag = 0x900u, lane = 0;
-        if (live) { L = a.l_seq[i]; nc = a.n_cigar[i]; flag = a.flag_in[i] & (0x0FFFu | BQC_FLAG_MATE_MAIN | BQC_FLAG_NO_QUAL); lane = a.lane[i]; }
-        uint32_t ts, tq, tc;
-        const uint32_t so = (uint32_t)gs + base_s + block_scan_excl((L + 1) / 2, sh, &ts);
-        const uint32_t qo = (uint32_t)gq + base_q + block_scan_excl(L, sh, &tq);
-        const uint32_t co = (uint32_t)gc + base_c + block_scan_excl(nc, sh, &tc);
-        base_s += ts; base_q += tq; base_c += tc;
-        uint32_t tgt1 = 0; // FASTA position + 1 of a triplet-eligible read
-        if (live) {
-            a.seq_off[i] = so; a.qual_off[i] = qo; a.cigar_off[i] = co;
-            if (L > a.max_read_len) err_key(a.err, i, 1);
-            else if (lane >= a.n_lanes) err_key(a.err, i, 2);
-            const bool offsets_ok = gs + base_s <= 0xFFFFFFFFull && gq + base_q <= 0xFFFFFFFFull && gc + base_c <= 0xFFFFFFFFull; // (else the batch fails: k_prep_scan)
-            if (offsets_ok && L > 0 && a.qual[qo] == 0xFF) flag |= BQC_FLAG_NO_QUAL;
-            const uint32_t* cg = a.cigar + co;
-            if (!offsets_ok) nc = 0;
-            const bool fast = !a.no_fast && L <= BQC_FAST_MAXLEN;
-            if (fast) maxfast = max(maxfast, L); else maxlong = max(maxlong, L);
-            uint32_t nseg = 0;
-            CovEntry ce = a.cov_in[i];
-            if (!(flag & 0x900u)) { // primary record: bamqualcheck.cpp:318-327
-                const bool dup = flag & 0x400u, qcf = flag & 0x200u;
-                if (!dup && !qcf) { // tripletCounting, :338-342
-                    const int e = triplet_eligible(flag, a.mapq[i], a.as_[i], cg, nc);
-                    if (e < 0) err_key(a.err, i, 4);
-                    if (e > 0) { // Genome: forward-only FASTA scan (TripletCounting.hpp:254-259)
-                        const int32_t rid = a.rid[i];
-                        int32_t target = -1;
-                        if (rid >= 0 && (uint32_t)rid < refs.n_refs) target = a.fasta_index ? a.fasta_index[rid] : rid;
-                        if (target < 0 || refs.ref[rid] == nullptr) err_key(a.err, i, 5);
-                        else { tgt1 = (uint32_t)target + 1u; flag |= BQC_FLAG_TRIPLET; }
-                    }
-                }
-                if (!(flag & 0xC0u)) err_key(a.err, i, 6);
-            }
-            // The read's covered interval(s) relative to its first live window (OverallNumbers.hpp:112-131): `c` runs over the
-            // seq-oriented CIGAR (reversed for reverse reads, bamqualcheck.cpp:349) and advances on S, M and D; M and D add
-            // coverage.  DEFINED: increments at window offset >= 2000 are dropped.  One interval unless a clip sits between
-            // two match operations.  The host decided WHETHER the read enters coverage() and where its window starts.
-            if (ce.win != BQC_COV_NONE) {
-                flag |= BQC_FLAG_COV;
-                const bool rc = flag & 0x10u;
-                const int64_t pos = (int64_t)ce.off_len;
-                uint32_t cc = 0; // `int c` in the reference; wraps identically
-                int64_t run_a = -1, run_z = -1;
-                bool first = true;
-                ce.off_len = 0;
-                auto emit = [&](int64_t lo, int64_t hi) {
-                    hi = hi < 2 * BQC_VSIZE ? hi : 2 * BQC_VSIZE;
-                    if (lo < 0 || lo >= hi) return;
-                    const uint32_t v = (uint32_t)lo | ((uint32_t)(hi - lo) << 16);
-                    if (first) { ce.off_len = v; first = false; return; }
-                    const uint32_t k = atomicAdd(&a.desc->n_cov_extra, 1u);
-                    if (k < a.cov_extra_cap) a.cov_extra[k] = CovExtra{ce.win, v, lane, 0};
-                    else atomicOr(&a.err->flags, BQC_DEVERR_INTERNAL); // (capacity = CIGAR words / 2 + 1: cannot happen)
-                };
-                for (uint32_t k = 0; k < nc; ++k) {
-                    const uint32_t w = cg[rc ? nc - 1 - k : k], op = w & 15u, nn = w >> 4;
-                    if (op == 4u) cc += nn;
-                    if (op == 0u || op == 2u) {
-                        const int64_t lo = pos + (int64_t)cc, hi = lo + nn;
-                        if (run_z == lo) run_z = hi;
-                        else { if (run_a >= 0) emit(run_a, run_z); run_a = lo; run_z = hi; }
-                        cc += nn;
-                    }
-                }
-                if (run_a >= 0) emit(run_a, run_z);
-            } else ce.off_len = 0;
-            a.cov_out[i] = ce;
-            // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
-            // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
-            if (fast && (flag & BQC_FLAG_TRIPLET) && nc > 1 && L >= 3) {
-                const uint32_t n0 = cg[0] >> 4;
-                if (n0 != 0) { // (n0 == 0: every position counts as inside the first operation, no walk)
-                    uint64_t rp = n0;
-                    int64_t cpos = (int64_t)a.pos[i] + n0;
-                    for (uint32_t k2 = 1; k2 < nc && rp < L; ++k2) {
-                        const uint32_t op = cg[k2] & 15u, nn = cg[k2] >> 4;
-                        if (op == 2u || op == 3u || op == 5u || op == 6u) cpos += nn;   // D N H P
-                        else if (op == 4u || op == 1u) rp += nn;                          // S I
-                        else {                                                            // M = X (and unknown)
-                            const uint64_t ia = rp > 1 ? rp : 1, ib = rp + nn < (uint64_t)L - 1 ? rp + nn : (uint64_t)L - 1;
-                            const int64_t posv = cpos - (int64_t)rp;
-                            if (ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2) {
-                                a.segs[co + nseg] = TripSeg{i, (int32_t)posv, (uint32_t)ia | ((uint32_t)ib << 8), 0};
-                                ++nseg;
-                            }
-                            rp += nn; cpos += nn;
-                        }
-                    }
-                }
-            }
-            a.nseg[i] = (uint8_t)nseg;
-            a.flag_out[i] = (uint16_t)flag;
+    if (threadIdx.x < 8) red[threadIdx.x] = threadIdx.x == 0 ? 0xFFFFFFFFu : 0u;
+    ReadIn in[4];
+    const uint32_t nlive = i0 >= a.n ? 0u : min(4u, a.n - i0);
+    if (nlive == 4u) {
+        const uint4 vl = *(const uint4*)(a.l_seq + i0);
+        const uint2 vc = *(const uint2*)(a.n_cigar + i0), vf = *(const uint2*)(a.flag_in + i0);
+        const uint32_t vlane = *(const uint32_t*)(a.lane + i0), vmq = *(const uint32_t*)(a.mapq + i0);
+        const int4 vr = *(const int4*)(a.rid + i0), vp = *(const int4*)(a.pos + i0), va = *(const int4*)(a.as_ + i0);
+        const uint4 c01 = *(const uint4*)(a.cov_in + i0), c23 = *(const uint4*)(a.cov_in + i0 + 2);
+        const uint32_t Ls[4] = {vl.x, vl.y, vl.z, vl.w}, ncs[4] = {vc.x & 0xFFFFu, vc.x >> 16, vc.y & 0xFFFFu, vc.y >> 16};
+        const uint32_t fs[4] = {vf.x & 0xFFFFu, vf.x >> 16, vf.y & 0xFFFFu, vf.y >> 16};
+        const int32_t rs[4] = {vr.x, vr.y, vr.z, vr.w}, ps[4] = {vp.x, vp.y, vp.z, vp.w}, as[4] = {va.x, va.y, va.z, va.w};
+        const CovEntry cs[4] = {{c01.x, c01.y}, {c01.z, c01.w}, {c23.x, c23.y}, {c23.z, c23.w}};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in[j] = ReadIn{Ls[j], ncs[j], fs[j], (vlane >> (8 * j)) & 0xFFu, (vmq >> (8 * j)) & 0xFFu, rs[j], ps[j], as[j], cs[j]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            in[j] = ReadIn{0, 0, 0x900u, 0, 0, -1, 0, 0, CovEntry{BQC_COV_NONE, 0}};
+            if ((uint32_t)j < nlive) { const uint32_t i = i0 + j; in[j] = ReadIn{a.l_seq[i], a.n_cigar[i], a.flag_in[i], a.lane[i], a.mapq[i], a.rid[i], a.pos[i], a.as_[i], a.cov_in[i]}; }
         }
-        // forward-only FASTA scan inside the block: an eligible read whose position lies before an earlier eligible read's
-        uint32_t tm;
-        const uint32_t before = max(run_max, block_scan_excl_max(tgt1, sh, &tm));
-        if (tgt1 && tgt1 < before) err_key(a.err, i, 5);
-        run_max = max(run_max, tm);
-        if (tgt1) blk_min = min(blk_min, tgt1);
     }
-    // block partials for k_build_plan: the FASTA positions of the block (checked there against everything before the block),
-    // the longest fast read
-    __shared__ uint32_t red[3];
-    if (threadIdx.x == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0; red[2] = 0; }
-    block_sync();
-    atomicMin(&red[0], blk_min); atomicMax(&red[1], maxfast); atomicMax(&red[2], maxlong);
+    // payload offsets: prefix inside the thread, then across the workgroup
+    uint32_t ls[4], lq[4], lc[4], ts = 0, tq = 0, tc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ls[j] = ts; lq[j] = tq; lc[j] = tc; ts += (in[j].L + 1) / 2; tq += in[j].L; tc += in[j].nc; }
+    uint32_t tot;
+    const unsigned long long bs = gs + block_scan_excl(ts, sh, &tot), bq = gq + block_scan_excl(tq, sh, &tot), bc = gc + block_scan_excl(tc, sh, &tot);
+    ReadOut out[4];
+    uint32_t tmax = 0, tmin = 0xFFFFFFFFu, maxfast = 0, maxlong = 0, cnt[4] = {0, 0, 0, 0};
+    bool local_bad[4] = {false, false, false, false};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        out[j] = ReadOut{0x900u, 2u << 8, 0, CovEntry{BQC_COV_NONE, 0}};
+        if ((uint32_t)j >= nlive) continue;
+        const unsigned long long so = bs + ls[j], qo = bq + lq[j], co = bc + lc[j];
+        const bool ok = so + (in[j].L + 1) / 2 <= 0xFFFFFFFFull && qo + in[j].L <= 0xFFFFFFFFull && co + in[j].nc <= 0xFFFFFFFFull;
+        out[j] = prep_one(a, refs, i0 + j, in[j], (uint32_t)qo, (uint32_t)co, ok);
+        if (out[j].tgt1) { local_bad[j] = out[j].tgt1 < tmax; tmax = max(tmax, out[j].tgt1); tmin = min(tmin, out[j].tgt1); }
+        const uint32_t cl = out[j].cls >> 8;
+        if (cl == 2u) maxlong = max(maxlong, in[j].L); else maxfast = max(maxfast, in[j].L);
+        cnt[cl] += 1; cnt[3] += out[j].cls & 0xFFu;
+    }
+    if (nlive == 4u) {
+        *(uint4*)(a.seq_off + i0) = make_uint4((uint32_t)bs + ls[0], (uint32_t)bs + ls[1], (uint32_t)bs + ls[2], (uint32_t)bs + ls[3]);
+        *(uint4*)(a.qual_off + i0) = make_uint4((uint32_t)bq + lq[0], (uint32_t)bq + lq[1], (uint32_t)bq + lq[2], (uint32_t)bq + lq[3]);
+        *(uint4*)(a.cigar_off + i0) = make_uint4((uint32_t)bc + lc[0], (uint32_t)bc + lc[1], (uint32_t)bc + lc[2], (uint32_t)bc + lc[3]);
+        *(uint2*)(a.flag_out + i0) = make_uint2(out[0].flag | (out[1].flag << 16), out[2].flag | (out[3].flag << 16));
+        *(uint2*)(a.cls + i0) = make_uint2(out[0].cls | (out[1].cls << 16), out[2].cls | (out[3].cls << 16));
+        *(uint4*)(a.cov_out + i0) = make_uint4(out[0].ce.win, out[0].ce.off_len, out[1].ce.win, out[1].ce.off_len);
+        *(uint4*)(a.cov_out + i0 + 2) = make_uint4(out[2].ce.win, out[2].ce.off_len, out[3].ce.win, out[3].ce.off_len);
+    } else {
+        for (uint32_t j = 0; j < nlive; ++j) {
+            const uint32_t i = i0 + j;
+            a.seq_off[i] = (uint32_t)bs + ls[j]; a.qual_off[i] = (uint32_t)bq + lq[j]; a.cigar_off[i] = (uint32_t)bc + lc[j];
+            a.flag_out[i] = (uint16_t)out[j].flag; a.cls[i] = (uint16_t)out[j].cls; a.cov_out[i] = out[j].ce;
+        }
+    }
+    // forward-only FASTA scan: an eligible read whose position lies before an earlier eligible read's — inside the thread
+    // (local_bad), inside the workgroup (here), across workgroups (k_build_plan)
+    uint32_t blk_max;
+    const uint32_t before = block_scan_excl_max(tmax, sh, &blk_max);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (out[j].tgt1 && (local_bad[j] || out[j].tgt1 < before)) err_key(a.err, i0 + j, 5);
+    // block partials: FASTA positions (for the scan across blocks), longest fast / generic read; class counts of the super-window
+    if (tmin != 0xFFFFFFFFu) atomicMin(&red[0], tmin);
+    if (maxfast) atomicMax(&red[1], maxfast);
+    if (maxlong) atomicMax(&red[2], maxlong);
+    if (!a.order) { // stream order: the block's reads lie in one super-window
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t v = wave_sum(cnt[k]); if (lane_id() == 0 && v) atomicAdd(&red[4 + k], v); }
+    }
     block_sync();
     if (threadIdx.x == 0) {
-        a.blk_tgt[2ull * blockIdx.x] = run_max;
+        a.blk_tgt[2ull * blockIdx.x] = blk_max;
         a.blk_tgt[2ull * blockIdx.x + 1] = red[0];
         a.blk_maxfast[2ull * blockIdx.x] = red[1];
         a.blk_maxfast[2ull * blockIdx.x + 1] = red[2];
     }
+    if (!a.order && threadIdx.x < 4 && red[4 + threadIdx.x])
+        atomicAdd((uint32_t*)&a.sw_counts[blockIdx.x / (BQC_SW_READS / PR_BLOCK)] + threadIdx.x, red[4 + threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -274,12 +339,12 @@ __global__ __launch_bounds__(PR_THREADS) void k_prep_reads(PrepArgs a, DevRefs r
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t read_class(const PrepArgs& a, uint32_t r, uint32_t* nseg) // 0 / 1: fast read by mate slot, 2: generic path
 {
-    const uint32_t L = a.l_seq[r];
-    if (a.no_fast || L > BQC_FAST_MAXLEN) { *nseg = 0; return 2u; }
-    *nseg = a.nseg[r];
-    return (a.flag_out[r] & 0x40u) ? 0u : 1u;
+    const uint32_t v = a.cls[r];
+    *nseg = v & 0xFFu;
+    return v >> 8;
 }
 
+// (only for batches with several read groups: in stream order k_prep_reads has counted the classes already)
 __global__ __launch_bounds__(PR_THREADS) void k_build_count(PrepArgs a)
 {
     __shared__ uint32_t sh[4 * (PR_THREADS / 64)];
@@ -495,7 +560,7 @@ extern "C" void bqc_launch_prep(const PrepArgs& a, const DevRefs& refs, hipStrea
     hipLaunchKernelGGL(k_prep_sizes, dim3(nblk), dim3(PR_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_prep_reads, dim3(nblk), dim3(PR_THREADS), 0, s, a, refs);
-    hipLaunchKernelGGL(k_build_count, dim3(a.n_sw), dim3(PR_THREADS), 0, s, a);
+    if (a.order) hipLaunchKernelGGL(k_build_count, dim3(a.n_sw), dim3(PR_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_build_scatter, dim3(a.n_sw), dim3(PR_THREADS), 0, s, a);
 }

@@ -38,7 +38,7 @@ struct PrepArgs {
     CovEntry* cov_out;
     CovExtra* cov_extra;
     uint32_t cov_extra_cap;
-    uint8_t* nseg;            // triplet segments per read
+    uint16_t* cls;            // per read: class << 8 | triplet segments (class 0 / 1: fast read by mate slot, 2: generic path)
     TripSeg* segs;            // at cigar_off[r] + j
     uint32_t* perm;
     uint32_t perm_cap;

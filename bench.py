@@ -209,7 +209,7 @@ def e2e_leg(args, refs, cpu_kernel_value):
             out = os.path.join(tmp, "o%d.bamqc" % len(runs))
             t0 = time.perf_counter()
             r = subprocess.run([exe, "-r", fa, "-o", out, "-c", ",".join(names)] + extra + [bam], capture_output=True, text=True,
-                               env=dict(os.environ, BQC_TIMING="1"))
+                               env=dict(os.environ, BQC_TIMING="1", BQC_T0="%.6f" % time.monotonic()))
             dt = time.perf_counter() - t0
             assert r.returncode == 0, r.stderr[-2000:]
             m = re.search(r"record loop ([0-9.]+) s", r.stderr)

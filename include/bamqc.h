@@ -180,6 +180,11 @@ typedef struct bqc_dbatch bqc_dbatch; /* a batch resident in device memory */
 /* ---- aggregation (replaces bamqualcheck.cpp:303-453) ----------------------- */
 int bqc_abi_version(void);
 int bqc_create(const bqc_options* opt, bqc_ctx** out);
+/* Starts the HIP runtime on `device` (~0.1 s on a cold process): callable from any thread, e.g. while the inputs are opened. */
+int bqc_warmup(int32_t device);
+/* The FASTA order of the contigs (bqc_options.fasta_index) may also be given after creation, before the first batch: a
+ * program can then create the context while it still reads the FASTA file. */
+int bqc_set_fasta_index(bqc_ctx* ctx, const int32_t* fasta_index);
 void bqc_destroy(bqc_ctx* ctx);
 const char* bqc_last_error(const bqc_ctx* ctx); /* ctx may be NULL: last create error */
 

@@ -48,7 +48,7 @@ def stream_through_cli(tmp, seed, n_reads, names, lens, cli_args, read_len=150, 
     th.join()
     os.unlink(fifo)
     assert p.returncode == 0 and not err, (p.returncode, stderr[-2000:], err)
-    m = re.search(r"phases: FASTA ([0-9.]+) s, context ([0-9.]+) s, references ([0-9.]+) s, record loop ([0-9.]+) s, finalize ([0-9.]+) s, write ([0-9.]+) s", stderr)
+    m = re.search(r"phases: FASTA ([0-9.]+) s \([^)]*\), context ([0-9.]+) s, references ([0-9.]+) s, record loop ([0-9.]+) s, finalize ([0-9.]+) s, write ([0-9.]+) s", stderr)
     wall = sum(float(x) for x in m.groups()) if m else float("nan")
     return out, stderr, wall
 
