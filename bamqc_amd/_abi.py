@@ -41,7 +41,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_lanes", C.c_uint32), ("n_refs", C.c_uint32),
                 ("isize", C.c_int32), ("max_read_len", C.c_uint32), ("hist_cap", C.c_uint32),
                 ("main_chrom", u8p), ("fasta_index", i32p), ("device", C.c_int32),
-                ("sketch", SketchOptions)]
+                ("sketch", SketchOptions), ("shard_tail", C.c_uint32)]
 
 
 class Batch(C.Structure):
@@ -85,6 +85,20 @@ class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_read_index", C.c_uint64), ("n_reads", C.c_uint32),
                 ("read_len", C.c_uint32), ("n_refs", C.c_uint32), ("ref_len", u32p), ("n_lanes", C.c_uint32),
                 ("isize", C.c_int32), ("long_reads", C.c_int32)]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("status", C.c_int32), ("begin_block", C.c_uint64), ("end_block", C.c_uint64),
+                ("first", C.c_uint64), ("over", C.c_uint64), ("sample_id", C.c_char_p), ("n_lane_names", C.c_uint32),
+                ("lane_names", C.POINTER(C.c_char_p)), ("lane_index", u32p)]
+
+
+class ShardResult(C.Structure):
+    _fields_ = [("n_lane_names", C.c_uint32), ("lane_names", C.POINTER(C.c_char_p)), ("lane_index", u32p)]
+
+
+SHARD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ShardInfo), C.POINTER(ShardResult))
+SHARD_WRITE, SHARD_DONE, SHARD_FALLBACK, SHARD_FAIL = 0, 1, 2, 3
 
 
 class HeaderInfo(C.Structure):
@@ -134,7 +148,7 @@ def make_batch(cols):
 
 
 def make_options(n_lanes=1, n_refs=1, isize=1000, max_read_len=1024, hist_cap=4096, main_chrom=None,
-                 fasta_index=None, device=0, klist=(), qlist=(), e=0.01, seed=1):
+                 fasta_index=None, device=0, klist=(), qlist=(), e=0.01, seed=1, shard_tail=0):
     keep = {}
     o = Options()
     o.struct_size = C.sizeof(Options)
@@ -156,6 +170,7 @@ def make_options(n_lanes=1, n_refs=1, isize=1000, max_read_len=1024, hist_cap=40
     if len(ql):
         o.sketch.qlist = _ptr(ql, u32p)
     o.sketch.e, o.sketch.seed = e, seed
+    o.shard_tail = 1 if shard_tail else 0
     return o, keep
 
 

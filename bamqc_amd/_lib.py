@@ -33,6 +33,10 @@ _SIGNATURES = {
     "bqc_sync": (C.c_int, [C.c_void_p]),
     "bqc_reset": (C.c_int, [C.c_void_p]),
     "bqc_flush": (C.c_int, [C.c_void_p]),
+    "bqc_shard_fasta_span": (C.c_int, [C.c_void_p, _abi.i32p]),
+    "bqc_shard_state_bytes": (C.c_uint64, [C.c_void_p]),
+    "bqc_shard_resolve": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bqc_shard_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bqc_state_words": (C.c_uint64, [C.c_void_p]),
     "bqc_state_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bqc_state_import": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -52,6 +56,12 @@ _SIGNATURES = {
     "bqc_synth_stream": (C.c_int, [C.POINTER(_abi.SynthParams), C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     "bqc_bam_write": (C.c_int, [C.c_char_p, C.POINTER(_abi.Batch), C.c_uint32, C.POINTER(C.c_char_p), _abi.u32p, C.c_uint32, C.c_uint64, C.c_int]),
     "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bqc_bam_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "bqc_bam_range_begin_block": (C.c_uint64, [C.c_void_p]),
+    "bqc_bam_range_end_block": (C.c_uint64, [C.c_void_p]),
+    "bqc_bam_range_first": (C.c_uint64, [C.c_void_p]),
+    "bqc_bam_range_over": (C.c_uint64, [C.c_void_p]),
+    "bqc_file_size": (C.c_uint64, [C.c_char_p]),
     "bqc_bam_close": (None, [C.c_void_p]),
     "bqc_bam_error": (C.c_char_p, [C.c_void_p]),
     "bqc_bam_n_refs": (C.c_uint32, [C.c_void_p]),
@@ -69,6 +79,7 @@ _SIGNATURES = {
                                  C.POINTER(C.POINTER(_abi.u8p)), C.POINTER(_abi.u64p)]),
     "bqc_fasta_free": (None, [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_abi.u8p), _abi.u64p]),
     "bqc_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "bqc_main_shard": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, _abi.SHARD_HOOK, C.c_void_p]),
     "bqc_calib_read4": (C.c_int, [C.c_uint64, C.c_int]),
     "bqc_inflate_raw": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "bqc_crc32": (C.c_uint32, [C.c_char_p, C.c_uint64]),

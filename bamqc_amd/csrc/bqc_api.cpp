@@ -18,7 +18,7 @@
 #include "../host/parallel.h"
 
 extern "C" {
-void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, hipStream_t);
+void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, const uint8_t* sel, uint32_t count_start, hipStream_t);
 void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32_t* out, uint64_t n_dwords, hipStream_t);
 hipError_t bqc_long_init();
 hipError_t bqc_short_init();
@@ -56,7 +56,7 @@ static int reset_stream_records(bqc_ctx* c)
 {
     ErrRec e{};
     e.first_key = BQC_ERRKEY_NONE;
-    const int32_t cur[2] = {-1, 0};
+    const int32_t cur[2] = {-1, -1}; // last / first FASTA position of the stream's triplet-eligible reads
     HIPCHK(c, hipMemcpyAsync(c->d_err0, &e, sizeof e, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_cursor, cur, 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // (the sources are on this function's stack)
@@ -86,6 +86,11 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     c->opt.fasta_index = c->fasta_index.empty() ? nullptr : c->fasta_index.data();
     c->sl = make_state_layout(opt->n_lanes, opt->max_read_len, opt->hist_cap, (uint32_t)opt->isize + 1);
     c->cov.assign(opt->n_lanes, LaneCov());
+    c->shard.tail = opt->shard_tail != 0;
+    c->shard.pending.assign(opt->n_lanes, c->shard.tail ? 1 : 0);
+    c->shard.has_prev.assign(opt->n_lanes, 0);
+    c->shard.prev_rid.assign(opt->n_lanes, 0);
+    c->shard.prev_bp.assign(opt->n_lanes, 0);
     c->d_ref.assign(nr, nullptr);
     c->d_refn.assign(nr, nullptr);
     c->ref_len.assign(nr, 0);
@@ -277,7 +282,7 @@ extern "C" int bqc_flush(bqc_ctx* c)
     int rc = sync_and_check(c);
     if (rc) return rc;
     bqc_state_ready(c);
-    bqc_launch_cov_final(c->sl, c->d_state, c->d_carry, c->d_parity, c->d_started, c->stream);
+    bqc_launch_cov_final(c->sl, c->d_state, c->d_carry, c->d_parity, c->d_started, nullptr, 1, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->flushed = true;
@@ -291,6 +296,7 @@ extern "C" int bqc_state_export(bqc_ctx* c, void* dst)
     if (!c || !dst) return BQC_ERR_ARG;
     int rc = bqc_flush(c);
     if (rc) return rc;
+    bqc_state_ready(c);
     HIPCHK(c, hipMemcpyAsync(dst, c->d_state, c->sl.words * 8, hipMemcpyDeviceToDevice, c->stream));
     if (c->sketch) sketch_state_export(c->sketch, (uint64_t*)dst + c->sl.words, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -313,6 +319,8 @@ extern "C" int bqc_state_export_host(bqc_ctx* c, uint64_t* dst)
     if (!c || !dst) return BQC_ERR_ARG;
     int rc = bqc_flush(c);
     if (rc) return rc;
+    bqc_state_ready(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(dst, c->d_state, c->sl.words * 8, hipMemcpyDeviceToHost));
     if (c->sketch) {
         uint64_t* tmp = nullptr;

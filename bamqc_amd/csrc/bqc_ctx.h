@@ -37,6 +37,7 @@ struct HostPass {
     std::vector<CovTile> tiles;
     std::vector<uint8_t> lane_mask, started_after;
     std::vector<uint64_t> add_idx, add_val; // host-computed additions (zero-depth windows)
+    uint32_t n_pending = 0;                 // shard mode: reads marked BQC_COV_PENDING in `cov` (their log: ShardCtx::batches.back())
     // scratch kept from batch to batch
     std::vector<std::vector<uint32_t>> lane_first; // per read group: first read index whose window is >= k
     std::vector<uint64_t> lane_count;
@@ -64,6 +65,24 @@ struct BatchMem {
     size_t o_col[13] = {0};              // flag mapq lane rid pos tlen nm as l_seq n_cigar seq qual cigar
     size_t col_bytes[13] = {0};
     size_t o_xr = 0, o_xv = 0, o_cov_in = 0, o_order = 0, o_sws = 0, o_stretch = 0, o_tiles = 0, o_mask = 0, o_started = 0, o_aidx = 0, o_aval = 0;
+};
+
+// Shard mode (bqc_options.shard_tail): the coverage reads set aside until the predecessor shard's final state is known.
+struct PendBatch {                 // those of one batch, in stream order
+    std::vector<uint8_t> lane;
+    std::vector<int32_t> rid;
+    std::vector<uint32_t> bp;
+    void* dmem = nullptr;          // device: PendRun[n] | counter | PendExtra[extra_cap]
+    uint32_t extra_cap = 0;
+    uint32_t n() const { return (uint32_t)lane.size(); }
+};
+struct ShardCtx {
+    bool tail = false, resolved = false, exported = false;
+    std::vector<uint8_t> pending;  // [lane] 1: the read group's reads are still being set aside
+    std::vector<uint8_t> has_prev; // [lane] the read before (of those that enter coverage): for the test "resets whatever the state"
+    std::vector<int32_t> prev_rid;
+    std::vector<uint32_t> prev_bp;
+    std::deque<PendBatch> batches;
 };
 
 struct bqc_dbatch {
@@ -125,6 +144,7 @@ struct bqc_ctx {
     uint64_t upload_counter = 0; // number of batches passed so far
     uint64_t state_seq = 0;      // sequence number of the batch the host stream state (cov) reflects
     HostPass hp;                 // host pass of the batch being submitted (its vectors are reused)
+    ShardCtx shard;
     // batches in flight
     static const int kSlots = 3;
     Slot slots[kSlots];

@@ -31,6 +31,7 @@ void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevR
 uint32_t bqc_short_parts();
 void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
 void bqc_launch_err_merge(ErrRec* dst, const ErrRec* src, hipStream_t);
+void bqc_launch_cov_final(const StateLayout&, uint64_t*, const uint32_t* carry, const uint32_t* parity, const uint8_t* started, const uint8_t* sel, uint32_t count_start, hipStream_t);
 }
 
 using clk = std::chrono::steady_clock;
@@ -47,6 +48,91 @@ void bqc_state_ready(bqc_ctx* c)
     bqc_launch_t8_fold(c->d_t8rows, c->d_t8used, c->t8_slots_used, c->sl, c->d_state, c->t8_rows_lane, c->stream);
     c->t8_slots_used = 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// coverage anchors and tiles of a batch (host)
+// ---------------------------------------------------------------------------------------------------
+// The order-dependent part of OverallNumbers::coverage (OverallNumbers.hpp:84-110): every 1000-position window is numbered in
+// flush order ("virtual coordinates"): a reset advances the window index by 2, a slide by 1.  A read that enters coverage()
+// gets {window, position in it}; the covered interval comes from its CIGAR on the device.  Then the coverage tiles: those that
+// hold a live window of some read (its first and the next one), the two windows carried in from the previous batch and the two
+// carried out (W1, W1 + 1 = the last read's).  Used for the reads of a batch (host_pass) and for the set-aside reads of a
+// shard (bqc_shard_resolve).
+namespace {
+struct CovPlanner {
+    bqc_ctx* c;
+    HostPass& H;
+    uint32_t n, nl;
+    std::vector<uint8_t> started_before;
+    std::vector<uint32_t> last_rel;
+    CovPlanner(bqc_ctx* c_, HostPass& H_, uint32_t n_) : c(c_), H(H_), n(n_), nl(c_->opt.n_lanes), started_before(nl), last_rel(nl, 0)
+    {
+        H.lane_mask.assign(nl, 0);
+        H.lane_first.resize(nl);
+        for (uint32_t l = 0; l < nl; ++l) {
+            started_before[l] = !c->cov[l].first;
+            c->cov[l].batch_base = c->cov[l].win;
+            H.lane_first[l].clear();
+        }
+    }
+    void step(uint32_t i, uint32_t lane, int32_t rid, uint32_t beginpos, uint64_t& rel, uint32_t& pos)
+    {
+        LaneCov& s = c->cov[lane];
+        if (s.first) { s.first = false; s.id = rid; s.shift = (int32_t)beginpos; }
+        if (s.id != rid || (uint32_t)(beginpos - (uint32_t)s.shift) > 2u * BQC_VSIZE) { // reset: two windows flushed
+            s.id = rid; s.win += 2; s.shift = (int32_t)beginpos;
+        }
+        pos = beginpos - (uint32_t)s.shift;
+        if (pos > BQC_VSIZE && pos < 2u * BQC_VSIZE) { // slide: one window flushed
+            s.win += 1; s.shift += BQC_VSIZE; pos = beginpos - (uint32_t)s.shift;
+        }
+        rel = s.win - s.batch_base;
+        if (rel > 0xFFFFFFF0ull) return;
+        std::vector<uint32_t>& first = H.lane_first[lane]; // first[k] = first read of the lane whose window is >= k
+        if (first.size() <= rel) first.resize((size_t)rel + 1, i);
+        last_rel[lane] = (uint32_t)rel;
+    }
+    void finish()
+    {
+        H.tiles.clear(); H.add_idx.clear(); H.add_val.clear();
+        for (uint32_t l = 0; l < nl; ++l) {
+            const std::vector<uint32_t>& first = H.lane_first[l];
+            if (first.empty()) continue;
+            H.lane_mask[l] = 1;
+            const uint32_t W1 = last_rel[l]; // windows < W1 are complete after this batch
+            auto first_at = [&](uint64_t k) { return k < first.size() ? first[k] : n; };
+            uint32_t last_tile = 0xFFFFFFFFu;
+            uint64_t covered_final = 0;
+            auto push_tile = [&](uint32_t w) {
+                const uint32_t t = w / BQC_COV_TILE_WINDOWS;
+                if (last_tile != 0xFFFFFFFFu && t <= last_tile) return;
+                last_tile = t;
+                const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
+                CovTile ct{};
+                ct.lane = l; ct.win_lo = wlo; ct.win_final = W1; ct.mixed = H.multi_lane ? 1u : 0u;
+                ct.list_begin = first_at(wlo == 0 ? 0 : wlo - 1);
+                ct.list_end = first_at((uint64_t)wlo + BQC_COV_TILE_WINDOWS);
+                H.tiles.push_back(ct);
+                const uint64_t hi = std::min<uint64_t>((uint64_t)wlo + BQC_COV_TILE_WINDOWS, W1);
+                if (hi > wlo) covered_final += hi - wlo;
+            };
+            if (started_before[l]) { push_tile(0); push_tile(1); }
+            // a window value w is live for some read iff a read's first window is w: first[w] != first[w + 1] (or w is the last)
+            for (uint64_t w = 0; w < first.size(); ++w) {
+                const bool present = w + 1 == first.size() || first[w] != first[w + 1];
+                if (present) { push_tile((uint32_t)w); push_tile((uint32_t)w + 1); }
+            }
+            if (W1 > covered_final) { // complete windows nobody touched: depth 0 everywhere
+                H.add_idx.push_back(c->sl.lane_base(l) + c->sl.o_poscov + 0);
+                H.add_val.push_back((uint64_t)(W1 - covered_final) * BQC_VSIZE);
+            }
+            c->cov[l].batch_base = c->cov[l].win; // the next batch numbers its windows from this batch's last live window
+        }
+        H.started_after.resize(nl);
+        for (uint32_t l = 0; l < nl; ++l) H.started_after[l] = !c->cov[l].first; // lanes that have seen a coverage read so far
+    }
+};
+} // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // host pass: sizes, read groups, coverage anchors
@@ -118,19 +204,13 @@ static int host_pass(bqc_ctx* c, const bqc_batch* b, HostPass& H)
             if (lane < nl) H.order[w[lane]++] = i; else H.order[w_bad++] = i;
         }
     }
-    // (c) the order-dependent part of OverallNumbers::coverage, in stream order: anchors (OverallNumbers.hpp:84-110).  Every
-    // 1000-position window is numbered in flush order ("virtual coordinates"): a reset advances the window index by 2, a slide
-    // by 1.  A read that enters coverage() gets {window, position in it}; the covered interval comes from its CIGAR on the device.
+    // (c) the order-dependent part of OverallNumbers::coverage, in stream order (CovPlanner)
     { const size_t cap = H.cov.capacity(); H.cov.resize(n); if (H.cov.capacity() != cap) advise_huge(H.cov); }
-    H.lane_mask.assign(nl, 0);
-    H.lane_first.resize(nl);
-    std::vector<uint8_t> started_before(nl);
-    std::vector<uint32_t> last_rel(nl, 0);
-    for (uint32_t l = 0; l < nl; ++l) {
-        started_before[l] = !c->cov[l].first;
-        c->cov[l].batch_base = c->cov[l].win;
-        H.lane_first[l].clear();
-    }
+    CovPlanner plan(c, H, n);
+    ShardCtx& sh = c->shard;
+    const bool set_aside = sh.tail && !sh.resolved;
+    PendBatch* pb = nullptr;
+    H.n_pending = 0;
     const uint32_t n_refs = c->opt.n_refs;
     const uint8_t* main_chrom = c->main_chrom.data();
     for (uint32_t i = 0; i < n; ++i) {
@@ -140,61 +220,30 @@ static int host_pass(bqc_ctx* c, const bqc_batch* b, HostPass& H)
         const bool cand = !(flag & 0x900u) && (flag & 0xC0u) && !(flag & 0x4u) && !(flag & 0x400u) && rid >= 0 && (uint32_t)rid < n_refs && main_chrom[rid] &&
                           lane < nl;
         if (!cand) { H.cov[i] = CovEntry{BQC_COV_NONE, 0}; continue; }
-        LaneCov& s = c->cov[lane];
         const uint32_t beginpos = (uint32_t)b->pos[i];
-        if (s.first) { s.first = false; s.id = rid; s.shift = (int32_t)beginpos; }
-        if (s.id != rid || (uint32_t)(beginpos - (uint32_t)s.shift) > 2u * BQC_VSIZE) { // reset: two windows flushed
-            s.id = rid; s.win += 2; s.shift = (int32_t)beginpos;
+        if (set_aside && sh.pending[lane]) {
+            // Does the state machine reset at this read WHATEVER its state?  Its position in the live windows is
+            // (beginPos - previous beginPos) + (previous read's position, 0..2000): a reset for certain iff the chromosome changes or
+            // that whole range lies above 2000 in the reference's unsigned arithmetic.
+            const uint32_t d = beginpos - sh.prev_bp[lane];
+            const bool certain = sh.has_prev[lane] && (rid != sh.prev_rid[lane] || (d > 2u * BQC_VSIZE && d <= 0xFFFFFFFFu - 2u * BQC_VSIZE));
+            sh.has_prev[lane] = 1; sh.prev_rid[lane] = rid; sh.prev_bp[lane] = beginpos;
+            if (!certain) {
+                if (!pb) { sh.batches.emplace_back(); pb = &sh.batches.back(); }
+                H.cov[i] = CovEntry{BQC_COV_PENDING, pb->n()};
+                pb->lane.push_back((uint8_t)lane); pb->rid.push_back(rid); pb->bp.push_back(beginpos);
+                continue;
+            }
+            sh.pending[lane] = 0; // from here on this read group runs as a stream of its own would from this read
         }
-        uint32_t pos = beginpos - (uint32_t)s.shift;
-        if (pos > BQC_VSIZE && pos < 2u * BQC_VSIZE) { // slide: one window flushed
-            s.win += 1; s.shift += BQC_VSIZE; pos = beginpos - (uint32_t)s.shift;
-        }
-        const uint64_t rel = s.win - s.batch_base;
+        uint64_t rel;
+        uint32_t pos;
+        plan.step(i, lane, rid, beginpos, rel, pos);
         if (rel > 0xFFFFFFF0ull) return bqc_fail(c, BQC_ERR_ARG, "batch spans too many coverage windows (split the batch)");
         H.cov[i] = CovEntry{(uint32_t)rel, pos};
-        std::vector<uint32_t>& first = H.lane_first[lane]; // first[k] = first read of the lane whose window is >= k
-        if (first.size() <= rel) first.resize((size_t)rel + 1, i);
-        last_rel[lane] = (uint32_t)rel;
     }
-    // coverage tiles: the tiles that hold a live window of some read (its first and the next one), the two windows carried in
-    // from the previous batch and the two carried out (W1, W1 + 1 = the last read's)
-    H.tiles.clear(); H.add_idx.clear(); H.add_val.clear();
-    for (uint32_t l = 0; l < nl; ++l) {
-        const std::vector<uint32_t>& first = H.lane_first[l];
-        if (first.empty()) continue;
-        H.lane_mask[l] = 1;
-        const uint32_t W1 = last_rel[l]; // windows < W1 are complete after this batch
-        auto first_at = [&](uint64_t k) { return k < first.size() ? first[k] : n; };
-        uint32_t last_tile = 0xFFFFFFFFu;
-        uint64_t covered_final = 0;
-        auto push_tile = [&](uint32_t w) {
-            const uint32_t t = w / BQC_COV_TILE_WINDOWS;
-            if (last_tile != 0xFFFFFFFFu && t <= last_tile) return;
-            last_tile = t;
-            const uint32_t wlo = t * BQC_COV_TILE_WINDOWS;
-            CovTile ct{};
-            ct.lane = l; ct.win_lo = wlo; ct.win_final = W1; ct.mixed = H.multi_lane ? 1u : 0u;
-            ct.list_begin = first_at(wlo == 0 ? 0 : wlo - 1);
-            ct.list_end = first_at((uint64_t)wlo + BQC_COV_TILE_WINDOWS);
-            H.tiles.push_back(ct);
-            const uint64_t hi = std::min<uint64_t>((uint64_t)wlo + BQC_COV_TILE_WINDOWS, W1);
-            if (hi > wlo) covered_final += hi - wlo;
-        };
-        if (started_before[l]) { push_tile(0); push_tile(1); }
-        // a window value w is live for some read iff a read's first window is w: first[w] != first[w + 1] (or w is the last)
-        for (uint64_t w = 0; w < first.size(); ++w) {
-            const bool present = w + 1 == first.size() || first[w] != first[w + 1];
-            if (present) { push_tile((uint32_t)w); push_tile((uint32_t)w + 1); }
-        }
-        if (W1 > covered_final) { // complete windows nobody touched: depth 0 everywhere
-            H.add_idx.push_back(c->sl.lane_base(l) + c->sl.o_poscov + 0);
-            H.add_val.push_back((uint64_t)(W1 - covered_final) * BQC_VSIZE);
-        }
-        c->cov[l].batch_base = c->cov[l].win; // the next batch numbers its windows from this batch's last live window
-    }
-    H.started_after.resize(nl);
-    for (uint32_t l = 0; l < nl; ++l) H.started_after[l] = !c->cov[l].first; // lanes that have seen a coverage read so far
+    H.n_pending = pb ? pb->n() : 0;
+    plan.finish();
     for (uint32_t e = 0; e < b->n_nm_extra; ++e)
         if (b->nm_extra_read[e] >= n) return bqc_fail(c, BQC_ERR_ARG, "nm_extra_read out of range");
     return 0;
@@ -434,6 +483,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     if (!out) return bqc_fail(c, BQC_ERR_ARG, "bqc_upload: null argument");
     int rc = check_batch_args(c, b, "bqc_upload");
     if (rc) return rc;
+    if (c->shard.tail && !c->shard.resolved) return bqc_fail(c, BQC_ERR_STATE, "bqc_upload: resident batches are not available to a shard_tail context (use bqc_submit)");
     HIPCHK(c, hipSetDevice(c->device));
     const auto t0 = clk::now();
     HostPass& H = c->hp;
@@ -513,6 +563,8 @@ void bqc_pipeline_destroy(bqc_ctx* c)
     }
     for (auto& pb : c->pool) (void)hipFree(pb.first);
     c->pool.clear();
+    for (PendBatch& pb : c->shard.batches) if (pb.dmem) (void)hipFree(pb.dmem);
+    c->shard.batches.clear();
 }
 
 static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint64_t* ticket_out)
@@ -537,6 +589,17 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
     const double t_pass = secs_since(t0) - t_wait;
     if ((rc = layout_batch(c, s.m, b, H, false))) return poison(c, rc);
     BatchMem& m = s.m;
+    if (H.n_pending) { // shard mode: the covered runs of the reads set aside stay on the device until bqc_shard_resolve
+        PendBatch& pb = c->shard.batches.back();
+        pb.extra_cap = (uint32_t)std::min<uint64_t>(H.cigar_words / 2 + 1, 0xFFFFFFF0ull);
+        const size_t bytes = sizeof(PendRun) * (size_t)pb.n() + 256 + sizeof(PendExtra) * (size_t)pb.extra_cap;
+        const hipError_t he = hipMalloc(&pb.dmem, bytes);
+        if (he != hipSuccess) { poison(c, BQC_ERR_DEVICE); return bqc_fail(c, BQC_ERR_DEVICE, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); }
+        m.prep.pend = (PendRun*)pb.dmem;
+        m.prep.pend_extra_n = (uint32_t*)((char*)pb.dmem + sizeof(PendRun) * (size_t)pb.n());
+        m.prep.pend_extra = (PendExtra*)((char*)m.prep.pend_extra_n + 256);
+        m.prep.pend_extra_cap = pb.extra_cap;
+    }
     // page-locked image: the host pass's tables, and the columns too unless the caller's are page-locked already
     const size_t img_begin = pinned_columns ? m.o_xr : m.h2d_begin, img_bytes = m.h2d_end - img_begin;
     if (s.hcap < img_bytes) {
@@ -605,3 +668,174 @@ extern "C" int bqc_host_register(void* p, uint64_t bytes)
     return hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? 0 : BQC_ERR_DEVICE;
 }
 extern "C" int bqc_host_unregister(void* p) { return p && hipHostUnregister(p) == hipSuccess ? 0 : BQC_ERR_DEVICE; }
+
+// ---------------------------------------------------------------------------------------------------
+// shards of one record stream (multi-GPU): hand-over of the coverage state machine
+// ---------------------------------------------------------------------------------------------------
+// exported block: int32 first / last FASTA position of the shard's triplet-eligible reads, then per read group
+// {first, started, pad, pad, id, shift} (12 bytes) and the 2000 depths of its two live windows
+namespace {
+struct LaneWire { uint8_t first, started, pad0, pad1; int32_t id, shift; };
+}
+static size_t shard_bytes(const bqc_ctx* c) { return 8 + (size_t)c->opt.n_lanes * (sizeof(LaneWire) + 2 * BQC_VSIZE * 4); }
+extern "C" uint64_t bqc_shard_state_bytes(const bqc_ctx* c) { return c ? shard_bytes(c) : 0; }
+
+extern "C" int bqc_shard_fasta_span(bqc_ctx* c, int32_t span[2])
+{
+    if (!c || !span) return BQC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = c->poisoned ? 0 : bqc_sync(c);
+    if (rc) return rc;
+    int32_t cur[2];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    span[0] = cur[1]; span[1] = cur[0];
+    return 0;
+}
+
+extern "C" int bqc_shard_export(bqc_ctx* c, void* out)
+{
+    if (!c || !out) return bqc_fail(c, BQC_ERR_ARG, "bqc_shard_export: null argument");
+    if (c->poisoned) return bqc_fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    if (c->shard.tail && !c->shard.resolved) return bqc_fail(c, BQC_ERR_STATE, "bqc_shard_export before bqc_shard_resolve");
+    if (c->flushed && !c->shard.exported) return bqc_fail(c, BQC_ERR_STATE, "bqc_shard_export after bqc_flush");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = bqc_sync(c);
+    if (rc) return rc;
+    const uint32_t nl = c->opt.n_lanes;
+    std::vector<uint32_t> parity(nl + 1);
+    std::vector<uint8_t> started(nl);
+    int32_t cur[2];
+    HIPCHK(c, hipMemcpy(parity.data(), c->d_parity, 4 * (size_t)nl, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(started.data(), c->d_started, nl, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    char* w = (char*)out;
+    const int32_t head[2] = {cur[1], cur[0]}; // first, last FASTA position of the eligible reads (-1: none)
+    memcpy(w, head, 8); w += 8;
+    for (uint32_t l = 0; l < nl; ++l) {
+        const LaneCov& s = c->cov[l];
+        const LaneWire lw{(uint8_t)s.first, started[l], 0, 0, s.id, s.shift};
+        memcpy(w, &lw, sizeof lw); w += sizeof lw;
+        HIPCHK(c, hipMemcpy(w, c->d_carry + ((size_t)l * 2 + (parity[l] & 1u)) * 2 * BQC_VSIZE, 2 * BQC_VSIZE * 4, hipMemcpyDeviceToHost));
+        w += 2 * BQC_VSIZE * 4;
+    }
+    c->shard.exported = true;
+    c->flushed = true; // the live windows are the successor's now: this state vector holds complete windows only
+    return 0;
+}
+
+extern "C" int bqc_shard_resolve(bqc_ctx* c, const void* pred)
+{
+    if (!c || !pred) return bqc_fail(c, BQC_ERR_ARG, "bqc_shard_resolve: null argument");
+    if (c->poisoned) return bqc_fail(c, BQC_ERR_STATE, "context is in an error state: %s", c->err.c_str());
+    ShardCtx& sh = c->shard;
+    if (!sh.tail || sh.resolved) return bqc_fail(c, BQC_ERR_STATE, "bqc_shard_resolve: not a shard_tail context, or resolved already");
+    if (c->flushed) return bqc_fail(c, BQC_ERR_STATE, "bqc_shard_resolve after bqc_flush");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = bqc_sync(c); // every batch of the shard is in: the pending logs are complete
+    if (rc) return rc;
+    const uint32_t nl = c->opt.n_lanes;
+    const size_t carry_lane = 2 * 2 * BQC_VSIZE; // words per read group in d_carry: [2 halves][2000]
+    // the shard's own ("main") trajectories aside; the predecessor's final state in their place
+    const std::vector<LaneCov> main_cov = c->cov;
+    uint32_t* d_save = nullptr; // carry | parity | started of the main trajectories
+    const size_t save_bytes = carry_lane * 4 * nl + 4 * ((size_t)nl + 1) + nl;
+    HIPCHK(c, hipMalloc(&d_save, save_bytes + 256));
+    uint32_t* d_save_par = d_save + carry_lane * nl;
+    uint8_t* d_save_started = (uint8_t*)(d_save_par + nl + 1);
+    HIPCHK(c, hipMemcpyAsync(d_save, c->d_carry, carry_lane * 4 * nl, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_save_par, c->d_parity, 4 * ((size_t)nl + 1), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_save_started, c->d_started, nl, hipMemcpyDeviceToDevice, c->stream));
+    const char* r = (const char*)pred + 8;
+    std::vector<uint32_t> carry_in(carry_lane * nl, 0);
+    std::vector<uint8_t> started_in(nl);
+    for (uint32_t l = 0; l < nl; ++l) {
+        LaneWire lw;
+        memcpy(&lw, r, sizeof lw); r += sizeof lw;
+        LaneCov s;
+        s.first = lw.first != 0; s.id = lw.id; s.shift = lw.shift; s.win = 0; s.batch_base = 0;
+        c->cov[l] = s;
+        started_in[l] = lw.started;
+        memcpy(carry_in.data() + carry_lane * l, r, 2 * BQC_VSIZE * 4); r += 2 * BQC_VSIZE * 4; // live half -> half 0
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_carry, carry_in.data(), carry_lane * 4 * nl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_parity, 0, 4 * ((size_t)nl + 1), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_started, started_in.data(), nl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the reads set aside, batch by batch, through the same planner and k_cov
+    HostPass& H = c->hp;
+    void* d_work = nullptr;
+    size_t work_cap = 0;
+    for (PendBatch& pb : sh.batches) {
+        const uint32_t n = pb.n();
+        H.n = n; H.multi_lane = nl > 1;
+        H.cov.resize(n);
+        CovPlanner plan(c, H, n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t rel;
+            uint32_t pos;
+            plan.step(i, pb.lane[i], pb.rid[i], pb.bp[i], rel, pos);
+            if (rel > 0xFFFFFFF0ull) { (void)hipFree(d_save); (void)hipFree(d_work); return poison(c, bqc_fail(c, BQC_ERR_ARG, "shard spans too many coverage windows")); }
+            H.cov[i] = CovEntry{(uint32_t)rel, pos};
+        }
+        plan.finish();
+        Carver cv;
+        const size_t o_cin = cv.take(sizeof(CovEntry) * (size_t)n), o_lane = cv.take(n), o_tiles = cv.take(sizeof(CovTile) * H.tiles.size()), o_mask = cv.take(nl),
+                     o_started = cv.take(nl), o_aidx = cv.take(8 * H.add_idx.size()), o_aval = cv.take(8 * H.add_val.size()), o_h2d_end = cv.off,
+                     o_cov = cv.take(sizeof(CovEntry) * (size_t)n), o_covx = cv.take(sizeof(CovExtra) * ((size_t)pb.extra_cap + 1)), o_desc = cv.take(sizeof(BatchDesc));
+        if (work_cap < cv.off) {
+            if (d_work) (void)hipFree(d_work);
+            d_work = nullptr;
+            const hipError_t he = hipMalloc(&d_work, cv.off + cv.off / 4);
+            if (he != hipSuccess) { (void)hipFree(d_save); return poison(c, bqc_fail(c, BQC_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(he))); }
+            work_cap = cv.off + cv.off / 4;
+        }
+        std::vector<char> img(o_h2d_end);
+        memcpy(img.data() + o_cin, H.cov.data(), sizeof(CovEntry) * (size_t)n);
+        memcpy(img.data() + o_lane, pb.lane.data(), n);
+        if (!H.tiles.empty()) memcpy(img.data() + o_tiles, H.tiles.data(), sizeof(CovTile) * H.tiles.size());
+        memcpy(img.data() + o_mask, H.lane_mask.data(), nl);
+        memcpy(img.data() + o_started, H.started_after.data(), nl);
+        if (!H.add_idx.empty()) { memcpy(img.data() + o_aidx, H.add_idx.data(), 8 * H.add_idx.size()); memcpy(img.data() + o_aval, H.add_val.data(), 8 * H.add_val.size()); }
+        char* base = (char*)d_work;
+        HIPCHK(c, hipMemcpyAsync(base, img.data(), o_h2d_end, hipMemcpyHostToDevice, c->stream));
+        const PendRun* pend = (const PendRun*)pb.dmem;
+        const uint32_t* extra_n = (const uint32_t*)((const char*)pb.dmem + sizeof(PendRun) * (size_t)n);
+        const PendExtra* extra = (const PendExtra*)((const char*)extra_n + 256);
+        bqc_launch_pend_cov(n, (const CovEntry*)(base + o_cin), pend, extra, extra_n, pb.extra_cap, (const uint8_t*)(base + o_lane), (CovEntry*)(base + o_cov),
+                            (CovExtra*)(base + o_covx), (BatchDesc*)(base + o_desc), c->stream);
+        DevBatch d{};
+        d.n_reads = n; d.lane = (const uint8_t*)(base + o_lane); d.cov = (const CovEntry*)(base + o_cov); d.cov_extra = (const CovExtra*)(base + o_covx);
+        d.desc = (const BatchDesc*)(base + o_desc); d.cov_tiles = (const CovTile*)(base + o_tiles); d.n_cov_tiles = (uint32_t)H.tiles.size();
+        if (!d.n_cov_tiles) bqc_launch_or_bytes(c->d_started, (const uint8_t*)(base + o_started), nl, c->stream);
+        else bqc_launch_cov(d, c->sl, c->d_state, c->d_carry, c->d_parity, (const uint8_t*)(base + o_mask), c->d_started, (const uint8_t*)(base + o_started), nl, c->stream);
+        bqc_launch_add_words(c->d_state, (const uint64_t*)(base + o_aidx), (const uint64_t*)(base + o_aval), (uint32_t)H.add_idx.size(), c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // (img and the tables are reused by the next batch)
+        (void)hipFree(pb.dmem);
+        pb.dmem = nullptr;
+    }
+    sh.batches.clear();
+    // Read groups that met a certain reset in this shard: the trajectory that came in ends there — the reset flushes its two live
+    // windows (bamqualcheck's update_coverage on both) — and the read group goes on with its main trajectory.  The others (every
+    // read set aside, or none at all) simply continue from the state that came in.
+    std::vector<uint8_t> sel(nl, 0);
+    bool any = false;
+    for (uint32_t l = 0; l < nl; ++l) { sel[l] = sh.pending[l] ? 0 : 1; any |= sel[l] != 0; }
+    if (any) {
+        uint8_t* d_sel = (uint8_t*)d_save + save_bytes; // (256 spare bytes behind the saved arrays; nl <= 256)
+        HIPCHK(c, hipMemcpyAsync(d_sel, sel.data(), nl, hipMemcpyHostToDevice, c->stream));
+        bqc_launch_cov_final(c->sl, c->d_state, c->d_carry, c->d_parity, c->d_started, d_sel, 0, c->stream);
+        for (uint32_t l = 0; l < nl; ++l)
+            if (sel[l]) {
+                c->cov[l] = main_cov[l];
+                HIPCHK(c, hipMemcpyAsync(c->d_carry + carry_lane * l, d_save + carry_lane * l, carry_lane * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_parity + l, d_save_par + l, 4, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->d_started + l, d_save_started + l, 1, hipMemcpyDeviceToDevice, c->stream));
+            }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_save);
+    if (d_work) (void)hipFree(d_work);
+    for (uint32_t l = 0; l < nl; ++l) sh.pending[l] = 0;
+    sh.resolved = true;
+    return 0;
+}

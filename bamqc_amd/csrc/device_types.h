@@ -50,6 +50,12 @@ struct CovEntry {
     uint32_t off_len; // host: pos; device: off | len << 16
 };
 #define BQC_COV_NONE 0xFFFFFFFFu
+// Shard of a stream that does not start at the stream's first record (multi-GPU): the window of a read group's first reads is
+// unknown until the predecessor shard's final state arrives.  The host marks such reads BQC_COV_PENDING with their index in
+// the batch's pending log (off_len); k_prep_reads stores the covered run(s) relative to beginPos there instead of an interval.
+#define BQC_COV_PENDING 0xFFFFFFFEu
+struct PendRun { uint32_t c0, len; };                 // first covered run: starts c0 positions behind beginPos (len = 0: none)
+struct PendExtra { uint32_t idx, c0, len, pad; };     // further runs of pending read idx
 struct CovExtra {     // second, third ... covered interval of a read whose clips sit between match operations (rare)
     uint32_t win, off_len, lane, pad;
 };

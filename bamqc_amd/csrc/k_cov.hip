@@ -148,12 +148,15 @@ __global__ __launch_bounds__(256) void k_cov(DevBatch b, StateLayout sl, uint64_
 }
 
 // end of stream: histogram the two live windows of every started lane (bamqualcheck.cpp:447-453)
+// (sel != nullptr: only the lanes with sel[lane] != 0 — the hand-over of a shard's set-aside reads, where the flush is the one a
+// reset performs in the middle of the stream: count_start = 0)
 __global__ __launch_bounds__(256) void k_cov_final(StateLayout sl, uint64_t* __restrict__ state, const uint32_t* __restrict__ carry,
-                                                      const uint32_t* __restrict__ parity, const uint8_t* __restrict__ started)
+                                                      const uint32_t* __restrict__ parity, const uint8_t* __restrict__ started, const uint8_t* __restrict__ sel,
+                                                      uint32_t count_start)
 {
     __shared__ uint32_t hist[BQC_COVSIZE + 1];
     const uint32_t lane = blockIdx.x;
-    if (!started[lane]) return;
+    if (!started[lane] || (sel && !sel[lane])) return;
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x) hist[i] = 0;
     block_sync();
     const uint32_t* c = carry + ((uint64_t)lane * 2 + (parity[lane] & 1u)) * 2000;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void k_cov_final(StateLayout sl, uint64_t* __r
     block_sync();
     for (uint32_t i = threadIdx.x; i <= BQC_COVSIZE; i += blockDim.x)
         if (hist[i]) gadd(state + sl.lane_base(lane) + sl.o_poscov + i, hist[i]);
-    if (threadIdx.x == 0) gadd(state + sl.lane_base(lane) + sl.o_covstart, 1);
+    if (threadIdx.x == 0 && count_start) gadd(state + sl.lane_base(lane) + sl.o_covstart, 1);
 }
 
 __global__ void k_or_bytes(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n)
@@ -195,9 +198,9 @@ extern "C" void bqc_launch_cov(const DevBatch& b, const StateLayout& sl, uint64_
 }
 
 extern "C" void bqc_launch_cov_final(const StateLayout& sl, uint64_t* state, const uint32_t* carry, const uint32_t* parity,
-                                     const uint8_t* started, hipStream_t s)
+                                     const uint8_t* started, const uint8_t* sel, uint32_t count_start, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_cov_final, dim3(sl.n_lanes), dim3(256), 0, s, sl, state, carry, parity, started);
+    hipLaunchKernelGGL(k_cov_final, dim3(sl.n_lanes), dim3(256), 0, s, sl, state, carry, parity, started, sel, count_start);
 }
 
 extern "C" void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t s)

@@ -12,6 +12,7 @@
 //                                first-mate and second-mate reads of one short stretch of the stream (shared 128-byte lines) while
 //                                every lane of k_short only ever sees one mate.
 // Only the O(1)-per-read coverage anchor recurrence (OverallNumbers.hpp:84-110) stays on the host (bqc_pipeline.cpp).
+#include <algorithm>
 #include "kernels_common.h"
 #include "prep.h"
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_prep_sizes(PrepArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0) { // first kernel of the batch: its records start empty; a replayed batch starts from its own cursor
         a.err->first_key = BQC_ERRKEY_NONE; a.err->flags = 0; a.err->aux0 = a.err->aux1 = 0;
         a.desc->n_cov_extra = 0;
+        if (a.pend_extra_n) *a.pend_extra_n = 0;
         if (a.replay) *a.cursor = *a.cursor_save; else *a.cursor_save = *a.cursor;
     }
     for (uint32_t k = blockIdx.x * PR_THREADS + threadIdx.x; k < a.n_sw; k += gridDim.x * PR_THREADS) a.sw_counts[k] = SwCounts{0, 0, 0, 0};
@@ -182,12 +184,23 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
     if (ce.win != BQC_COV_NONE) {
         flag |= BQC_FLAG_COV;
         const bool rc = flag & 0x10u;
-        const int64_t pos = (int64_t)ce.off_len;
+        const bool pending = ce.win == BQC_COV_PENDING; // shard mode: the window comes later (bqc_shard_resolve): runs relative to beginPos
+        const uint32_t pend_idx = ce.off_len;
+        const int64_t pos = pending ? 0 : (int64_t)ce.off_len;
         uint32_t cc = 0; // `int c` in the reference; wraps identically
         int64_t run_a = -1, run_z = -1;
         bool first = true;
         ce.off_len = 0;
         auto emit = [&](int64_t lo, int64_t hi) {
+            if (pending) { // (pos <= 2000 later: a run that starts 2000 or more behind beginPos can never count)
+                if (lo < 0 || lo >= 2 * BQC_VSIZE || lo >= hi) return;
+                const uint32_t len = (uint32_t)(hi - lo < 2 * BQC_VSIZE ? hi - lo : 2 * BQC_VSIZE);
+                if (first) { a.pend[pend_idx] = PendRun{(uint32_t)lo, len}; first = false; return; }
+                const uint32_t k = atomicAdd(a.pend_extra_n, 1u);
+                if (k < a.pend_extra_cap) a.pend_extra[k] = PendExtra{pend_idx, (uint32_t)lo, len, 0};
+                else atomicOr(&a.err->flags, BQC_DEVERR_INTERNAL);
+                return;
+            }
             hi = hi < 2 * BQC_VSIZE ? hi : 2 * BQC_VSIZE;
             if (lo < 0 || lo >= hi) return;
             const uint32_t v = (uint32_t)lo | ((uint32_t)(hi - lo) << 16);
@@ -212,6 +225,7 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
             }
             if (run_a >= 0) emit(run_a, run_z);
         }
+        if (pending) { if (first) a.pend[pend_idx] = PendRun{0, 0}; ce = CovEntry{BQC_COV_NONE, 0}; }
     } else ce.off_len = 0;
     // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
     // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
@@ -372,22 +386,24 @@ __global__ __launch_bounds__(PR_THREADS) void k_build_count(PrepArgs a)
 __global__ __launch_bounds__(1024) void k_build_plan(PrepArgs a)
 {
     __shared__ uint32_t sh[2 * 16 + 8];
-    __shared__ uint32_t s_fast_w, s_first_bad;
+    __shared__ uint32_t s_fast_w, s_first_bad, s_gmin;
     const uint32_t nblk = (a.n + PR_BLOCK - 1) / PR_BLOCK;
     // ---- (1) + (2)
     {
         uint32_t carry = (uint32_t)(*a.cursor + 1); // position + 1 of the last eligible read of the stream so far (0: none)
-        uint32_t mf = 0;
-        if (threadIdx.x == 0) s_first_bad = 0xFFFFFFFFu;
+        uint32_t mf = 0, gmin = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) { s_first_bad = 0xFFFFFFFFu; s_gmin = 0xFFFFFFFFu; }
         for (uint32_t b0 = 0; b0 < nblk; b0 += blockDim.x) {
             const uint32_t b = b0 + threadIdx.x;
             const uint32_t mx = b < nblk ? a.blk_tgt[2ull * b] : 0u, mn = b < nblk ? a.blk_tgt[2ull * b + 1] : 0xFFFFFFFFu;
             if (b < nblk) mf = max(mf, a.blk_maxfast[2ull * b]);
             uint32_t tot;
             const uint32_t before = max(carry, block_scan_excl_max(mx, sh, &tot));
+            gmin = min(gmin, mn);
             if (mn < before) atomicMin(&s_first_bad, b); // some eligible read of block b lies before an earlier block's
             carry = max(carry, tot);
         }
+        if (gmin != 0xFFFFFFFFu) atomicMin(&s_gmin, gmin);
         block_sync();
         const uint32_t bad = s_first_bad;
         if (bad != 0xFFFFFFFFu) { // find the first such read of that block (rare: the run ends with an error)
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(1024) void k_build_plan(PrepArgs a)
             for (uint32_t w = 0; w < blockDim.x / 64; ++w) m = max(m, sh[w]);
             s_fast_w = max(1u, (m + 8 * BQC_FAST_NH - 1) / (8 * BQC_FAST_NH));
             *a.cursor = (int32_t)carry - 1;
+            if (a.cursor[1] < 0 && s_gmin != 0xFFFFFFFFu) a.cursor[1] = (int32_t)s_gmin - 1; // first eligible read of the stream (shards check their order with it)
         }
         block_sync();
     }
@@ -563,4 +580,38 @@ extern "C" void bqc_launch_prep(const PrepArgs& a, const DevRefs& refs, hipStrea
     if (a.order) hipLaunchKernelGGL(k_build_count, dim3(a.n_sw), dim3(PR_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_build_scatter, dim3(a.n_sw), dim3(PR_THREADS), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shard mode: the set-aside reads of a batch, once their windows are known
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pend_interval(uint32_t pos, uint32_t c0, uint32_t len) // off | len << 16 inside the read's two live windows, 0: nothing
+{
+    const uint32_t lo = pos + c0;
+    if (!len || lo >= 2u * BQC_VSIZE) return 0u;
+    const uint32_t hi = min(lo + len, 2u * BQC_VSIZE);
+    return lo | ((hi - lo) << 16);
+}
+__global__ __launch_bounds__(256) void k_pend_cov(uint32_t n, const CovEntry* __restrict__ cov_in, const PendRun* __restrict__ pend, const PendExtra* __restrict__ extra,
+                                                     const uint32_t* __restrict__ extra_n, uint32_t extra_cap, const uint8_t* __restrict__ lane,
+                                                     CovEntry* __restrict__ cov_out, CovExtra* __restrict__ cov_extra, BatchDesc* __restrict__ desc)
+{
+    const uint32_t ne = min(*extra_n, extra_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const CovEntry ce = cov_in[i];
+        const PendRun r = pend[i];
+        cov_out[i] = CovEntry{ce.win, pend_interval(ce.off_len, r.c0, r.len)};
+    }
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        const PendExtra x = extra[e];
+        const CovEntry ce = cov_in[x.idx];
+        cov_extra[e] = CovExtra{ce.win, pend_interval(ce.off_len, x.c0, x.len), lane[x.idx], 0};
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { desc->n_cov_extra = ne; desc->fatal = 0; }
+}
+extern "C" void bqc_launch_pend_cov(uint32_t n, const CovEntry* cov_in, const PendRun* pend, const PendExtra* extra, const uint32_t* extra_n, uint32_t extra_cap,
+                                    const uint8_t* lane, CovEntry* cov_out, CovExtra* cov_extra, BatchDesc* desc, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_pend_cov, dim3(std::min<uint32_t>((n + 255) / 256, 4096u)), dim3(256), 0, s, n, cov_in, pend, extra, extra_n, extra_cap, lane, cov_out, cov_extra, desc);
 }

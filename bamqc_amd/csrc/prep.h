@@ -38,6 +38,10 @@ struct PrepArgs {
     CovEntry* cov_out;
     CovExtra* cov_extra;
     uint32_t cov_extra_cap;
+    PendRun* pend;            // shard mode: covered runs of the reads marked BQC_COV_PENDING (retained until bqc_shard_resolve)
+    PendExtra* pend_extra;
+    uint32_t* pend_extra_n;
+    uint32_t pend_extra_cap;
     uint16_t* cls;            // per read: class << 8 | triplet segments (class 0 / 1: fast read by mate slot, 2: generic path)
     TripSeg* segs;            // at cigar_off[r] + j
     uint32_t* perm;
@@ -59,3 +63,6 @@ struct PrepArgs {
 };
 
 extern "C" void bqc_launch_prep(const PrepArgs& a, const DevRefs& refs, hipStream_t s);
+// shard mode: intervals of a batch's pending reads once the host knows their windows (cov_in = {win, pos} per pending read)
+extern "C" void bqc_launch_pend_cov(uint32_t n, const CovEntry* cov_in, const PendRun* pend, const PendExtra* extra, const uint32_t* extra_n, uint32_t extra_cap,
+                                    const uint8_t* lane, CovEntry* cov_out, CovExtra* cov_extra, BatchDesc* desc, hipStream_t s);

@@ -1,20 +1,28 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The record stream shards by chromosome: every statistic of the hot path is a sum over reads except
-the coverage-depth histogram, whose window state machine (reference src/OverallNumbers.hpp:84-110)
-resets whenever the chromosome changes — and a reset flushes exactly the two windows the end-of-run
-flush would (bamqualcheck.cpp:447-453).  So ranks that each own whole chromosomes of a
-coordinate-sorted BAM produce state vectors that ADD to the single-process result.  The only
-collective is one reduce (uint64 sum, carried as int64) of the flat state vector at the end.
+The record stream is split by BYTES of the compressed file: process i of n runs the program (`bqc_main_shard`: the same C++
+reader, decode thread and asynchronous submit pipeline as the single-GPU program) over the records that start in its n-th of
+the file — no process inflates or decodes another's part, and the split does not care about chromosomes or sort order.
+Every statistic of the path is a sum over reads except the coverage-depth histogram, whose window state machine (reference
+src/OverallNumbers.hpp:84-110) depends on the reads before: a process that does not start at the stream's first record sets
+aside, per read group, its reads up to the first one at which the state machine resets whatever its state (another chromosome,
+or more than 2000 positions from the read before) and runs them once its predecessor's final state has arrived
+(include/bamqc.h: bqc_shard_resolve / bqc_shard_export).  Collectives: one all_gather of a few words per process (status, split
+check, FASTA order), one point-to-point hand-over of the coverage state per neighbour pair (8 KB per read group), ONE reduce
+(uint64 sum, carried as int64) of the flat state vector onto process 0, which writes the output.
 """
+import ctypes as C
 import os
+import time
 
 import numpy as np
 
+from . import _abi, _lib
+
 
 def plan_shards(ref_lens, world_size):
-    """Longest-processing-time assignment of contigs to ranks. Returns owner[rid] (np.int32).
-    Deterministic: ties break on the lower contig id / lower rank."""
+    """Longest-processing-time assignment of contigs to ranks (the chromosome-sharded mode of earlier versions; kept as a
+    planning helper). Returns owner[rid] (np.int32).  Deterministic: ties break on the lower contig id / lower rank."""
     order = sorted(range(len(ref_lens)), key=lambda i: (-int(ref_lens[i]), i))
     load = [0] * world_size
     owner = np.zeros(len(ref_lens), np.int32)
@@ -34,81 +42,151 @@ def reduce_state(vec, dst=0):
     return vec
 
 
-def gather_lane_names(names, dst=0):
-    """Union of the lane-name maps (getLane inserts unknown @RG IDs with index 0,
-    bamqualcheck.cpp:86) so the output lists the same blocks as a single process."""
-    import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
-        return dict(names)
-    objs = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(dict(names), objs, dst=dst)
-    if dist.get_rank() != dst:
-        return None
+def merge_lane_names(maps):
+    """Union of the lane-name maps of the processes, first come first kept (getLane inserts unknown @RG IDs with index 0,
+    bamqualcheck.cpp:86), so that the output lists the same blocks as a single process."""
     merged = {}
-    for d in objs:
+    for d in maps:
         for k, v in d.items():
             merged.setdefault(k, v)
     return merged
 
 
-def run_sharded(bam, fasta, out, chroms=None, isize=1000, klist=(32,), qlist=(17,), backend=None, device=None,
-                batch_reads=1 << 20, max_read_len=65536, hist_cap=65536):
-    """bamqualcheck over a coordinate-sorted BAM, sharded by chromosome across the ranks of the
-    initialised process group (or a single process). Rank 0 writes `out`. Returns 0 / error code."""
+def gather_lane_names(names, dst=0):
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return dict(names)
+    objs = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(dict(names), objs, dst=dst)
+    return merge_lane_names(objs) if dist.get_rank() == dst else None
+
+
+def split_is_consistent(ranges):
+    """ranges[i] = (has_blocks, begin_block, end_block, first, over) of shard i.  Every shard that starts in the middle of the
+    file GUESSED where its first record starts; the guess is right iff the predecessor's last record ends exactly there
+    (`over` of the predecessor, relative to the block both call their boundary)."""
+    prev = None
+    for has, b0, b1, first, over in ranges:
+        if not has:
+            continue  # (a shard without blocks: its neighbours meet directly)
+        if prev is not None:
+            if prev[2] != b0 or prev[4] != first:
+                return False
+        prev = (has, b0, b1, first, over)
+    return True
+
+
+def fasta_order_is_consistent(spans):
+    """spans[i] = (first, last) FASTA position of shard i's triplet-eligible reads (-1: none): the forward-only FASTA scan
+    (TripletCounting.hpp:254-259) of the whole stream succeeds iff no shard starts before its predecessors ended."""
+    last = -1
+    for first, lst in spans:
+        if first < 0:
+            continue
+        if first < last:
+            return False
+        last = max(last, lst)
+    return True
+
+
+def run_sharded(argv, backend=None, device=None):
+    """`bamqualcheck` (argv as for the program, argv[0] = program name) over the initialised process group: returns the exit
+    status of this process (0 on every process on success)."""
     import torch
     import torch.distributed as dist
-    from . import Aggregator, hostio
+    lib = _lib.load()
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     backend = backend or (dist.get_backend() if dist.is_initialized() else "none")
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    f = hostio.BamFile(bam)
-    chroms = chroms if chroms is not None else ",".join("chr%d" % i for i in range(1, 23))
-    main = np.array([1 if n in chroms.split(",") else 0 for n in f.ref_names], np.uint8)
-    f.set_main_chrom(main)
-    owner = plan_shards(f.ref_lens, world)
-    f.set_rid_filter((owner == rank).astype(np.uint8), keep_unplaced=(rank == world - 1))
-    try:
-        fa = hostio.load_fasta(fasta)
-    except IOError:
-        fa = []
-    fidx = np.full(max(1, len(f.ref_names)), -1, np.int32)
-    for r, name in enumerate(f.ref_names):
-        for i, (n, _) in enumerate(fa):
-            if n == name:
-                fidx[r] = i
-                break
-    agg = Aggregator(n_lanes=max(1, f.lane_count), n_refs=len(f.ref_names), isize=isize, main_chrom=main, fasta_index=fidx,
-                     max_read_len=max_read_len, hist_cap=hist_cap, klist=klist, qlist=qlist, device=device)
-    for r in range(len(f.ref_names)):
-        if fidx[r] >= 0 and owner[r] == rank:
-            agg.set_reference(r, fa[fidx[r]][1])
-    last_rid = -2
-    for cols in f.batches(max_reads=batch_reads):
-        rid = cols["rid"]
-        placed = rid[rid >= 0]
-        if len(placed) and (np.any(np.diff(placed) < 0) or placed[0] < last_rid):
-            raise RuntimeError("multi-GPU sharding needs a coordinate-sorted BAM (reference ids went backwards)")
-        if len(placed):
-            last_rid = int(placed[-1])
-        agg.submit(cols)
-    names = gather_lane_names(dict(f.lanes()))
-    if world > 1:
+    argv = list(argv) + ["--device", str(device)]
+    cargs = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    if world == 1:
+        return int(lib.bqc_main(len(argv), cargs))
+    tdev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+    keep = {}
+
+    def hook(_user, info_p, out_p):
+        info = info_p.contents
+        ctx = info.ctx
+        mine = dict(status=int(info.status), has_ctx=bool(ctx), b0=int(info.begin_block), b1=int(info.end_block), first=int(info.first),
+                    over=int(info.over), span=(-1, -1),
+                    lanes={info.lane_names[i].decode(): int(info.lane_index[i]) for i in range(info.n_lane_names)})
+        if ctx and not mine["status"]:
+            sp = (C.c_int32 * 2)()
+            if lib.bqc_shard_fasta_span(ctx, sp):
+                print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+                mine["status"] = 1
+            mine["span"] = (int(sp[0]), int(sp[1]))
+        every = [None] * world
+        dist.all_gather_object(every, mine)  # ---- agree on the status before any data collective
+        if any(e["status"] for e in every):
+            return _abi.SHARD_FAIL
+        if not any(e["has_ctx"] for e in every):
+            return _abi.SHARD_DONE  # (no @RG line: there are no counters)
+        if not fasta_order_is_consistent([e["span"] for e in every]):
+            if rank == 0:
+                print("ERROR: Could not read fasta record (the BAM file's contig order runs backwards in the FASTA file)", flush=True)
+            return _abi.SHARD_FAIL
+        size = int(lib.bqc_file_size([a for a in argv if a.endswith(".bam")][-1].encode()))
+        ranges = [(e["b0"] < min(e["b1"], size), e["b0"], e["b1"], e["first"], e["over"]) for e in every]
+        if not split_is_consistent(ranges):
+            if rank == 0:
+                print("bamqualcheck: the split of the file could not be verified; processing it in one process", flush=True)
+            return _abi.SHARD_FALLBACK if rank == 0 else _abi.SHARD_DONE
+        # ---- coverage state down the chain: predecessor's final state in, own final state out
+        nbytes = int(lib.bqc_shard_state_bytes(ctx))
+        if rank > 0:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=tdev)
+            dist.recv(t, src=rank - 1)
+            buf = np.ascontiguousarray(t.cpu().numpy())
+            rc = lib.bqc_shard_resolve(ctx, buf.ctypes.data_as(C.c_void_p))
+        else:
+            rc = 0
+        if not rc:
+            if rank < world - 1:
+                buf = np.zeros(nbytes, np.uint8)
+                rc = lib.bqc_shard_export(ctx, buf.ctypes.data_as(C.c_void_p))
+            else:
+                rc = lib.bqc_flush(ctx)  # the last shard ends as a whole stream does: its two live windows per read group are flushed
+        if rank < world - 1:  # (sent also after a failure: the successor is waiting)
+            dist.send(torch.from_numpy(buf if not rc else np.zeros(nbytes, np.uint8)).to(tdev), dst=rank + 1)
+        bad = torch.tensor([1 if rc else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            if rc:
+                print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+            return _abi.SHARD_FAIL
+        # ---- ONE reduce of the flat state vector onto process 0
+        words = int(lib.bqc_state_words(ctx))
         if backend == "nccl":
-            vec = torch.empty(agg.state_words, dtype=torch.int64, device=torch.device("cuda", device))
-            agg.state_export_device(vec.data_ptr())
+            vec = torch.empty(words, dtype=torch.int64, device=tdev)
+            rc = lib.bqc_state_export(ctx, C.c_void_p(vec.data_ptr()))
             reduce_state(vec)
-            if rank == 0:
-                agg.state_import_device(vec.data_ptr())
+            if rank == 0 and not rc:
+                rc = lib.bqc_state_import(ctx, C.c_void_p(vec.data_ptr()))
         else:  # gloo: host tensors
-            vec = torch.from_numpy(agg.state_export_host().view(np.int64))
+            host = np.zeros(words, np.uint64)
+            rc = lib.bqc_state_export_host(ctx, host.ctypes.data_as(_abi.u64p))
+            vec = torch.from_numpy(host.view(np.int64))
             reduce_state(vec)
-            if rank == 0:
-                agg.state_import_host(vec.numpy().view(np.uint64))
-    if rank == 0:
-        agg.finalize_raw()
-        order = sorted(names.items())
-        agg.write_bamqc(out, sample_id=f.sample_id, lane_names=[n for n, _ in order], lane_index=[i for _, i in order])
-    agg.close()
-    return 0
+            if rank == 0 and not rc:
+                rc = lib.bqc_state_import_host(ctx, host.ctypes.data_as(_abi.u64p))
+        if rc:
+            print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+            return _abi.SHARD_FAIL
+        if rank != 0:
+            return _abi.SHARD_DONE
+        merged = sorted(merge_lane_names([e["lanes"] for e in every]).items())  # writeOutput iterates a std::map: lexicographic
+        names = (C.c_char_p * len(merged))(*[k.encode() for k, _ in merged])
+        idx = np.ascontiguousarray([v for _, v in merged], np.uint32)
+        keep["names"], keep["idx"] = names, idx
+        out = out_p.contents
+        out.n_lane_names = len(merged)
+        out.lane_names = names
+        out.lane_index = idx.ctypes.data_as(_abi.u32p)
+        return _abi.SHARD_WRITE
+
+    cb = _abi.SHARD_HOOK(hook)
+    return int(lib.bqc_main_shard(len(argv), cargs, rank, world, cb, None))

@@ -35,7 +35,7 @@ bool BamReader::fill(size_t need, std::string& err)
 {
     while (buf_.size() - cur_ < need) {
         if (eof_) { if (!sticky_err_.empty()) err = sticky_err_; return false; }
-        if (cur_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + cur_); cur_ = 0; }
+        if (cur_ > (1u << 22)) { buf_.erase(buf_.begin(), buf_.begin() + cur_); base_u_ += cur_; cur_ = 0; }
         std::string e;
         const auto w0 = std::chrono::steady_clock::now();
         const bool got = bg_.next_chunk(chunk_, e);
@@ -142,6 +142,68 @@ static inline bool plausible_record(const uint8_t* base, size_t avail, size_t p,
     return true;
 }
 
+bool BamReader::open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, std::string& err)
+{
+    if (!open(path, err)) return false; // header (from the file's start)
+    ranged_ = true;
+    const uint64_t size = bgzf_file_size(path);
+    range_b1_ = end_hint >= size ? UINT64_MAX : bgzf_find_block(path, end_hint, err);
+    if (!err.empty()) return false;
+    if (range_b1_ >= size) range_b1_ = UINT64_MAX;
+    if (begin_hint == 0) { // the first shard keeps reading where the header ended; its stream started at offset 0
+        range_b0_ = 0;
+        if (range_b1_ != UINT64_MAX) { // (reopen with the mark: the header is parsed again from the same bytes)
+            const size_t keep_cur = cur_;
+            bg_.~BgzfReader();
+            new (&bg_) BgzfReader();
+            buf_.clear(); cur_ = 0; base_u_ = 0; eof_ = false; sticky_err_.clear();
+            if (!bg_.open_at(path, 0, range_b1_, err)) return false;
+            std::string e;
+            if (!fill(keep_cur, e)) { err = e.empty() ? "truncated BAM header" : e; return false; }
+            cur_ = keep_cur;
+        }
+        return true;
+    }
+    range_b0_ = bgzf_find_block(path, begin_hint, err);
+    if (!err.empty()) return false;
+    bg_.~BgzfReader();
+    new (&bg_) BgzfReader();
+    buf_.clear(); cur_ = 0; base_u_ = 0; eof_ = false; sticky_err_.clear();
+    if (range_b0_ >= size || (range_b1_ != UINT64_MAX && range_b0_ >= range_b1_)) { range_done_ = true; eof_ = true; range_b0_ = std::min(range_b0_, size); return true; } // empty shard
+    if (!bg_.open_at(path, range_b0_, range_b1_, err)) return false;
+    need_locate_ = true;
+    return true;
+}
+
+// first record of a shard that starts in the middle of the file: the first offset at which three records in a row look like
+// records (the test of the parallel record walk); the predecessor shard confirms it afterwards (range_over / range_first)
+bool BamReader::locate_first_record(std::string& err)
+{
+    need_locate_ = false;
+    std::string e;
+    (void)fill(4u << 20, e); // best effort: a small shard has less
+    if (!e.empty()) { err = e; return false; }
+    const size_t avail = buf_.size() - cur_;
+    const uint8_t* base = buf_.data() + cur_;
+    const int32_t n_ref = (int32_t)hdr_.ref_names.size();
+    static const bool skew = getenv("BQC_TEST_SHARD_SKEW") != nullptr; // tests: a wrong guess (the second record found), to exercise the fallback
+    for (size_t p = 0; p < avail; ++p) {
+        if (beyond_range(p)) break; // no record starts inside this shard
+        size_t q1, q2, q3;
+        const bool hit = plausible_record(base, avail, p, n_ref, q1) &&
+                         (q1 >= avail || (plausible_record(base, avail, q1, n_ref, q2) && (q2 >= avail || plausible_record(base, avail, q2, n_ref, q3))));
+        if (!hit) continue;
+        if (skew && q1 < avail) p = q1;
+        range_first_ = p;
+        cur_ += p;
+        return true;
+    }
+    range_first_ = avail; // nothing starts here: the shard is empty, the predecessor's last record covers it
+    range_done_ = true;
+    range_over_ = 0;
+    return true;
+}
+
 void BamReader::walk_segment(const uint8_t* base, size_t avail, size_t a, size_t b, bool exact_start, WalkSeg& out) const
 {
     out.recs.clear();
@@ -183,7 +245,11 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
     {
         // records this batch will hold: its read limit or, for long reads, its base limit
         const double n_exp = std::min((double)max_reads, avg_rec_bases_ > 0 ? (double)max_bases / avg_rec_bases_ + 1.0 : (double)max_reads);
-        const double want = std::min(n_exp * avg_rec_bytes_ * 1.02, 3.0e9);
+        double want = std::min(n_exp * avg_rec_bytes_ * 1.02, 3.0e9);
+        if (ranged_ && bg_.mark_u() != UINT64_MAX) { // a shard: nothing is wanted far behind its end
+            const uint64_t here = base_u_ + cur_, m = bg_.mark_u();
+            want = std::min(want, (double)(m > here ? m - here : 0) + (double)(1u << 20));
+        }
         std::string e;
         (void)fill((size_t)want, e); // best effort: at the end of the file (or a damaged block) less is there
     }
@@ -214,6 +280,7 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
     size_t n_take = 0;
     for (; n_take < recs.size() && n_take < max_reads && bases < max_bases; ++n_take) {
         Rec& r = recs[n_take];
+        if (ranged_ && beyond_range(r.off)) break; // starts behind the shard's end: the serial walk below notes where
         r.so = so; r.qo = qo; r.co = co;
         so += (r.l_seq + 1) / 2; qo += r.l_seq; co += r.n_cig;
         bases += r.l_seq;
@@ -240,6 +307,11 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<Rec>& recs = recs_;
     recs.clear();
+    if (range_done_) return 0;
+    if (need_locate_) {
+        if (!locate_first_record(err)) { err_code = BQC_ERR_IO; return -1; }
+        if (range_done_) return 0;
+    }
     recs.reserve(std::min<size_t>(max_reads, 1u << 20));
     size_t bases = 0, so = 0, qo = 0, co = 0;
     size_t rel = 0; // bytes of this batch walked so far; cur_ stays at the batch start, so fill() never drops them
@@ -251,6 +323,11 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         // With a refID filter nothing may have been kept yet: those bytes are released at once (cur_ moves on; fill() drops what
         // lies before it), otherwise a rank whose chromosomes sit late in the file would hold everything before them in memory.
         if (recs.empty() && rel > (8u << 20)) { cur_ += rel; released += rel; rel = 0; }
+        if (ranged_ && beyond_range(rel)) { // the next record starts in the successor's blocks: this shard ends here
+            range_over_ = base_u_ + cur_ + rel - bg_.mark_u();
+            range_done_ = true;
+            break;
+        }
         // fast path: the whole record is already in the buffer (fill() is only called when it is not)
         size_t avail = buf_.size() - cur_;
         if (avail < rel + 4 || avail < rel + 4 + (size_t)rd32(buf_.data() + cur_ + rel)) {

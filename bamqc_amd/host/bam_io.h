@@ -50,6 +50,17 @@ void parse_read_groups(BamHeader& h); // getSampleIdAndLaneNames, bamqualcheck.c
 class BamReader : public RecordReader {
 public:
     bool open(const char* path, std::string& err);
+    // One shard of the record stream (multi-GPU): the header is read from the file's start as always; records are then taken
+    // from the first record that STARTS in a BGZF block at or behind bgzf_find_block(begin_hint) — located by the same test
+    // the parallel record walk uses for its guesses — up to the last record that starts before the block at
+    // bgzf_find_block(end_hint) (records run on into the next shard's blocks).  begin_hint 0: from the first record;
+    // end_hint UINT64_MAX: to the end.  Neighbouring shards verify afterwards that the first ended where the second began:
+    // range_over() of a shard (bytes of its last record beyond its end block) == range_first() of its successor.
+    bool open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, std::string& err);
+    uint64_t range_begin_block() const { return range_b0_; }
+    uint64_t range_end_block() const { return range_b1_; }
+    uint64_t range_first() const { return range_first_; }   // uncompressed offset of the shard's first record in its first block
+    uint64_t range_over() const { return range_over_; }     // valid after the last batch: where the next record starts, relative to the end block
     const BamHeader& header() const { return hdr_; }
     BamHeader& header() override { return hdr_; }
     void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
@@ -81,6 +92,12 @@ private:
     bool filter_ = false, keep_unplaced_ = true;
     uint64_t nrec_ = 0;
     double t_wait_ = 0, t_copy_ = 0; // BQC_TIMING=3
+    // shard of the stream (open_range)
+    bool ranged_ = false, need_locate_ = false, range_done_ = false;
+    uint64_t range_b0_ = 0, range_b1_ = UINT64_MAX, range_first_ = 0, range_over_ = 0;
+    uint64_t base_u_ = 0; // position of buf_[0] in the uncompressed stream of bg_
+    bool locate_first_record(std::string& err);
+    bool beyond_range(size_t rel) const { const uint64_t m = bg_.mark_u(); return m != UINT64_MAX && base_u_ + cur_ + rel >= m; }
 };
 
 // SAM text from a stream (the reference reads SAM from stdin when the input is "-": bamqualcheck.cpp:252-260,

@@ -90,11 +90,74 @@ bool BgzfReader::open(const char* path, std::string& err, unsigned threads)
     return true;
 }
 
+bool BgzfReader::open_at(const char* path, uint64_t begin, uint64_t mark, std::string& err, unsigned threads)
+{
+    if (!open(path, err, threads)) return false;
+    if (begin && fseeko(f_, (off_t)begin, SEEK_SET) != 0) { err = std::string("could not seek in ") + path; return false; }
+    file_pos_ = begin;
+    mark_ = mark;
+    if (mark_ <= begin) mark_u_ = 0;
+    return true;
+}
+
+uint64_t bgzf_file_size(const char* path)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;
+    fseeko(f, 0, SEEK_END);
+    const uint64_t n = (uint64_t)ftello(f);
+    fclose(f);
+    return n;
+}
+
+uint64_t bgzf_find_block(const char* path, uint64_t hint, std::string& err)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { err = std::string("could not open ") + path; return 0; }
+    fseeko(f, 0, SEEK_END);
+    const uint64_t size = (uint64_t)ftello(f);
+    if (hint >= size) { fclose(f); return size; }
+    // a window that holds every candidate start within 64 KiB of the hint (a block is at most 64 KiB) and three blocks behind it
+    std::vector<uint8_t> w((size_t)std::min<uint64_t>(size - hint, 5 * kMaxBlock));
+    fseeko(f, (off_t)hint, SEEK_SET);
+    const size_t got = fread(w.data(), 1, w.size(), f);
+    fclose(f);
+    w.resize(got);
+    auto block_at = [&](size_t p, size_t& bsize) { // a BGZF header at w[p]?
+        if (p + 18 > w.size()) return false;
+        const uint8_t* h = w.data() + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return false;
+        const size_t xlen = h[10] | (h[11] << 8);
+        if (p + 12 + xlen > w.size()) return false;
+        size_t x = 12;
+        bsize = 0;
+        while (x + 4 <= 12 + xlen) {
+            const size_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (x + 4 + slen > 12 + xlen) return false;
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        return bsize >= 12 + xlen + 8;
+    };
+    for (size_t p = 0; p < w.size(); ++p) {
+        size_t q = p, bs = 0;
+        int ok = 0;
+        for (; ok < 3; ++ok) { // the chain of three headers, or the end of the file
+            if (hint + q == size) { ok = 3; break; }
+            if (!block_at(q, bs)) break;
+            q += bs;
+        }
+        if (ok == 3) return hint + p;
+    }
+    return size;
+}
+
 bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
 {
     out.clear();
     if (eof_) return false;
-    const size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
+    size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
+    if (mark_u_.load() != UINT64_MAX) want = 4 * kMaxBlock;                          // behind the mark: only the rest of a record is wanted
     // keep the tail of the previous round (a partial block) at the front of raw_
     size_t have = raw_.size();
     { const size_t cap = raw_.capacity(); raw_.resize(have + want); if (raw_.capacity() != cap) advise_huge(raw_); }
@@ -122,10 +185,15 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
         const uint8_t* t = raw_.data() + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
         if (isize > kMaxBlock) { err = "BGZF block larger than 64 KiB"; return false; }
+        if (mark_u_.load() == UINT64_MAX) { // where the wanted block boundary lies in the uncompressed stream
+            if (file_pos_ + p == mark_) mark_u_ = u_total_ + utotal;
+            else if (file_pos_ + p > mark_) { mark_missed_ = true; err = "the split point of the file is not a BGZF block boundary"; return false; }
+        }
         blocks.push_back(BlockRef{p + 12 + xlen, bsize - 12 - xlen - 8, isize, utotal});
         utotal += isize;
         p += bsize;
     }
+    if (mark_u_.load() == UINT64_MAX && eof_ && p == raw_.size() && file_pos_ + p == mark_) mark_u_ = u_total_ + utotal; // (mark = end of the file)
     if (eof_ && p != raw_.size()) { err = "truncated BGZF file"; return false; }
     { const size_t cap = out.capacity(); out.resize(utotal); if (out.capacity() != cap) advise_huge(out); }
     std::atomic<bool> bad{false};
@@ -141,6 +209,8 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
     });
     if (bad) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
     raw_.erase(raw_.begin(), raw_.begin() + p);
+    file_pos_ += p;
+    u_total_ += utotal;
     if (out.empty() && eof_) return false;
     return true;
 }

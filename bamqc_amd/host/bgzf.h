@@ -2,6 +2,7 @@
 // Replaces SeqAn's BAM stream layer (reference src/bamqualcheck.cpp:262, readRecord :306).
 // Format: public SAM/BAM specification (gzip members <= 64 KiB with a "BC" extra field).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -17,6 +18,12 @@ class BgzfReader {
 public:
     ~BgzfReader();
     bool open(const char* path, std::string& err, unsigned threads = 0);
+    // Start at `begin` (the file offset of a BGZF block, see bgzf_find_block) instead of the file's start.  `mark` (a later block
+    // boundary, or UINT64_MAX): mark_u() becomes the number of uncompressed bytes this reader yields before that block once it
+    // gets there, and from there on it reads in small steps (the caller only needs the rest of a record).
+    bool open_at(const char* path, uint64_t begin, uint64_t mark, std::string& err, unsigned threads = 0);
+    uint64_t mark_u() const { return mark_u_.load(); }      // UINT64_MAX: not reached yet
+    bool mark_missed() const { return mark_missed_.load(); } // the block chain stepped over `mark`: it is not a block boundary
     // Fills `out` with the next run of uncompressed bytes (many blocks at once); returns false at EOF.
     // On a malformed stream sets err and returns false.  A read-ahead thread inflates the following runs meanwhile.
     bool next_chunk(raw_vector<uint8_t>& out, std::string& err);
@@ -38,7 +45,18 @@ private:
     uint64_t cbytes_ = 0;
     bool eof_ = false;
     raw_vector<uint8_t> raw_;
+    uint64_t file_pos_ = 0;          // file offset of raw_[0]
+    uint64_t mark_ = UINT64_MAX;     // file offset whose uncompressed position is wanted
+    uint64_t u_total_ = 0;           // uncompressed bytes yielded so far
+    std::atomic<uint64_t> mark_u_{UINT64_MAX};
+    std::atomic<bool> mark_missed_{false};
 };
+
+// The offset of the first BGZF block at or behind `hint` (a gzip member header with the BC subfield whose BSIZE leads to two
+// more such headers, or to the end of the file); the file size if there is none.  Every caller gets the same answer for the
+// same hint, so two readers that split a file at bgzf_find_block(hint) agree on the boundary.
+uint64_t bgzf_find_block(const char* path, uint64_t hint, std::string& err);
+uint64_t bgzf_file_size(const char* path);
 
 class BgzfWriter {
 public:

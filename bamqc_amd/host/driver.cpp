@@ -157,6 +157,20 @@ extern "C" int bqc_bam_open(const char* path, bqc_bam** out)
     *out = b;
     return 0;
 }
+extern "C" int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out)
+{
+    if (!path || !out) return BQC_ERR_ARG;
+    auto* b = new bqc_bam();
+    *out = b;
+    if (!b->bam.open_range(path, begin_hint, end_hint, b->err)) return BQC_ERR_IO;
+    b->refresh_lanes();
+    return 0;
+}
+extern "C" uint64_t bqc_bam_range_begin_block(const bqc_bam* b) { return b->bam.range_begin_block(); }
+extern "C" uint64_t bqc_bam_range_end_block(const bqc_bam* b) { return b->bam.range_end_block(); }
+extern "C" uint64_t bqc_bam_range_first(const bqc_bam* b) { return b->bam.range_first(); }
+extern "C" uint64_t bqc_bam_range_over(const bqc_bam* b) { return b->bam.range_over(); }
+extern "C" uint64_t bqc_file_size(const char* path) { return path ? bgzf_file_size(path) : 0; }
 extern "C" int bqc_inflate_raw(const uint8_t* in, uint64_t in_n, uint8_t* out, uint64_t out_n)
 {
     static thread_local Inflater inf;
@@ -538,7 +552,11 @@ struct BatchQueue { // decode thread -> submit thread
 };
 } // namespace
 
-extern "C" int bqc_main(int argc, const char** argv)
+namespace {
+struct ShardArgs { uint32_t index, count; bqc_shard_hook hook; void* user; };
+}
+
+static int run_program(int argc, const char** argv, const ShardArgs* shard)
 {
     ProgramOptions opt;
     std::string perr;
@@ -560,14 +578,26 @@ extern "C" int bqc_main(int argc, const char** argv)
     SamReader sam_rd;
     std::string err;
     const bool from_stdin = opt.bamFile == "-";
-    if (from_stdin ? !sam_rd.open(stdin, err) : !bam_rd.open(opt.bamFile.c_str(), err)) {
+    // a failure before the hook is reached must still reach it: the other processes wait for this one
+    auto shard_abort = [&]() { if (shard) { bqc_shard_info si{}; si.status = 1; bqc_shard_result sr{}; (void)shard->hook(shard->user, &si, &sr); } return 1; };
+    if (shard && from_stdin) { fprintf(stderr, "ERROR: a stream on stdin cannot be split between processes\n"); return shard_abort(); }
+    bool opened;
+    if (from_stdin) opened = sam_rd.open(stdin, err);
+    else if (shard) { // this process's part of the compressed file
+        const uint64_t size = bqc_file_size(opt.bamFile.c_str());
+        const uint64_t lo = size / shard->count * shard->index, hi = shard->index + 1 == shard->count ? UINT64_MAX : size / shard->count * (shard->index + 1);
+        opened = bam_rd.open_range(opt.bamFile.c_str(), lo, hi, err);
+    } else opened = bam_rd.open(opt.bamFile.c_str(), err);
+    if (!opened) {
         fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
-        return 1;
+        return shard_abort();
     }
     RecordReader& rd = from_stdin ? static_cast<RecordReader&>(sam_rd) : static_cast<RecordReader&>(bam_rd);
-    FILE* of = fopen(opt.outputFile.c_str(), "wb"); // opened (truncated) before the scan, :278-283
-    if (!of) { fprintf(stderr, "ERROR: Could not open output file %s\n", opt.outputFile.c_str()); return 1; }
-    fclose(of);
+    if (!shard || shard->index == 0) {
+        FILE* of = fopen(opt.outputFile.c_str(), "wb"); // opened (truncated) before the scan, :278-283
+        if (!of) { fprintf(stderr, "ERROR: Could not open output file %s\n", opt.outputFile.c_str()); return shard_abort(); }
+        fclose(of);
+    }
     const BamHeader& H = rd.header();
     const uint32_t n_refs = (uint32_t)H.ref_names.size();
     // initChroms (:106-123): names that are not BAM references are silently dropped
@@ -626,7 +656,8 @@ extern "C" int bqc_main(int argc, const char** argv)
         HostBatch hb;
         int code = 0;
         const int rc = rd.next_batch(hb, 1, 1 << 20, err, code);
-        if (rc != 0) { fprintf(stderr, "%s\n", rc < 0 ? err.c_str() : "ERROR: records present but the header has no @RG line"); return 1; }
+        if (rc != 0) { fprintf(stderr, "%s\n", rc < 0 ? err.c_str() : "ERROR: records present but the header has no @RG line"); return shard_abort(); }
+        if (shard) { bqc_shard_info si{}; bqc_shard_result sr{}; (void)shard->hook(shard->user, &si, &sr); } // (nothing to merge: no counters at all)
         return 0;
     }
     // the context is created (device memory, streams, sketch tables: ~0.1 s) by a thread of its own while this one reads the FASTA file
@@ -636,6 +667,7 @@ extern "C" int bqc_main(int argc, const char** argv)
     bo.n_lanes = H.lane_count; bo.n_refs = n_refs; bo.isize = opt.isize;
     bo.max_read_len = opt.max_read_len; bo.hist_cap = opt.hist_cap;
     bo.main_chrom = main_chrom.data(); bo.fasta_index = nullptr; bo.device = opt.device; // (FASTA order: bqc_set_fasta_index below)
+    bo.shard_tail = shard && shard->index > 0 ? 1u : 0u;
     if (!opt.no_sketch) {
         bo.sketch.n_k = (uint32_t)opt.klist.size(); bo.sketch.klist = opt.klist.data();
         bo.sketch.n_q = (uint32_t)opt.q_cutoff.size(); bo.sketch.qlist = opt.q_cutoff.data();
@@ -662,12 +694,12 @@ extern "C" int bqc_main(int argc, const char** argv)
     const auto t_fasta = clk::now();
     creator.join();
     const auto t_create = clk::now();
-    if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return 1; }
-    if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return 1; }
+    if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return shard_abort(); }
+    if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
     for (uint32_t r = 0; r < n_refs; ++r)
         if (fasta_index[r] >= 0) {
             const auto& c = fa[fasta_index[r]].codes;
-            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return 1; }
+            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
         }
     fa.clear();
     fa.shrink_to_fit();
@@ -742,15 +774,32 @@ extern "C" int bqc_main(int argc, const char** argv)
         else fprintf(Q.err == "Read does not have Z" ? stdout : stderr, "%s\n", Q.err.c_str());
         status = 1;
     }
+    // writeOutput iterates laneNames (std::map: lexicographic), including IDs inserted by getLane
+    std::vector<const char*> names;
+    std::vector<uint32_t> idx;
+    for (auto& kv : rd.header().lane_names) { names.push_back(kv.first.c_str()); idx.push_back(kv.second); }
+    if (shard) { // what needs the other processes: split check, coverage hand-over, sum of the state vectors, lane names
+        bqc_shard_info si{};
+        si.ctx = ctx; si.status = status;
+        si.begin_block = bam_rd.range_begin_block(); si.end_block = bam_rd.range_end_block(); si.first = bam_rd.range_first(); si.over = bam_rd.range_over();
+        si.sample_id = rd.header().sample_id.c_str();
+        si.n_lane_names = (uint32_t)names.size(); si.lane_names = names.data(); si.lane_index = idx.data();
+        bqc_shard_result sr{};
+        const int verdict = shard->hook(shard->user, &si, &sr);
+        if (verdict == BQC_SHARD_FALLBACK) { // the split could not be verified: the whole file again, in this process alone
+            bqc_destroy(ctx);
+            g_pins.release_all();
+            return run_program(argc, argv, nullptr);
+        }
+        if (verdict != BQC_SHARD_WRITE) { bqc_destroy(ctx); g_pins.release_all(); return verdict == BQC_SHARD_DONE && !status ? 0 : 1; }
+        names.assign(sr.lane_names, sr.lane_names + sr.n_lane_names);
+        idx.assign(sr.lane_index, sr.lane_index + sr.n_lane_names);
+    }
     if (status) { bqc_destroy(ctx); return 1; }
     const bqc_counts* counts = nullptr;
     const auto t_loop_end = clk::now();
     if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
     const auto t_final = clk::now();
-    // writeOutput iterates laneNames (std::map: lexicographic), including IDs inserted by getLane
-    std::vector<const char*> names;
-    std::vector<uint32_t> idx;
-    for (auto& kv : rd.header().lane_names) { names.push_back(kv.first.c_str()); idx.push_back(kv.second); }
     bqc_header_info hi;
     hi.sample_id = rd.header().sample_id.c_str();
     hi.n_names = (uint32_t)names.size();
@@ -771,4 +820,13 @@ extern "C" int bqc_main(int argc, const char** argv)
     since_launch("done");
     if (fast_exit) { fflush(stdout); fflush(stderr); _exit(0); }
     return 0;
+}
+
+extern "C" int bqc_main(int argc, const char** argv) { return run_program(argc, argv, nullptr); }
+
+extern "C" int bqc_main_shard(int argc, const char** argv, uint32_t shard_index, uint32_t shard_count, bqc_shard_hook hook, void* user)
+{
+    if (!hook || shard_count == 0 || shard_index >= shard_count) return 1;
+    const ShardArgs sa{shard_index, shard_count, hook, user};
+    return run_program(argc, argv, &sa);
 }

@@ -30,10 +30,14 @@ def batch_to_cols(b):
 
 
 class BamFile:
-    def __init__(self, path):
+    def __init__(self, path, begin_hint=None, end_hint=None):
+        """The whole file, or (begin_hint / end_hint: compressed byte offsets) one shard of its record stream."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
-        rc = self.lib.bqc_bam_open(path.encode(), C.byref(self.h))
+        if begin_hint is None and end_hint is None:
+            rc = self.lib.bqc_bam_open(path.encode(), C.byref(self.h))
+        else:
+            rc = self.lib.bqc_bam_open_range(path.encode(), begin_hint or 0, 2 ** 64 - 1 if end_hint is None else end_hint, C.byref(self.h))
         if rc:
             msg = (self.lib.bqc_bam_error(self.h) or b"").decode()
             self.lib.bqc_bam_close(self.h)
@@ -44,6 +48,13 @@ class BamFile:
         self.ref_lens = [int(self.lib.bqc_bam_ref_len(self.h, i)) for i in range(n)]
         self.sample_id = (self.lib.bqc_bam_sample_id(self.h) or b"").decode()
         self.lane_count = int(self.lib.bqc_bam_lane_count(self.h))
+
+    @property
+    def range_info(self):
+        """(begin block, end block, first, over) of a shard: see bqc_bam_open_range."""
+        f = self.lib
+        return (int(f.bqc_bam_range_begin_block(self.h)), int(f.bqc_bam_range_end_block(self.h)), int(f.bqc_bam_range_first(self.h)),
+                int(f.bqc_bam_range_over(self.h)))
 
     def lanes(self):
         """[(name, index)] in output order (lexicographic by @RG ID)."""

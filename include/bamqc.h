@@ -99,6 +99,8 @@ typedef struct bqc_options {
                                   absent (TripletCounting.hpp:254-259); NULL = identity   */
     int32_t device;            /* HIP device ordinal                                     */
     bqc_sketch_options sketch;
+    uint32_t shard_tail;       /* 1: this context processes a shard of the record stream that does NOT begin with the
+                                  stream's first record (multi-GPU, see bqc_shard_resolve)              */
 } bqc_options;
 
 /* ---- input batch (host, structure of arrays) -------------------------------
@@ -224,6 +226,22 @@ int bqc_reset(bqc_ctx* ctx); /* zero every counter (keeps references) */
 /* End of stream: flush the two live coverage windows (bamqualcheck.cpp:447-453)
  * into the state vector.  Idempotent. */
 int bqc_flush(bqc_ctx* ctx);
+
+/* ---- shards of one record stream (multi-GPU) ------------------------------------------------------------------
+ * Every statistic of the path is a sum over reads except the coverage-depth histogram: its window state machine
+ * (OverallNumbers.hpp:84-110) depends on the reads before.  The stream may still be cut anywhere: a context created with
+ * shard_tail = 1 sets aside, per read group, its reads up to the first one at which the state machine resets WHATEVER its
+ * state (another chromosome, or more than 2000 positions away from the read before) and works normally from there on.
+ * When all its batches are in: bqc_shard_resolve(predecessor's exported state) runs the reads set aside from the state the
+ * predecessor ended in; bqc_shard_export yields this shard's own final state (its two live windows per read group are then
+ * the successor's to flush: the state vector of a shard that has exported holds complete windows only).  The last shard
+ * ends with bqc_flush / bqc_finalize as a whole stream does.  The exported block also carries the shard's first and last
+ * FASTA position of triplet-eligible reads (words 0 and 1 of the block, int32, -1: none), so that the forward-only FASTA
+ * scan (TripletCounting.hpp:254-259) can be checked across shards. */
+int bqc_shard_fasta_span(bqc_ctx* ctx, int32_t span[2]); /* first / last FASTA position of the triplet-eligible reads so far (-1: none); waits for the batches in flight */
+uint64_t bqc_shard_state_bytes(const bqc_ctx* ctx);
+int bqc_shard_resolve(bqc_ctx* ctx, const void* predecessor_state);
+int bqc_shard_export(bqc_ctx* ctx, void* state);
 
 /* Flat state vector (uint64 words, pure sums => additive across shards).
  * export/import take DEVICE pointers (e.g. a torch tensor's data_ptr) so a

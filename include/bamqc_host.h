@@ -53,6 +53,16 @@ int bqc_bam_write(const char* path, const bqc_batch* b, uint32_t n_refs, const c
 /* ---- BAM / FASTA input (replaces SeqAn BamStream / SequenceStream) --------- */
 typedef struct bqc_bam bqc_bam;
 int bqc_bam_open(const char* path, bqc_bam** out);  /* on failure *out still holds the message */
+/* One shard of the record stream (multi-GPU): the records that START in the BGZF blocks between the first block boundary at
+ * or behind the compressed offset begin_hint and the first one at or behind end_hint (0 / UINT64_MAX: the file's ends).  A
+ * shard in the middle of a file locates its first record by a plausibility test; shards verify each other afterwards:
+ * bqc_bam_range_over of a shard must equal bqc_bam_range_first of its successor (else: process the file unsharded). */
+int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out);
+uint64_t bqc_bam_range_begin_block(const bqc_bam* b);
+uint64_t bqc_bam_range_end_block(const bqc_bam* b);   /* UINT64_MAX: end of the file */
+uint64_t bqc_bam_range_first(const bqc_bam* b);       /* valid after the first bqc_bam_next */
+uint64_t bqc_bam_range_over(const bqc_bam* b);        /* valid after the last bqc_bam_next  */
+uint64_t bqc_file_size(const char* path);
 void bqc_bam_close(bqc_bam* b);
 const char* bqc_bam_error(const bqc_bam* b);
 uint32_t bqc_bam_n_refs(const bqc_bam* b);
@@ -88,6 +98,34 @@ int bqc_calib_read4(uint64_t bytes, int repeat);
 
 /* ---- the program: drop-in for the reference's main() (bamqualcheck.cpp:239-457) ---- */
 int bqc_main(int argc, const char** argv);
+
+/* The program as one of shard_count processes (one per GPU) that split the BAM file's byte stream between them: this process
+ * takes the records that start in its part of the compressed file (bqc_bam_open_range with hints i / n of the file size), its
+ * context is a shard_tail context unless it is the first.  After its record loop it calls `hook` once — also when it failed,
+ * so that all processes can agree — and the hook does what needs the other processes (launcher's business: torch.distributed
+ * over RCCL in bamqc_amd/distributed.py): verify the split (range_over of a shard == range_first of its successor), hand the
+ * coverage state down the chain (bqc_shard_export / bqc_shard_resolve), sum the state vectors onto the first process
+ * (bqc_state_export / _import) and merge the lane names.  The hook returns BQC_SHARD_WRITE (this process finalises and writes
+ * the output, with the lane names it put into `out`), BQC_SHARD_DONE (nothing more to do here), BQC_SHARD_FALLBACK (the split
+ * could not be verified: this process runs the whole file again, unsharded) or BQC_SHARD_FAIL (exit status 1). */
+typedef struct bqc_shard_info {
+    bqc_ctx* ctx;                     /* NULL when the program failed before it was created                  */
+    int32_t status;                   /* exit status so far: 0, or 1 after an error (message already printed) */
+    uint64_t begin_block, end_block;  /* bqc_bam_range_*                                                      */
+    uint64_t first, over;
+    const char* sample_id;
+    uint32_t n_lane_names;            /* lane names known to this process, incl. ids first seen on a read     */
+    const char* const* lane_names;
+    const uint32_t* lane_index;
+} bqc_shard_info;
+typedef struct bqc_shard_result {     /* filled by the hook for BQC_SHARD_WRITE: the merged lane names, output order */
+    uint32_t n_lane_names;
+    const char* const* lane_names;
+    const uint32_t* lane_index;
+} bqc_shard_result;
+enum { BQC_SHARD_WRITE = 0, BQC_SHARD_DONE = 1, BQC_SHARD_FALLBACK = 2, BQC_SHARD_FAIL = 3 };
+typedef int (*bqc_shard_hook)(void* user, const bqc_shard_info* info, bqc_shard_result* out);
+int bqc_main_shard(int argc, const char** argv, uint32_t shard_index, uint32_t shard_count, bqc_shard_hook hook, void* user);
 
 #ifdef __cplusplus
 }

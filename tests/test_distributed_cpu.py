@@ -68,3 +68,47 @@ def test_state_reduce_and_lane_union_world2_gloo():
         want = want + w  # numpy uint64 addition wraps mod 2^64
     assert np.array_equal(got, want)
     assert names == {"L1": 0, "L2": 1, "zz_unknown": 0}
+
+
+def test_split_and_fasta_order_checks():
+    ok = [(True, 0, 100, 0, 5), (True, 100, 200, 5, 7), (False, 200, 200, 0, 0), (True, 200, 2 ** 64 - 1, 7, 0)]
+    assert D.split_is_consistent(ok)
+    assert not D.split_is_consistent([(True, 0, 100, 0, 5), (True, 100, 200, 6, 7)])      # the successor guessed another record start
+    assert not D.split_is_consistent([(True, 0, 100, 0, 5), (True, 104, 200, 5, 7)])      # ... or another block boundary
+    assert D.fasta_order_is_consistent([(0, 3), (-1, -1), (3, 5)])
+    assert not D.fasta_order_is_consistent([(2, 3), (1, 5)])
+    assert D.merge_lane_names([{"L1": 0, "L2": 1}, {"L1": 0, "zz": 0}]) == {"L1": 0, "L2": 1, "zz": 0}
+
+
+def test_byte_range_shards_partition_the_record_stream(tmp_path):
+    """CPU: the shard reader.  For 2..16 shards of a BAM with two read groups every record is read by exactly one shard, in
+    order, and the chain check holds (a shard's last record ends where its successor's first begins); with
+    BQC_TEST_SHARD_SKEW (wrong guesses) the chain check fails — that is what sends the program to its unsharded fallback."""
+    import subprocess
+    from bamqc_amd import hostio
+    bam = str(tmp_path / "r.bam")
+    hostio.synth_stream(bam, None, 31, 400_000, ["chr1", "chr2"], [3_000_000, 1_000_000], n_lanes=2, level=1)
+    size = os.path.getsize(bam)
+    keys = ("flag", "pos", "rid", "l_seq", "nm", "seq", "qual", "cigar", "lane")
+
+    def read(f):
+        bl = list(f.batches(max_reads=77_777))
+        return {k: np.concatenate([b[k] for b in bl]) if bl else np.zeros(0) for k in keys}
+
+    whole = read(hostio.BamFile(bam))
+    assert len(whole["flag"]) == 400_000
+    for n in (2, 3, 7, 16):
+        hints = [size * r // n for r in range(n + 1)]
+        parts, infos = [], []
+        for r in range(n):
+            f = hostio.BamFile(bam, hints[r], None if r == n - 1 else hints[r + 1])
+            parts.append(read(f))
+            infos.append(f.range_info)
+        for k in keys:
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), (n, k)
+        assert D.split_is_consistent([(i[0] < min(i[1], size), i[0], i[1], i[2], i[3]) for i in infos])
+    code = ("import sys; sys.path.insert(0, %r)\nfrom bamqc_amd import hostio\nf = hostio.BamFile(%r, %d, None)\n"
+            "n = sum(len(b['flag']) for b in f.batches())\nprint(f.range_info[2])\n") % (ROOT, bam, size // 2)
+    good = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, BQC_TEST_SHARD_SKEW="1"))
+    assert good.returncode == 0 and bad.returncode == 0 and good.stdout != bad.stdout
