@@ -1,73 +1,167 @@
-// k_long.hip — per-base statistics for reads that do not fit the short-read fast path (longer than 256 bases;
-// every read when BQC_NO_FAST=1): wave per read, lane per base, any read length.
+// k_long.hip — per-base statistics for reads that do not fit the short-read fast path (longer than 255 bases; every read
+// when BQC_NO_FAST=1), any read length, on the register machinery of k_short (swar.h).
 //
-// The per-cycle histograms of a 10 kb read (2 mates x 6 counters x 10 000 cycles) do not fit in LDS, so the work is
-// tiled over sequencing cycles: workgroup (x, y) walks the chunks x, x + gridDim.x, ... and handles only the bases whose
-// cycle lies in [y * 1024, (y + 1) * 1024) — for a reverse-strand read that is the mirrored base range.  Each base
-// belongs to exactly one cycle tile, so the 8-mer windows starting there and its triplet evaluation are done by the
-// same workgroup.  LDS: 65 536 packed u8 8-mer counters (exact carry accounting on wrap, as in k_short), one cycle tile
-// of [2 mates][A C G T N qualsum][1024] and the 1 024 triplet counters.  Per-read sums (quality, N, GC) are combined
-// across cycle tiles through a small per-read scratch array and turned into histograms by k_long_finish.
+// A wave handles one ROW of one read at a time: 992 consecutive sequencing cycles, 16 per lane for the lanes 1..62; lane 0
+// holds the 16 cycles in front of the row and lane 63 the 16 behind it (needed for the 8-mer windows that run out of the row
+// and the flanking bases of a triplet; what those two lanes hold is counted by the neighbouring rows).  The per-cycle
+// histograms of a 10 kb read (2 mates x 6 counters x 10 000 cycles) do not fit in LDS, so workgroup (x, y) walks the
+// chunks x, x + gridDim.x, ... and handles row y of every read — for a reverse-strand read that is the mirrored base
+// range, loaded mirrored and turned in registers.  Per lane, as in k_short: 12 B of bases and 16 B of qualities straight
+// from global memory, four one-hot planes added into vertical 4-bit counters (spilled to the LDS cycle tile every 15 rows),
+// the 16 8-mer windows by funnel shifts into packed u8 LDS counters, triplets as nibble-flag SWAR.  The CIGAR is turned into
+// its match-like segments ONCE per row by the whole wave (operation k in lane k, prefix sums by DPP scans); every segment
+// that touches the row is one triplet pass with its own alignment offset.  Per-read sums (quality, N, GC) are combined
+// across rows through a small per-read scratch array and turned into histograms by k_long_finish.
 //
 // Reference: QualityCheck.hpp:122-166 (read_counts), OverallNumbers.hpp:137-168 (count8mers),
 // TripletCounting.hpp:195-236 (countBasesInTriplets).
 #include "kernels_common.h"
+#include "swar.h"
 
-#define KL_CT    1024
-#define KL_T8    0
-#define KL_CYC   16384
-#define KL_TRIP  (KL_CYC + 2 * 6 * KL_CT)
-#define KL_WORDS (KL_TRIP + 1024)
-
-__device__ __noinline__ void kl_t8_wrap(uint64_t* __restrict__ em, uint32_t h, uint32_t old)
-{
-    uint32_t f = h & 3u, bin = h; // every wrap of field f: +256 for its bin, and -1 for the next bin (the carry spilled into it)
-    while (f < 4u && ((old >> (8u * f)) & 0xFFu) == 0xFFu) {
-        gadd(em + bin, 256);
-        if (f < 3u) gadd(em + bin + 1, (uint64_t)-1ll);
-        ++f; ++bin;
-    }
-}
+#define KL_ROW    992                              // cycles a row owns (lanes 1..62)
+#define KL_T8     0                                // 16384 words: 65536 packed u8 8-mer counters (LDS address 0: see k_short)
+#define KL_TRIP   16384                            // [4 groups][256] bins c(j-1) r(j) c(j) r(j+1) in cycle space
+#define KL_CYC    (KL_TRIP + 1024)                 // [2 mates][A C G T other qual][1024]: cycle t of the row (lane w = 1 + t / 16) at (t % 16) * 64 + w
+#define KL_LUT    (KL_CYC + 2 * 6 * 1024)          // [17][8] masks for "the first n of the lane's cycles" (k_short's table)
+#define KL_WORDS  (KL_LUT + 17 * 8)
+#define KL_WAVES  16
 
 __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0)
 {
     const uint64_t lb = sl.lane_base(lane);
-    for (uint32_t i = threadIdx.x; i < 65536; i += blockDim.x) {
-        const uint32_t v = (lds[KL_T8 + (i >> 2)] >> (8u * (i & 3u))) & 0xFFu;
-        if (v) gadd(state + lb + sl.o_eightmer + i, v);
+    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) { // packed counters: byte b of dword i is bin 4 i + ((4 - b) & 3)
+        const uint32_t v = lds[KL_T8 + i];
+        if (!v) continue;
+        lds[KL_T8 + i] = 0;
+#pragma unroll
+        for (uint32_t b8 = 0; b8 < 4; ++b8)
+            if ((v >> (8u * b8)) & 0xFFu) gadd(state + lb + sl.o_eightmer + 4u * i + ((4u - b8) & 3u), (v >> (8u * b8)) & 0xFFu);
     }
-    block_sync();
-    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) lds[KL_T8 + i] = 0;
-    for (uint32_t i = threadIdx.x; i < 2 * 6 * KL_CT; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) { // bin = c(j-1) r(j) c(j) r(j+1) of group i >> 8, in cycle space
+        const uint32_t v = lds[KL_TRIP + i];
+        if (!v) continue;
+        lds[KL_TRIP + i] = 0;
+        const uint32_t grp = i >> 8, f3 = (i >> 6) & 3u, f2 = (i >> 4) & 3u, f1 = (i >> 2) & 3u, f0 = i & 3u;
+        uint32_t ctx, base;
+        if (grp < 2u) { ctx = (f3 << 4) | (f2 << 2) | f0; base = f1; }                               // forward: as is
+        else { ctx = ((3u - f0) << 4) | ((3u - f2) << 2) | (3u - f3); base = 3u - f1; }                // reverse: complement, mirrored
+        gadd(state + lb + sl.o_triplet + ctx * 16u + grp * 4u + base, v);
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * 6 * 1024; i += blockDim.x) {
         const uint32_t v = lds[KL_CYC + i];
         if (!v) continue;
         lds[KL_CYC + i] = 0;
-        const uint32_t m = i / (6 * KL_CT), c = (i / KL_CT) % 6, j = cyc0 + i % KL_CT;
+        const uint32_t m = i / (6 * 1024), c = (i / 1024) % 6, jj = i % 1024, w = jj % 64, t = jj / 64;
+        if (w == 0 || w == 63) continue; // (never written)
+        const uint32_t j = cyc0 + 16u * (w - 1u) + t;
         if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
-    }
-    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
-        const uint32_t v = lds[KL_TRIP + i];
-        if (v) { gadd(state + lb + sl.o_triplet + i, v); lds[KL_TRIP + i] = 0; }
     }
 }
 
-__global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                   uint32_t* __restrict__ err, uint32_t* __restrict__ rsum /* [n_reads][3] */)
+// Per-cycle accumulators of one lane (its 16 cycles), for the reads of ONE mate: 4-bit vertical counters per base plane
+// and packed 16-bit quality sums (k_short's CycAcc for two 8-cycle halves).
+struct KlAcc { uint32_t l1[2][4]; uint32_t qo[4], qe[4]; };
+__device__ __forceinline__ void kl_zero(KlAcc& A)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) A.l1[h][p] = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { A.qo[d] = 0; A.qe[d] = 0; }
+}
+__device__ __noinline__ void kl_spill_half(uint32_t a, uint32_t c, uint32_t g, uint32_t t, uint32_t* base /* tile + w + 64 * 8 * half */)
+{
+    const uint32_t v[4] = {a, c, g, t};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) atomicAdd(base + p * 1024 + 64 * (7 - n), (v[p] >> (4 * n)) & 15u);
+}
+__device__ __noinline__ void kl_qflush_pair(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t* base /* tile + 5 * 1024 + w + 64 * 8 * half */)
+{
+    const uint32_t vo[2] = {o0, o1}, ve[2] = {e0, e1};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        atomicAdd(base + 64 * (4 * d + 0), vo[d] >> 16);
+        atomicAdd(base + 64 * (4 * d + 1), ve[d] >> 16);
+        atomicAdd(base + 64 * (4 * d + 2), vo[d] & 0xFFFFu);
+        atomicAdd(base + 64 * (4 * d + 3), ve[d] & 0xFFFFu);
+    }
+}
+__device__ __forceinline__ void kl_spill(KlAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        kl_spill_half(A.l1[h][0], A.l1[h][1], A.l1[h][2], A.l1[h][3], lds + KL_CYC + mate * 6 * 1024 + w + 64 * 8 * h);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) A.l1[h][p] = 0;
+    }
+}
+__device__ __forceinline__ void kl_qflush(KlAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        kl_qflush_pair(A.qo[2 * h], A.qe[2 * h], A.qo[2 * h + 1], A.qe[2 * h + 1], lds + KL_CYC + (mate * 6 + 5) * 1024 + w + 64 * 8 * h);
+        A.qo[2 * h] = A.qe[2 * h] = A.qo[2 * h + 1] = A.qe[2 * h + 1] = 0;
+    }
+}
+__device__ __forceinline__ void kl_add(KlAcc& A, const Planes (&P)[2], const uint32_t (&Q)[4])
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { A.l1[h][0] += P[h].a; A.l1[h][1] += P[h].c; A.l1[h][2] += P[h].g; A.l1[h][3] += P[h].t; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { A.qe[d] += Q[d] & 0x00FF00FFu; A.qo[d] += __builtin_amdgcn_perm(0u, Q[d], 0x0C030C01u); }
+}
+__device__ __forceinline__ void kl_lut_nib(uint32_t (&d)[2], const uint32_t* e) { const uint2 v = *(const uint2*)e; d[0] = v.x; d[1] = v.y; }
+__device__ __forceinline__ void kl_lut_byte(uint32_t (&d)[4], const uint32_t* e) { const uint4 v = *(const uint4*)e; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+
+__global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
+                                                            uint32_t* __restrict__ err, uint32_t* __restrict__ rsum /* [n_reads][3] */)
 {
     extern __shared__ uint32_t lds[];
+    if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KL_T8 at LDS address 0)
+        if (threadIdx.x == 0) atomicOr(err, BQC_DEVERR_INTERNAL);
+        return;
+    }
+    const uint32_t cyc0 = blockIdx.y * KL_ROW;
+    if (cyc0 >= b.desc->long_max_len) return; // no read of the batch reaches this row (the grid is sized from an upper bound)
     for (uint32_t i = threadIdx.x; i < KL_WORDS; i += blockDim.x) lds[i] = 0;
     block_sync();
-    const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const uint32_t cyc0 = blockIdx.y * KL_CT;
+    const uint32_t M = 0x11111111u;
+    const uint32_t ln = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t w = ln;                         // lane w holds the cycles cyc0 - 16 + 16 w .. + 15
+    const bool own = w >= 1u && w <= 62u;          // ... and counts them, unless it is one of the two flank lanes
+    const uint32_t* LUT = lds + KL_LUT;
+    if (threadIdx.x <= 16u) { // masks for "the first n of the lane's cycles" (n nibbles from the top / n bytes from the top)
+        const uint32_t n = threadIdx.x;
+        uint32_t* e = lds + KL_LUT + 8u * n;
+        for (uint32_t h = 0; h < 2; ++h) {
+            const uint32_t v = n > 8u * h ? (n - 8u * h < 8u ? n - 8u * h : 8u) : 0u;
+            e[h] = v ? 0xFFFFFFFFu << (4u * (8u - v)) : 0u;
+        }
+        for (uint32_t d = 0; d < 4; ++d) {
+            const uint32_t v = n > 4u * d ? (n - 4u * d < 4u ? n - 4u * d : 4u) : 0u;
+            e[4 + d] = v ? 0xFFFFFFFFu << (8u * (4u - v)) : 0u;
+        }
+    }
+    block_sync();
+    KlAcc A0, A1; // per-cycle accumulators of this lane, first / second mate
+    kl_zero(A0); kl_zero(A1);
+    uint32_t n1[2] = {0, 0}, n2[2] = {0, 0}; // rows since the last counter spill / quality flush, per mate (wave-uniform)
     uint32_t cur_lane = 0xFFFFFFFFu;
+    const int32_t c_lo = (int32_t)cyc0 - 16 + 16 * (int32_t)w; // this lane's first cycle
+    const uint8_t* g_seq = b.seq;
+    const uint8_t* g_qual = b.qual;
     const uint32_t n_chunks = b.desc->n_chunks_slow;
-    if (cyc0 >= b.desc->long_max_len) return; // no read of the batch reaches this cycle tile (the grid is sized from an upper bound)
     for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane
         const bool done = ci >= n_chunks;
         Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
+                if (own) { kl_spill(A0, lds, 0, w); kl_qflush(A0, lds, 0, w); kl_spill(A1, lds, 1, w); kl_qflush(A1, lds, 1, w); }
+                n1[0] = n1[1] = n2[0] = n2[1] = 0;
                 block_sync();
                 kl_flush(lds, sl, state, cur_lane, cyc0);
                 block_sync();
@@ -76,122 +170,251 @@ __global__ __launch_bounds__(1024) void k_long(DevBatch b, StateLayout sl, uint6
         }
         if (done) break;
         uint64_t* em = state + sl.lane_base(cur_lane) + sl.o_eightmer;
-        for (uint32_t k = wave; k < ch.count; k += nwaves) {
+        for (uint32_t k = wave; k < ch.count; k += KL_WAVES) {
             const uint32_t r = b.perm[ch.first + k];
             const uint32_t flag = b.flag[r];
-            if ((flag & 0x900u) || !(flag & 0xC0u)) continue;  // skipped records; missing mate flag is raised by k_reads / host
+            if ((flag & 0x900u) || !(flag & 0xC0u)) continue;  // skipped records; a missing mate flag is raised by the pre-pass / k_reads
             const uint32_t L = b.l_seq[r];
-            if (L <= cyc0) continue;                              // no base of this read falls into this cycle tile
+            if (L <= cyc0) continue;                              // no base of this read falls into this row
             const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
-            const bool rc = flag & 0x10u, noqual = flag & BQC_FLAG_NO_QUAL;
-            const uint8_t* __restrict__ sq = b.seq + b.seq_off[r];
-            const uint8_t* __restrict__ ql = b.qual + b.qual_off[r];
-            const uint64_t lut_seq = rc ? LUT5_RC : LUT5_FWD;   // seq-orient code (after reverseComplement)
-            const uint32_t cyc1 = min(L, cyc0 + KL_CT);           // cycles [cyc0, cyc1)
-            const uint32_t lo_i = rc ? L - cyc1 : cyc0, hi_i = rc ? L - cyc0 : cyc1; // the bases with those cycles
-            // triplets (BAM orientation)
-            const uint32_t ncig = b.n_cigar[r];
-            const uint32_t* __restrict__ cg = b.cigar + b.cigar_off[r];
-            const int32_t rid = b.rid[r];
-            const bool trip = (flag & BQC_FLAG_TRIPLET) && L >= 3 && ncig > 0 && !noqual && rid >= 0 && (uint32_t)rid < refs.n_refs &&
-                              refs.ref[rid] != nullptr;
-            const uint8_t* __restrict__ ref = trip ? refs.ref[rid] : nullptr;
-            const int64_t reflen = trip ? (int64_t)refs.len[rid] : 0;
-            const int64_t pos = b.pos[r];
-            const uint32_t grp = (rc ? 2u : 0u) + mate; // fwd1st, fwd2nd, rev1st, rev2nd (TripletCounting.hpp:174-189)
-            const uint32_t n0 = trip ? cg[0] >> 4 : 0u;
-            // CIGAR cursor of the triplet walk (first op assumed match-like, :203), resumed from tile to tile
-            uint32_t w_kk = 1;
-            uint64_t w_rp = n0;
-            int64_t w_c = pos + (int64_t)n0;
-            uint32_t nN = 0, nGC = 0, qs = 0;
-            bool bad_q = false;
-
-            uint32_t by_nx = 0, q_nx = 0; // loads of the next 64 positions are issued one iteration ahead
-            if (lo_i + ln < L) { by_nx = sq[(lo_i + ln) >> 1]; if (!noqual) q_nx = ql[lo_i + ln]; }
-            for (uint32_t t0 = lo_i; t0 < hi_i; t0 += BQC_TILE_STRIDE) {
-                const uint32_t i = t0 + ln;
-                const bool in = i < L;
-                const uint32_t nib = in ? ((i & 1u) ? (by_nx & 15u) : (by_nx >> 4)) : 0u, q = in ? q_nx : 0u;
+            const bool rc = flag & 0x10u, noq = flag & BQC_FLAG_NO_QUAL;
+            // BAM index of the first base of lane 0's window, and of this lane's: forward reads run with the cycles, reverse reads
+            // against them (lane w then takes the mirrored window and turns it in registers)
+            const int32_t o0 = rc ? (int32_t)L - (int32_t)cyc0 : (int32_t)cyc0 - 16;
+            const int32_t sw = rc ? -(int32_t)w : (int32_t)w;
+            const uint32_t nv = c_lo < 0 ? 0u : (uint32_t)min(max((int32_t)L - c_lo, 0), 16); // valid cycles of this lane
+            const uint32_t nvq = noq ? 0u : nv;
+            uint32_t s[3], q[4];
+            {
+                // the window is loaded from one byte (odd o0: one nibble) earlier; lanes whose window lies outside the read load
+                // neighbouring data (the buffers are padded) and mask it
+                const int64_t so = (int64_t)b.seq_off[r] + ((o0 - 1) >> 1) + 8 * sw;
+                const int64_t qo = (int64_t)(noq ? 0u : b.qual_off[r]) + o0 + 16 * sw;
+                GVec<3>::ldu(s, g_seq + so);
+                GVec<4>::ldu(q, g_qual + qo);
+            }
+            uint32_t xm[2], qm[4];
+            kl_lut_nib(xm, LUT + 8u * nv);
+            kl_lut_byte(qm, LUT + 8u * nvq + 4u);
+            // ---------------- the lane's cycles: one-hot base nibbles X[h] = cycles 8h..8h+7 (first cycle in the top nibble) ...
+            uint32_t X[2];
+            {
+                const uint32_t sh = (o0 & 1) ? 28u : 24u; // the loaded bytes start 1 / 2 nibbles before the window
+                uint32_t bs[3], F[2];
+#pragma unroll
+                for (int h = 0; h < 3; ++h) bs[h] = bswap32(s[h]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) F[h] = alignbit(bs[h], bs[h + 1], sh);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) X[h] = (rc ? __brev(F[1 - h]) : F[h]) & xm[h]; // bit reversal = reversed order, complemented one-hot codes
+            }
+            // ... and qualities Q[d] = cycles 4d..4d+3, first cycle in the top byte
+            uint32_t Q[4];
+            {
+                const uint32_t sel = rc ? 0x07060504u : 0x00010203u;
+                uint32_t any = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { Q[d] = vperm(q[3 - d], q[d], sel) & qm[d]; any |= Q[d]; }
+                if (own && (any & 0x80808080u)) { // some Phred >= 128: check the 222 limit precisely
+                    bool bad = false;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+#pragma unroll
+                        for (int k8 = 0; k8 < 4; ++k8) bad |= ((Q[d] >> (8 * k8)) & 0xFFu) > 222u;
+                    if (bad) atomicOr(err, BQC_DEVERR_QUAL);
+                }
+            }
+            Planes P[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) P[h] = planes_of(X[h]);
+            // ---- per-cycle counters and the per-read sums (QualityCheck.hpp:122-166)
+            {
+                if (own) { if (mate) kl_add(A1, P, Q); else kl_add(A0, P, Q); }
+                if (++n1[mate] == 15u) { if (own) { if (mate) kl_spill(A1, lds, 1, w); else kl_spill(A0, lds, 0, w); } n1[mate] = 0; }
+                if (++n2[mate] == 255u) { if (own) { if (mate) kl_qflush(A1, lds, 1, w); else kl_qflush(A0, lds, 0, w); } n2[mate] = 0; }
+                uint32_t oany = 0, oth[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { oth[h] = own ? xm[h] & M & ~P[h].oh : 0u; oany |= oth[h]; }
+                if (oany) { // cycles holding anything but A/C/G/T (Dna5 'N' bin) are rare: counted directly
+                    uint32_t* ob = lds + KL_CYC + (mate * 6 + 4) * 1024 + w;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t o = oth[h];
+                        while (o) { const uint32_t bit = (uint32_t)__ffs((int)o) - 1u; o &= o - 1u; atomicAdd(ob + 64u * (8u * h + 7u - (bit >> 2)), 1u); }
+                    }
+                }
+                uint32_t v = 0, vn = 0, vgc = 0;
+                if (own) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) v = __builtin_amdgcn_sad_u8(Q[d], 0u, v);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { vn += (uint32_t)__popc(P[h].n); vgc += (uint32_t)__popc(P[h].c | P[h].g); }
+                }
+                const uint32_t s1 = wave_sum(v | (vn << 20)), s2 = wave_sum(vgc); // (<= 62 * 4080 < 2^20; <= 992)
+                if (ln == 0) {
+                    if (s1 & 0xFFFFFu) atomicAdd(&rsum[3 * (uint64_t)r], s1 & 0xFFFFFu);
+                    if (s1 >> 20) atomicAdd(&rsum[3 * (uint64_t)r + 1], s1 >> 20);
+                    if (s2) atomicAdd(&rsum[3 * (uint64_t)r + 2], s2);
+                }
+            }
+            // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
+            uint32_t cn[2], nb[3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cn[h] = (P[h].c | P[h].t) | ((P[h].g | P[h].t) << 1);
+                nb[h] = P[h].n | (~xm[h] & M); // literal N or outside the read: blocks 8-mer windows and triplet flanks
+            }
+            // ---- 8-mers: windows starting at the lane's cycles (OverallNumbers.hpp:137-168)
+            {
+                uint32_t S[2];
+                S[0] = vperm(squeeze2(cn[0]), squeeze2(cn[1]), 0x05040100u);
+                S[1] = lane_next(S[0]);
+                nb[2] = lane_next(nb[0]);
+                if (w == 63u) nb[2] = M;
+                uint32_t f[2];
                 {
-                    const uint32_t j = i + BQC_TILE_STRIDE;
-                    if (t0 + BQC_TILE_STRIDE < hi_i && j < L) { by_nx = sq[j >> 1]; if (!noqual) q_nx = ql[j]; }
+                    uint32_t sa[3], sb[3];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) sa[h] = nb[h] | alignbit(nb[h], nb[h + 1], 28);
+                    sa[2] = nb[2] | (nb[2] << 4);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) sb[h] = sa[h] | alignbit(sa[h], sa[h + 1], 24);
+                    sb[2] = sa[2] | (sa[2] << 8);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) f[h] = ~(sb[h] | alignbit(sb[h], sb[h + 1], 16)); // nibble LSB set <=> the window starting there is counted
                 }
-                const bool own = in && ln < BQC_TILE_STRIDE && i < hi_i;
-                const bool isN = nib == 15u;
-                { // read_counts (sequencing orientation)
-                    bad_q |= own && q > 222u;
-                    if (own) {
-                        const uint32_t c5 = lut5(lut_seq, nib);
-                        const uint32_t cyc = (rc ? (L - 1 - i) : i) - cyc0; // in [0, KL_CT)
-                        atomicAdd(&lds[KL_CYC + (mate * 6 + c5) * KL_CT + cyc], 1u);
-                        if (!noqual) atomicAdd(&lds[KL_CYC + (mate * 6 + 5) * KL_CT + cyc], q);
-                        qs += q;
+                if (own && nv > 0u) { // all 16 atomics are issued before the first returned value is looked at; a blocked window adds 0
+                    const uint32_t c32 = S[0], cx = S[1];
+                    uint32_t old[16];
+#pragma unroll
+                    for (int kw = 0; kw < 16; ++kw) {
+                        const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw);
+                        const uint32_t one = bfe(f[kw >> 3], 28 - 4 * (kw & 7), 1);
+                        old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    nN += (uint32_t)__popcll((unsigned long long)__ballot(own && isN));                 // literal 'N'
-                    nGC += (uint32_t)__popcll((unsigned long long)__ballot(own && (nib == 2u || nib == 4u))); // 'C' / 'G'
+                    uint32_t hot0 = 0, hot1 = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
+                    if (hot0 & 0x80808080u) t8_check<0>(em, c32, cx, f[0], old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
+                    if (hot1 & 0x80808080u) t8_check<8>(em, c32, cx, f[1], old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
                 }
-                { // count8mers; window starts at i (BAM orientation), bases already complemented for reverse reads
-                    const uint32_t c2 = lut5(lut_seq, nib) & 3u;
-                    const uint32_t v = in ? (c2 | (isN ? 0x10000u : 0u)) : 0x10000u; // past the end blocks the window
-                    const uint32_t p2 = (v << 2) | (uint32_t)__shfl_down((int)v, 1);
-                    const uint32_t p4 = (p2 << 4) | (uint32_t)__shfl_down((int)p2, 2);
-                    const uint32_t p8 = (p4 << 8) | (uint32_t)__shfl_down((int)p4, 4);
-                    if (own && (p8 >> 16) == 0) {
-                        uint32_t h = p8 & 0xFFFFu;
-                        if (rc) h = reverse8x2(h);
-                        const uint32_t old = atomicAdd(&lds[KL_T8 + (h >> 2)], 1u << (8u * (h & 3u)));
-                        if (((old >> (8u * (h & 3u))) & 0xFFu) == 0xFFu) kl_t8_wrap(em, h, old);
+            }
+            // ---- triplets in cycle space (TripletCounting.hpp:195-236): one pass per match-like CIGAR segment that touches the row
+            const uint32_t ncig = b.n_cigar[r];
+            const int32_t rid = b.rid[r];
+            const bool trip = (flag & BQC_FLAG_TRIPLET) && L >= 3 && ncig > 0 && !noq && rid >= 0 && (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
+            if (trip) {
+                const uint32_t* __restrict__ cg = b.cigar + b.cigar_off[r];
+                const uint32_t* rn = refs.refn[rid];
+                const int64_t reflen = (int64_t)refs.len[rid];
+                const int64_t nd8 = (reflen + 7) >> 3;
+                const int64_t pos0 = b.pos[r];
+                // the row's bases in BAM orientation (flank lanes included: their cycles are never evaluated, only looked at)
+                const int64_t I0 = rc ? (int64_t)L - cyc0 - KL_ROW : (int64_t)cyc0, I1 = I0 + KL_ROW;
+                const uint32_t rcm = rc ? 0x33333333u : 0u;
+                // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then moved next to each other in pairs
+                uint32_t qf[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t x = Q[d] & 0x7F7F7F7Fu;
+                    const uint32_t fq = (x + 0x6C6C6C6Cu) & ~(x + 0x21212121u) & ~Q[d];
+                    const uint32_t y = fq & 0x80808080u;
+                    qf[d] = y | (y << 4);
+                }
+                uint32_t ct[2]; // read codes as the triplet test sees them (BAM-orientation char -> Dna: non-ACGT -> A, i.e. 3 in the cycle space of a reverse read)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { const uint32_t x = ~P[h].oh & M; ct[h] = cn[h] | ((x | (x << 1)) & rcm); }
+                uint32_t* tbin = lds + KL_TRIP + ((rc ? 2u : 0u) + mate) * 256u; // fwd1st fwd2nd rev1st rev2nd
+                // One triplet pass: read positions [ia, ib) are aligned at chromPos = posv + i.
+                auto pass = [&](int64_t ia, int64_t ib, int64_t posv) {
+                    if (1 - posv > ia) ia = 1 - posv;                       // context posv+i-1 .. posv+i+1 inside the contig
+                    if (reflen - 1 - posv < ib) ib = reflen - 1 - posv;
+                    if (ib <= ia || ib <= I0 || ia >= I1) return;           // (wave-uniform)
+                    const int64_t ja64 = rc ? (int64_t)L - ib : ia, jb64 = rc ? (int64_t)L - ia : ib; // the same range in cycles
+                    const uint32_t ja = (uint32_t)min(max(ja64 - c_lo, (int64_t)0), (int64_t)16), jb = (uint32_t)min(max(jb64 - c_lo, (int64_t)0), (int64_t)16);
+                    // reference window of the lane as nibbles r1 r0 ~r0 ~r1, one nibble early (k_short: "nibble index minus one")
+                    const int64_t pp = posv + o0 + 15 + 16 * (int64_t)sw;  // (the table has 16 pad nibbles in front)
+                    const int64_t di = min(max(pp >> 3, (int64_t)0), nd8 + 1);
+                    uint32_t e[3];
+                    GVec<3>::lda(e, (const uint8_t*)(rn + di));
+                    uint32_t E[2];
+                    {
+                        const uint32_t sh = 28u - 4u * ((uint32_t)pp & 7u);
+                        uint32_t F[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) F[h] = alignbit(e[h], e[h + 1], sh);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) E[h] = rc ? __brev(F[1 - h]) : F[h];
                     }
-                }
-                if (trip) { // countBasesInTriplets (BAM orientation)
-                    const uint32_t nib_next = (uint32_t)__shfl_down((int)nib, 1);
-                    uint32_t nib_prev = (uint32_t)__shfl_up((int)nib, 1);
-                    if (ln == 0 && i > 0) { const uint32_t pb = sq[(i - 1) >> 1]; nib_prev = ((i - 1) & 1u) ? (pb & 15u) : (pb >> 4); }
-                    bool cand = own && i >= 1 && i + 1 < L;
-                    cand = cand && q >= 20u && q <= 94u; // (signed char)(q+33) >= '5'
-                    const uint32_t base = lut5(LUT5_FWD, nib);
-                    cand = cand && base != 4u && nib_prev != 15u && nib_next != 15u;
-                    int64_t cp = -1;
-                    bool found = false;
-                    if (n0 == 0 || i < n0) { cp = pos + (int64_t)i; found = true; }
-                    if (n0 != 0) { // advance the shared cursor past everything that ends before this tile, then scan the tile
-                        while (w_kk < ncig) {
-                            const uint32_t wv = cg[w_kk], op = wv & 15u, n = wv >> 4;
-                            const bool m = !(op == 2u || op == 3u || op == 5u || op == 6u || op == 4u || op == 1u);
-                            if (m && w_rp + n > (uint64_t)t0) break; // this match segment reaches into the tile
-                            if (op == 2u || op == 3u || op == 5u || op == 6u) w_c += n;    // D N H P
-                            else if (op == 4u || op == 1u) w_rp += n;                       // S I
-                            else { w_rp += n; w_c += n; }                                   // M = X entirely before the tile
-                            ++w_kk;
-                        }
-                        uint64_t rp = w_rp;
-                        int64_t c = w_c;
-                        for (uint32_t kk = w_kk; kk < ncig && rp <= (uint64_t)t0 + 63u; ++kk) {
-                            const uint32_t wv = cg[kk], op = wv & 15u, n = wv >> 4;
-                            if (op == 2u || op == 3u || op == 5u || op == 6u) c += n;
-                            else if (op == 4u || op == 1u) rp += n;
-                            else {
-                                if ((uint64_t)i >= rp && (uint64_t)i < rp + n) { cp = c + (int64_t)((uint64_t)i - rp); found = true; }
-                                rp += n; c += n;
+                    uint32_t I[4], bad[4]; // [1 .. 2] = this lane, [0] / [3] = the last / first dword of its neighbours
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        I[h + 1] = (E[h] & 0xCCCCCCCCu) | ct[h]; // nibble = [r c]
+                        const uint32_t t = I[h + 1] ^ (I[h + 1] >> 2);
+                        bad[h + 1] = ((t | (t >> 1)) & M) | nb[h]; // as a flank: mismatch or N
+                    }
+                    bad[0] = lane_prev(bad[2]); bad[3] = lane_next(bad[1]);
+                    I[0] = lane_prev(I[2]); I[3] = lane_next(I[1]);
+                    uint32_t pa[2], pb[2];
+                    kl_lut_nib(pa, LUT + 8u * ja);
+                    kl_lut_nib(pb, LUT + 8u * jb);
+                    uint32_t ok[2], okany = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t fl = alignbit(bad[h], bad[h + 1], 4) | alignbit(bad[h + 1], bad[h + 2], 28);
+                        ok[h] = own ? P[h].oh & ~fl & pb[h] & ~pa[h] & (vperm(qf[2 * h], qf[2 * h + 1], 0x07050301u) >> 3) : 0u; // nibble MSB -> LSB
+                        okany |= ok[h];
+                    }
+                    if (okany) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (!ok[h]) continue;
+                            const uint32_t SA = alignbit(I[h], I[h + 1], 6), SB = alignbit(I[h + 1], I[h + 2], 22);
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) { // bin = c(j-1) r(j) c(j) r(j+1): 8 contiguous bits of the [r c] stream
+                                const uint32_t ix = t < 6 ? bfe(SA, 20 - 4 * t, 8) : bfe(SB, 12 - 4 * (t - 6), 8);
+                                if (ok[h] & (1u << (28 - 4 * t))) atomicAdd(tbin + ix, 1u);
                             }
                         }
                     }
-                    cand = cand && found && cp >= 1 && cp + 1 < reflen;
-                    if (cand) {
-                        const uint32_t r0 = ref[cp - 1] & 3u, r1 = ref[cp] & 3u, r2 = ref[cp + 1] & 3u; // Dna5 -> Dna: N -> A
-                        if ((lut5(LUT5_FWD, nib_prev) & 3u) == r0 && (lut5(LUT5_FWD, nib_next) & 3u) == r2)
-                            atomicAdd(&lds[KL_TRIP + ((r0 << 4) | (r1 << 2) | r2) * 16 + grp * 4 + base], 1u);
+                };
+                const uint32_t n0 = cg[0] >> 4;
+                if (n0 == 0u) {
+                    // cigarCount starts at (size_t)-1: every position counts as inside the first operation (:203)
+                    if (pos0 > -(1 << 30) && pos0 < (1 << 30)) pass(1, (int64_t)L - 1, pos0);
+                } else {
+                    // The walk of :207-222, by the whole wave: operation kb + ln in lane ln.  Read / chromosome advance of every
+                    // operation (the first one is taken as match-like whatever it is), exclusive prefix sums by DPP scans (the
+                    // chromosome advance as two 16-bit halves: 64 operations of up to 2^28 positions), then the match-like ones that
+                    // reach into the row, one pass each.
+                    int64_t rp_c = 0, cp_c = 0; // positions in front of the current block of 64 operations
+                    for (uint32_t kb = 0; kb < ncig && rp_c < (int64_t)L; kb += 64u) {
+                        const uint32_t kk = kb + ln;
+                        const uint32_t wv = kk < ncig ? cg[kk] : 0u, op = wv & 15u, nn = wv >> 4;
+                        const bool live = kk < ncig;
+                        const bool ref_only = live && kk != 0u && (op == 2u || op == 3u || op == 5u || op == 6u); // D N H P
+                        const bool read_only = live && kk != 0u && (op == 4u || op == 1u);                         // S I
+                        const bool match = live && !ref_only && !read_only;
+                        const uint32_t ra = (live && !ref_only) ? min(nn, L + 1u) : 0u, ca = (live && !read_only) ? nn : 0u;
+                        const uint32_t ra_i = wave_scan_incl(ra), cl_i = wave_scan_incl(ca & 0xFFFFu), ch_i = wave_scan_incl(ca >> 16);
+                        const int64_t rp = rp_c + (ra_i - ra), cp = cp_c + (int64_t)(cl_i - (ca & 0xFFFFu)) + ((int64_t)(ch_i - (ca >> 16)) << 16);
+                        // segment of a match-like operation: read positions [ia, ib) at chromPos = posv + i
+                        const int64_t ia = rp > 1 ? rp : 1, ib = rp + nn < (int64_t)L - 1 ? rp + nn : (int64_t)L - 1;
+                        const int64_t posv = pos0 + cp - rp;
+                        const bool seg = match && rp < (int64_t)L && ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2 && ia < I1 && ib > I0;
+                        uint64_t todo = __ballot(seg);
+                        while (todo) {
+                            const int src = __ffsll((unsigned long long)todo) - 1;
+                            todo &= todo - 1;
+                            const int64_t u_ia = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ia, src);
+                            const int64_t u_ib = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ib, src);
+                            const int64_t u_pv = (int64_t)__builtin_amdgcn_readlane((int)(int32_t)posv, src);
+                            pass(u_ia, u_ib, u_pv);
+                        }
+                        rp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ra_i, 63);
+                        cp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cl_i, 63) + ((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ch_i, 63) << 16);
                     }
                 }
-            }
-            // per-read sums of this cycle tile -> scratch (combined over tiles by k_long_finish)
-            qs = wave_sum(qs);
-            if (__ballot(bad_q)) { if (ln == 0) atomicOr(err, BQC_DEVERR_QUAL); }
-            if (ln == 0) {
-                if (qs) atomicAdd(&rsum[3 * (uint64_t)r], qs);
-                if (nN) atomicAdd(&rsum[3 * (uint64_t)r + 1], nN);
-                if (nGC) atomicAdd(&rsum[3 * (uint64_t)r + 2], nGC);
             }
         }
     }
@@ -232,10 +455,10 @@ extern "C" void bqc_launch_long(const DevBatch& b, const StateLayout& sl, uint64
                                 uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, hipStream_t s)
 {
     if (n_chunks_ub == 0) return;
-    const uint32_t tiles = max_len_ub ? (max_len_ub + KL_CT - 1) / KL_CT : 1u;
-    uint32_t gx = n_cu / tiles ? n_cu / tiles : 1u; // one workgroup per CU (116 KB of LDS each): gx * tiles <= n_cu where possible
+    const uint32_t rows = max_len_ub ? (max_len_ub + KL_ROW - 1) / KL_ROW : 1u;
+    uint32_t gx = n_cu / rows ? n_cu / rows : 1u; // one workgroup per CU (119 KB of LDS each): gx * rows <= n_cu where possible
     if (gx > n_chunks_ub) gx = n_chunks_ub;
-    hipLaunchKernelGGL(k_long, dim3(gx, tiles), dim3(1024), KL_WORDS * 4, s, b, sl, state, refs, err, rsum);
+    hipLaunchKernelGGL(k_long, dim3(gx, rows), dim3(KL_WAVES * 64), KL_WORDS * 4, s, b, sl, state, refs, err, rsum);
     const uint32_t g2 = n_chunks_ub < n_cu * 8 ? n_chunks_ub : n_cu * 8;
     hipLaunchKernelGGL(k_long_finish, dim3(g2), dim3(256), 0, s, b, sl, state, rsum);
 }
