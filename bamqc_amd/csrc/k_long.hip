@@ -24,7 +24,7 @@
 #define KL_CYC    (KL_TRIP + 1024)                 // [2 mates][A C G T other qual][1024]: cycle t of the row (lane w = 1 + t / 16) at (t % 16) * 64 + w
 #define KL_LUT    (KL_CYC + 2 * 6 * 1024)          // [17][8] masks for "the first n of the lane's cycles" (k_short's table)
 #define KL_WORDS  (KL_LUT + 17 * 8)
-#define KL_WAVES  16
+#define KL_WAVES  12
 
 __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0)
 {
@@ -170,12 +170,51 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
         }
         if (done) break;
         uint64_t* em = state + sl.lane_base(cur_lane) + sl.o_eightmer;
+        // The reads of the chunk this wave takes (k = wave, wave + 16, ...) go through a two-deep pipeline, so that a row's
+        // instructions run while the next rows' loads are in flight: the columns of read k + 16 and the bases / qualities of its
+        // row are requested before read k is computed (a wave alone would wait for four dependent round trips per row).
+        struct Meta { uint32_t r, flag, L, so, qo, co, ncig; int32_t rid, pos; };
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }; // the same in every lane: keep it in a scalar register
+        auto load_meta = [&](uint32_t kk) {
+            Meta m{0, 0x900u, 0, 0, 0, 0, 0, -1, 0};
+            if (kk < ch.count) {
+                m.r = uni(b.perm[ch.first + kk]);
+                m.flag = b.flag[m.r]; m.L = b.l_seq[m.r]; m.so = b.seq_off[m.r]; m.qo = b.qual_off[m.r];
+                m.co = b.cigar_off[m.r]; m.ncig = b.n_cigar[m.r]; m.rid = b.rid[m.r]; m.pos = b.pos[m.r];
+            }
+            return m;
+        };
+        auto settle = [&](Meta& m) { // (called when the values are about to be used: the loads have had an iteration to arrive)
+            m.flag = uni(m.flag); m.L = uni(m.L); m.so = uni(m.so); m.qo = uni(m.qo); m.co = uni(m.co); m.ncig = uni(m.ncig);
+            m.rid = (int32_t)uni((uint32_t)m.rid); m.pos = (int32_t)uni((uint32_t)m.pos);
+        };
+        // bases / qualities of the row, and the read's first 64 CIGAR operations (operation ln in lane ln)
+        auto load_row = [&](const Meta& m, uint32_t (&s)[3], uint32_t (&q)[4], uint32_t& cw) { // (rows that are skipped load harmlessly from the buffers' start)
+            const bool rc_ = m.flag & 0x10u;
+            const bool use = !(m.flag & 0x900u) && (m.flag & 0xC0u) && m.L > cyc0;
+            const int32_t o0_ = rc_ ? (int32_t)m.L - (int32_t)cyc0 : (int32_t)cyc0 - 16;
+            const int32_t sw_ = rc_ ? -(int32_t)w : (int32_t)w;
+            // the window is loaded from one byte (odd o0: one nibble) earlier; lanes whose window lies outside the read load
+            // neighbouring data (the buffers are padded) and mask it
+            const int64_t so = use ? (int64_t)m.so + ((o0_ - 1) >> 1) + 8 * sw_ : 0;
+            const int64_t qo = use ? (int64_t)((m.flag & BQC_FLAG_NO_QUAL) ? 0u : m.qo) + o0_ + 16 * sw_ : 0;
+            GVec<3>::ldu(s, g_seq + so);
+            GVec<4>::ldu(q, g_qual + qo);
+            cw = use && ln < m.ncig ? b.cigar[(uint64_t)m.co + ln] : 0u;
+        };
+        Meta cur_m = load_meta(wave), nxt_m = load_meta(wave + KL_WAVES);
+        uint32_t s[3], q[4], cw, s_n[3], q_n[4], cw_n;
+        settle(cur_m);
+        load_row(cur_m, s, q, cw);
         for (uint32_t k = wave; k < ch.count; k += KL_WAVES) {
-            const uint32_t r = b.perm[ch.first + k];
-            const uint32_t flag = b.flag[r];
-            if ((flag & 0x900u) || !(flag & 0xC0u)) continue;  // skipped records; a missing mate flag is raised by the pre-pass / k_reads
-            const uint32_t L = b.l_seq[r];
-            if (L <= cyc0) continue;                              // no base of this read falls into this row
+            settle(nxt_m);                                  // (its columns were requested one iteration ago)
+            load_row(nxt_m, s_n, q_n, cw_n);
+            const Meta nn_m = load_meta(k + 2 * KL_WAVES);
+            {
+            const uint32_t r = cur_m.r, flag = cur_m.flag;
+            if ((flag & 0x900u) || !(flag & 0xC0u)) goto next_read;  // skipped records; a missing mate flag is raised by the pre-pass / k_reads
+            const uint32_t L = cur_m.L;
+            if (L <= cyc0) goto next_read;                            // no base of this read falls into this row
             const uint32_t mate = (flag & 0x40u) ? 0u : 1u;
             const bool rc = flag & 0x10u, noq = flag & BQC_FLAG_NO_QUAL;
             // BAM index of the first base of lane 0's window, and of this lane's: forward reads run with the cycles, reverse reads
@@ -184,15 +223,6 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             const int32_t sw = rc ? -(int32_t)w : (int32_t)w;
             const uint32_t nv = c_lo < 0 ? 0u : (uint32_t)min(max((int32_t)L - c_lo, 0), 16); // valid cycles of this lane
             const uint32_t nvq = noq ? 0u : nv;
-            uint32_t s[3], q[4];
-            {
-                // the window is loaded from one byte (odd o0: one nibble) earlier; lanes whose window lies outside the read load
-                // neighbouring data (the buffers are padded) and mask it
-                const int64_t so = (int64_t)b.seq_off[r] + ((o0 - 1) >> 1) + 8 * sw;
-                const int64_t qo = (int64_t)(noq ? 0u : b.qual_off[r]) + o0 + 16 * sw;
-                GVec<3>::ldu(s, g_seq + so);
-                GVec<4>::ldu(q, g_qual + qo);
-            }
             uint32_t xm[2], qm[4];
             kl_lut_nib(xm, LUT + 8u * nv);
             kl_lut_byte(qm, LUT + 8u * nvq + 4u);
@@ -300,15 +330,15 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 }
             }
             // ---- triplets in cycle space (TripletCounting.hpp:195-236): one pass per match-like CIGAR segment that touches the row
-            const uint32_t ncig = b.n_cigar[r];
-            const int32_t rid = b.rid[r];
+            const uint32_t ncig = cur_m.ncig;
+            const int32_t rid = cur_m.rid;
             const bool trip = (flag & BQC_FLAG_TRIPLET) && L >= 3 && ncig > 0 && !noq && rid >= 0 && (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
             if (trip) {
-                const uint32_t* __restrict__ cg = b.cigar + b.cigar_off[r];
+                const uint32_t* __restrict__ cg = b.cigar + cur_m.co;
                 const uint32_t* rn = refs.refn[rid];
                 const int64_t reflen = (int64_t)refs.len[rid];
                 const int64_t nd8 = (reflen + 7) >> 3;
-                const int64_t pos0 = b.pos[r];
+                const int64_t pos0 = cur_m.pos;
                 // the row's bases in BAM orientation (flank lanes included: their cycles are never evaluated, only looked at)
                 const int64_t I0 = rc ? (int64_t)L - cyc0 - KL_ROW : (int64_t)cyc0, I1 = I0 + KL_ROW;
                 const uint32_t rcm = rc ? 0x33333333u : 0u;
@@ -325,21 +355,25 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { const uint32_t x = ~P[h].oh & M; ct[h] = cn[h] | ((x | (x << 1)) & rcm); }
                 uint32_t* tbin = lds + KL_TRIP + ((rc ? 2u : 0u) + mate) * 256u; // fwd1st fwd2nd rev1st rev2nd
-                // One triplet pass: read positions [ia, ib) are aligned at chromPos = posv + i.
-                auto pass = [&](int64_t ia, int64_t ib, int64_t posv) {
+                // One triplet pass, in two steps so that the reference windows of several segments are in flight together.
+                // Read positions [ia, ib) are aligned at chromPos = posv + i.  issue: clip to the contig and the row, request the lane's
+                // reference window (nibbles r1 r0 ~r0 ~r1, one nibble early: k_short's "nibble index minus one"); false: nothing to do.
+                auto issue = [&](int64_t& ia, int64_t& ib, int64_t posv, uint32_t (&e)[3]) {
                     if (1 - posv > ia) ia = 1 - posv;                       // context posv+i-1 .. posv+i+1 inside the contig
                     if (reflen - 1 - posv < ib) ib = reflen - 1 - posv;
-                    if (ib <= ia || ib <= I0 || ia >= I1) return;           // (wave-uniform)
-                    const int64_t ja64 = rc ? (int64_t)L - ib : ia, jb64 = rc ? (int64_t)L - ia : ib; // the same range in cycles
-                    const uint32_t ja = (uint32_t)min(max(ja64 - c_lo, (int64_t)0), (int64_t)16), jb = (uint32_t)min(max(jb64 - c_lo, (int64_t)0), (int64_t)16);
-                    // reference window of the lane as nibbles r1 r0 ~r0 ~r1, one nibble early (k_short: "nibble index minus one")
+                    if (ib <= ia || ib <= I0 || ia >= I1) return false;     // (wave-uniform)
                     const int64_t pp = posv + o0 + 15 + 16 * (int64_t)sw;  // (the table has 16 pad nibbles in front)
                     const int64_t di = min(max(pp >> 3, (int64_t)0), nd8 + 1);
-                    uint32_t e[3];
                     GVec<3>::lda(e, (const uint8_t*)(rn + di));
+                    return true;
+                };
+                auto eval = [&](int64_t ia, int64_t ib, int64_t posv, const uint32_t (&e)[3]) {
+                    const int32_t ja32 = (int32_t)(rc ? (int64_t)L - ib : ia), jb32 = (int32_t)(rc ? (int64_t)L - ia : ib); // the same range in cycles
+                    const uint32_t ja = (uint32_t)min(max(ja32 - c_lo, 0), 16), jb = (uint32_t)min(max(jb32 - c_lo, 0), 16);
+                    const uint32_t pp = (uint32_t)((int32_t)posv + o0 + 15 + 16 * sw);
                     uint32_t E[2];
                     {
-                        const uint32_t sh = 28u - 4u * ((uint32_t)pp & 7u);
+                        const uint32_t sh = 28u - 4u * (pp & 7u);
                         uint32_t F[2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) F[h] = alignbit(e[h], e[h + 1], sh);
@@ -378,19 +412,23 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                         }
                     }
                 };
-                const uint32_t n0 = cg[0] >> 4;
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw) >> 4; // operation 0 sits in lane 0
                 if (n0 == 0u) {
                     // cigarCount starts at (size_t)-1: every position counts as inside the first operation (:203)
-                    if (pos0 > -(1 << 30) && pos0 < (1 << 30)) pass(1, (int64_t)L - 1, pos0);
+                    if (pos0 > -(1 << 30) && pos0 < (1 << 30)) {
+                        int64_t ia = 1, ib = (int64_t)L - 1;
+                        uint32_t e[3];
+                        if (issue(ia, ib, pos0, e)) eval(ia, ib, pos0, e);
+                    }
                 } else {
                     // The walk of :207-222, by the whole wave: operation kb + ln in lane ln.  Read / chromosome advance of every
                     // operation (the first one is taken as match-like whatever it is), exclusive prefix sums by DPP scans (the
                     // chromosome advance as two 16-bit halves: 64 operations of up to 2^28 positions), then the match-like ones that
-                    // reach into the row, one pass each.
+                    // reach into the row: one pass each, their reference windows requested three at a time.
                     int64_t rp_c = 0, cp_c = 0; // positions in front of the current block of 64 operations
                     for (uint32_t kb = 0; kb < ncig && rp_c < (int64_t)L; kb += 64u) {
                         const uint32_t kk = kb + ln;
-                        const uint32_t wv = kk < ncig ? cg[kk] : 0u, op = wv & 15u, nn = wv >> 4;
+                        const uint32_t wv = kb == 0u ? cw : (kk < ncig ? cg[kk] : 0u), op = wv & 15u, nn = wv >> 4;
                         const bool live = kk < ncig;
                         const bool ref_only = live && kk != 0u && (op == 2u || op == 3u || op == 5u || op == 6u); // D N H P
                         const bool read_only = live && kk != 0u && (op == 4u || op == 1u);                         // S I
@@ -404,18 +442,39 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                         const bool seg = match && rp < (int64_t)L && ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2 && ia < I1 && ib > I0;
                         uint64_t todo = __ballot(seg);
                         while (todo) {
-                            const int src = __ffsll((unsigned long long)todo) - 1;
-                            todo &= todo - 1;
-                            const int64_t u_ia = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ia, src);
-                            const int64_t u_ib = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ib, src);
-                            const int64_t u_pv = (int64_t)__builtin_amdgcn_readlane((int)(int32_t)posv, src);
-                            pass(u_ia, u_ib, u_pv);
+                            int64_t A[3], B[3], V[3];
+                            uint32_t e[3][3];
+                            bool go[3];
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) {
+                                go[g] = todo != 0;
+                                if (go[g]) {
+                                    const int src = __ffsll((unsigned long long)todo) - 1;
+                                    todo &= todo - 1;
+                                    A[g] = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ia, src);
+                                    B[g] = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ib, src);
+                                    V[g] = (int64_t)__builtin_amdgcn_readlane((int)(int32_t)posv, src);
+                                    go[g] = issue(A[g], B[g], V[g], e[g]);
+                                }
+                            }
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                                if (go[g]) eval(A[g], B[g], V[g], e[g]);
                         }
                         rp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ra_i, 63);
                         cp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cl_i, 63) + ((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ch_i, 63) << 16);
                     }
                 }
             }
+            }
+        next_read:
+            cur_m = nxt_m;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) s[h] = s_n[h];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) q[d] = q_n[d];
+            cw = cw_n;
+            nxt_m = nn_m;
         }
     }
 }
