@@ -24,13 +24,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
+                    help="config2 (default, the configuration the metric is quoted on): 10 M x 150 bp PE; config5: long reads, 10 kb, indel / soft-clip heavy")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (default: 10 M for config2, 100 k for config5)")
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--sketch", action="store_true", help="steps include the k-mer sketch of the program's default options (-k 32 -q 17)")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the BAM file -> bin/bamqualcheck -> .bamqc leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra device timings (default options with sketch; long reads)")
     ap.add_argument("--e2e-prefix", type=int, default=1_000_000, help="reads of the e2e input checked against the oracle")
     args = ap.parse_args()
+    long_reads = args.workload == "config5"
+    if args.reads is None:
+        args.reads = 100_000 if long_reads else 10_000_000
+    if args.read_len is None:
+        args.read_len = 10_000 if long_reads else 150
 
     import torch
     import torch.distributed as dist
@@ -53,17 +62,21 @@ def main():
     dev = torch.device("cuda", local)
 
     from bamqc_amd import Aggregator, _abi, synth
-    lens = [25_000_000] * 4
-    seed = 1002  # 1000 + config index
+    lens = [250_000_000] if long_reads else [25_000_000] * 4
+    seed = 1005 if long_reads else 1002  # 1000 + config index
+    opts = dict(n_refs=len(lens), n_lanes=1, isize=30_000 if long_reads else 1000, max_read_len=max(1024, 16_384 if long_reads else 0, args.read_len),
+                hist_cap=16_384 if long_reads else 4096, device=local)
+    if args.sketch:
+        opts.update(klist=(32,), qlist=(17,))
     t0 = time.time()
     refs = [synth.reference(seed, i, n) for i, n in enumerate(lens)]
-    cols = synth.batch(seed, args.reads, lens, refs, read_len=args.read_len, first_read_index=rank * args.reads)
+    cols = synth.batch(seed, args.reads, lens, refs, read_len=args.read_len, first_read_index=rank * args.reads, isize=opts["isize"], long_reads=long_reads)
     t_gen = time.time() - t0
-    agg = Aggregator(n_refs=4, n_lanes=1, isize=1000, max_read_len=max(1024, args.read_len), device=local)
+    agg = Aggregator(**opts)
     for i, r in enumerate(refs):
         agg.set_reference(i, r)
     t0 = time.time()
-    db = agg.upload(cols)  # host pre-pass + H2D; inputs are resident in HBM before the timed region
+    db = agg.upload(cols)  # host pass + H2D; inputs are resident in HBM before the timed region
     t_up = time.time() - t0
     abytes = db.algorithmic_bytes
     agg.set_timing(True)
@@ -82,7 +95,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        agg.process(db)
+        agg.process(db)  # device pre-pass (k_prep) + hot kernels over the resident batch
         for k, v in agg.last_timing().items():  # HIP events on the library's own stream
             kt.setdefault(k, []).append(v)
     agg.sync()
@@ -106,7 +119,6 @@ def main():
             total = agg.finalize()
             assert int(total[0]["scalars"][4]) == (args.reads * args.steps * world - int(total[0]["scalars"][0]) - int(total[0]["scalars"][3])) % 2 ** 32
 
-    out = None
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         value = world * args.reads * args.steps / elapsed
@@ -114,12 +126,14 @@ def main():
         dom = max(kavg, key=kavg.get)
         peak = 8000.0  # GB/s HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
         ach = abytes / (kavg[dom] * 1e-3) / 1e9
-        # HBM traffic per launch comes from rocprofv3 PMC passes (profiles/collect_r1.sh): counters cannot be read in-process
-        traffic = None
+        # HBM traffic per launch and the issue-slot counters come from rocprofv3 PMC passes (profiles/collect_r2.sh): counters
+        # cannot be read in-process
+        traffic, limiter = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if tj.get("kernel") == dom and args.reads == 10_000_000 and args.read_len == 150:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            if tj.get("kernel") == dom and args.reads == 10_000_000 and args.read_len == 150 and not args.sketch:
                 traffic = tj["traffic_bytes_per_launch"]
+                limiter = tj.get("limiter")
         except Exception:
             pass
         out = {
@@ -127,31 +141,84 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32/u64 integer", "data": "synthetic",
-            "config": {"workload": "config 2: %d reads x %d bp PE per GPU, 4 x 25 Mb contigs, 1 lane, device-resident SoA batch"
-                                   % (args.reads, args.read_len),
+            "config": {"workload": ("config 5: %d reads x %d bases per GPU, 20-60 CIGAR operations, 1 x 250 Mb contig, -i 30000" if long_reads else
+                                    "config 2: %d reads x %d bp PE per GPU, 4 x 25 Mb contigs, 1 lane") % (args.reads, args.read_len) +
+                                   ", device-resident raw SoA batch; a step = device pre-pass + hot kernels" + (" + k-mer sketch k32 q17" if args.sketch else ""),
                        "reads_per_gpu_per_step": args.reads, "parallelism": "shard by read batch; RCCL reduce of state vector at end"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
                          "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": traffic,
-                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated)" if traffic else None,
+                         "traffic_source": "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated)" if traffic else None,
+                         "limiter": limiter or {"what": "valu+lds issue (integer SWAR and LDS atomics per base), not HBM: see DESIGN.md 4.2"},
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_read": abytes / args.reads,
                          "kernel_ms": kavg},
-            "host": {"generate_s": t_gen, "prepass_upload_s": t_up,
+            "host": {"generate_s": t_gen, "host_pass_upload_s": t_up,
                      "pcie_inclusive_reads_per_s": args.reads / (t_up + ms_step * 1e-3)},
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not long_reads:
             out["cpu_baseline"] = cpu_baseline(cols, refs, args, agg, db)
-        if world == 1 and not args.no_e2e:
-            db.free()
-            agg.close()
-            del cols
+        db.free()
+        agg.close()
+        del cols
+        if world == 1 and not args.no_extra and not long_reads and not args.sketch:
+            out["extra"] = extra_timings(refs)
+        if world == 1 and not args.no_e2e and not long_reads:
             out["e2e"] = e2e_leg(args, refs, out.get("cpu_baseline", {}).get("value"))
-            print(json.dumps(out), flush=True)
-            return
         print(json.dumps(out), flush=True)
-    db.free()
-    agg.close()
+    else:
+        db.free()
+        agg.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_timings(refs):
+    """Device times that the headline step leaves out, measured the same way (resident batch, HIP events): the program's
+    default options (k-mer sketch k32 q17) on config-2-shaped reads, and the long-read kernels on config-5-shaped reads."""
+    from bamqc_amd import Aggregator, synth
+    out = {}
+    n = 4_000_000
+    lens = [25_000_000] * 4
+    cols = synth.batch(1002, n, lens, refs)
+    agg = Aggregator(n_refs=4, klist=(32,), qlist=(17,))
+    for i, r in enumerate(refs):
+        agg.set_reference(i, r)
+    db = agg.upload(cols)
+    agg.set_timing(True)
+    kt = {}
+    for it in range(8):
+        agg.process(db)
+        if it >= 3:
+            for k, v in agg.last_timing().items():
+                kt.setdefault(k, []).append(v)
+    agg.sync()
+    per10 = {k: float(np.mean(v)) * 1e7 / n for k, v in kt.items()}
+    out["default_options_with_sketch"] = {"reads": n, "ms_per_10M_reads": per10, "total_ms_per_10M_reads": sum(per10.values()),
+                                          "what": "config-2-shaped reads, -k 32 -q 17 (k_sketch is VALU bound: two 128-bit rolling hashes per base)"}
+    db.free()
+    agg.close()
+    del cols
+    n, L = 50_000, 10_000
+    ref5 = [synth.reference(1005, 0, 250_000_000)]
+    cols = synth.batch(1005, n, [250_000_000], ref5, read_len=L, isize=30_000, long_reads=True)
+    agg = Aggregator(n_refs=1, isize=30_000, max_read_len=16_384, hist_cap=16_384)
+    agg.set_reference(0, ref5[0])
+    db = agg.upload(cols)
+    ab = db.algorithmic_bytes
+    agg.set_timing(True)
+    kt = {}
+    for it in range(8):
+        agg.process(db)
+        if it >= 3:
+            for k, v in agg.last_timing().items():
+                kt.setdefault(k, []).append(v)
+    agg.sync()
+    km = {k: float(np.mean(v)) for k, v in kt.items()}
+    out["long_reads_config5_shape"] = {"reads": n, "read_len": L, "kernel_ms": km, "algorithmic_bytes": ab,
+                                       "k_long_GBps": ab / km["k_long"] / 1e6, "k_long_frac_of_8TBps": ab / km["k_long"] / 1e6 / 8000.0,
+                                       "reads_per_s": n / (sum(km.values()) * 1e-3)}
+    db.free()
+    agg.close()
+    return out
 
 
 def cpu_baseline(cols, refs, args, agg, db):
