@@ -124,6 +124,13 @@ def make_batch(cols):
     keep = {}
     b = Batch()
     b.n_reads = n
+    if n:  # BQC_FLAG_NO_QUAL is the decoder's to set (include/bamqc.h): column dicts built by hand get it here
+        l = np.asarray(cols["l_seq"], np.int64)
+        qo = np.cumsum(l) - l
+        q = np.asarray(cols["qual"], np.uint8)
+        noq = (l > 0) & (q[np.minimum(qo, max(len(q) - 1, 0))] == 0xFF) if len(q) else np.zeros(n, bool)
+        if noq.any():
+            cols = dict(cols, flag=np.asarray(cols["flag"], np.uint16) | (noq.astype(np.uint16) << 15))
     for name, dt, pt in _BATCH_COLS:
         a = np.ascontiguousarray(cols[name], dtype=dt)
         if a.size == 0:

@@ -147,7 +147,7 @@ __device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, in
 // One read's share of the pre-pass.  Everything but the payload offsets and the cross-read part of the FASTA scan.
 struct ReadIn { uint32_t L, nc, flag, lane, mapq; int32_t rid, pos, as; CovEntry ce; };
 struct ReadOut { uint32_t flag, cls, tgt1; CovEntry ce; };
-__device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& refs, uint32_t i, const ReadIn& in, uint32_t qo, uint32_t co, bool offsets_ok)
+__device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& refs, uint32_t i, const ReadIn& in, uint32_t co, bool offsets_ok)
 {
     ReadOut o;
     uint32_t flag = in.flag & (0x0FFFu | BQC_FLAG_MATE_MAIN | BQC_FLAG_NO_QUAL);
@@ -156,7 +156,8 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
     o.tgt1 = 0;
     if (L > a.max_read_len) err_key(a.err, i, 1);
     else if (lane >= a.n_lanes) err_key(a.err, i, 2);
-    if (offsets_ok && L > 0 && a.qual[qo] == 0xFF) flag |= BQC_FLAG_NO_QUAL;
+    // (BQC_FLAG_NO_QUAL — quality block starting with 0xFF, SURVEY U1 — is a fact of the record's decoding and arrives with the
+    // flag column: probing qual[qo] here cost one 128-byte line per read, more than every other byte this kernel reads)
     const uint32_t* cg = a.cigar + co;
     if (!offsets_ok) nc = 0; // (the batch fails: k_prep_scan)
     const bool fast = !a.no_fast && L <= BQC_FAST_MAXLEN;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_prep_reads(PrepArgs a, DevRefs r
         if ((uint32_t)j >= nlive) continue;
         const unsigned long long so = bs + ls[j], qo = bq + lq[j], co = bc + lc[j];
         const bool ok = so + (in[j].L + 1) / 2 <= 0xFFFFFFFFull && qo + in[j].L <= 0xFFFFFFFFull && co + in[j].nc <= 0xFFFFFFFFull;
-        out[j] = prep_one(a, refs, i0 + j, in[j], (uint32_t)qo, (uint32_t)co, ok);
+        out[j] = prep_one(a, refs, i0 + j, in[j], (uint32_t)co, ok);
         if (out[j].tgt1) { local_bad[j] = out[j].tgt1 < tmax; tmax = max(tmax, out[j].tgt1); tmin = min(tmin, out[j].tgt1); }
         const uint32_t cl = out[j].cls >> 8;
         if (cl == 2u) maxlong = max(maxlong, in[j].L); else maxfast = max(maxfast, in[j].L);

@@ -3,6 +3,7 @@
 // record loop's body replaced by the GPU aggregation of include/bamqc.h.  Also: FASTA loader
 // (replaces Genome / SequenceStream, src/TripletCounting.hpp:60-104) and the C wrappers of
 // include/bamqc_host.h around the BAM reader.
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -810,15 +811,32 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
     // the program proper (tools/bamqualcheck.cpp sets BQC_FAST_EXIT) leaves without the static destructors of the HIP runtime:
     // the output file is complete and closed, the process is about to end anyway
     const bool fast_exit = !rc && getenv("BQC_FAST_EXIT") && getenv("BQC_FAST_EXIT")[0] == '1';
-    bqc_destroy(ctx);        // (device memory and page locks are released explicitly: left to the kernel's process teardown they cost 0.2 s)
-    g_pins.release_all();
+    const char* done_fd = fast_exit ? getenv("BQC_DONE_FD") : nullptr; // the front end (tools/bamqualcheck.cpp) waits for a byte there
+    auto teardown = [&]() { // (device memory and page locks are released explicitly: left to the kernel's process teardown they cost 0.2 s more)
+        bqc_destroy(ctx);
+        g_pins.release_all();
+    };
+    if (!done_fd) teardown();
     if (timing)
-        fprintf(stderr, "[timing] phases: FASTA %.2f s (context created meanwhile in %.2f s), context %.2f s, references %.2f s, record loop %.2f s, finalize %.2f s, write %.2f s, destroy %.2f s\n",
+        fprintf(stderr, "[timing] phases: FASTA %.2f s (context created meanwhile in %.2f s), context %.2f s, references %.2f s, record loop %.2f s, finalize %.2f s, write %.2f s, destroy %.2f s%s\n",
                 secs(t_begin, t_fasta), t_create_s, secs(t_fasta, t_create), secs(t_create, t_setup), secs(t_setup, t_loop_end), secs(t_loop_end, t_final), secs(t_final, t_write),
-                secs(t_write, clk::now()));
+                secs(t_write, clk::now()), done_fd ? " (the context is released after the run has been reported complete)" : "");
     if (rc) { fprintf(stderr, "ERROR: Could not write output file %s\n", opt.outputFile.c_str()); return 1; }
     since_launch("done");
-    if (fast_exit) { fflush(stdout); fflush(stderr); _exit(0); }
+    if (fast_exit) { // the program proper leaves without the static destructors of the HIP runtime: the output file is complete and closed
+        fflush(stdout); fflush(stderr);
+        if (done_fd) { // nothing is printed from here on: the run is reported complete, then this process cleans up on its own
+            const int fd = atoi(done_fd);
+            const unsigned char st = 0;
+            if (write(fd, &st, 1) == 1) {
+                close(fd);
+                const int nul = open("/dev/null", O_WRONLY);
+                if (nul >= 0) { dup2(nul, 1); dup2(nul, 2); }
+            }
+            teardown();
+        }
+        _exit(0);
+    }
     return 0;
 }
 

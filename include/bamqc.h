@@ -65,7 +65,9 @@ enum {
 
 /* Host annotations carried in the spare high bits of the BAM flag column.     */
 #define BQC_FLAG_MATE_MAIN 0x1000u /* rNextId is a main chromosome (bamqualcheck.cpp:404) */
-#define BQC_FLAG_NO_QUAL   0x8000u /* quality block starts with 0xFF => record.qual empty */
+#define BQC_FLAG_NO_QUAL   0x8000u /* the record has no qualities (BAM: quality block starts with 0xFF; SAM: QUAL is "*")
+                                      => record.qual empty.  Set by whoever decodes the record: the library does not look
+                                      at the quality bytes to find out (it would cost a cache line per read).             */
 
 #define BQC_NM_ABSENT (-1)
 #define BQC_AS_ABSENT INT32_MIN
