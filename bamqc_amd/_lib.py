@@ -62,6 +62,8 @@ _SIGNATURES = {
     "bqc_bam_range_first": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_over": (C.c_uint64, [C.c_void_p]),
     "bqc_file_size": (C.c_uint64, [C.c_char_p]),
+    "bqc_gpu_inflate_device": (None, [C.c_int]),
+    "bqc_gpu_inflated_blocks": (C.c_uint64, []),
     "bqc_bam_close": (None, [C.c_void_p]),
     "bqc_bam_error": (C.c_char_p, [C.c_void_p]),
     "bqc_bam_n_refs": (C.c_uint32, [C.c_void_p]),

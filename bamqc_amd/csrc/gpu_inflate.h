@@ -1,0 +1,21 @@
+// gpu_inflate.h — raw DEFLATE of BGZF blocks on the GPU (gpu_inflate.hip); used by the BGZF reader (host/bgzf.cpp).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+struct GiBlock {      // one BGZF block's deflate stream
+    uint64_t coff;    // offset of the deflate data in the compressed buffer
+    uint64_t uoff;    // offset of its output in the uncompressed buffer
+    uint32_t csize;   // bytes of deflate data
+    uint32_t usize;   // ISIZE: the bytes it must inflate to
+};
+
+enum { GI_ERR_DATA = 1, GI_ERR_TRUNC = 2, GI_ERR_SIZE = 4 };
+
+struct GpuInflater;
+extern "C" {
+GpuInflater* bqc_gpu_inflater_create(int device); // nullptr: no such device
+void bqc_gpu_inflater_destroy(GpuInflater* g);
+// 0: every block inflated to exactly its usize bytes; > 0: GI_ERR_* bits (corrupt data); < 0: the GPU could not be used
+int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_bytes, const GiBlock* blocks, size_t n_blocks, uint8_t* out, size_t out_bytes);
+}

@@ -1,0 +1,388 @@
+// gpu_inflate.hip — raw DEFLATE (RFC 1951) of BGZF blocks on the GPU (row N2: the host's inflate is the wall of every whole-file
+// run — 0.5 core-seconds per million reads on the CPU, against 0.25 ms of kernels).  OPT-IN (BQC_GPU_INFLATE=1 /
+// bqc_gpu_inflate_device): correct and tested against zlib, not yet faster end to end than 16 host threads — see "Measured".
+//
+// BGZF blocks are independent, at most 64 KiB, and carry their uncompressed size: ONE LANE PER BLOCK.  The state a decoder needs is
+// kept in LDS, shared out lane by lane (2.1 KB each): 9-bit root table of the literal/length code and 7-bit root table of the
+// distance code as u16 entries `symbol << 4 | code bits`, and for the longer codes (rare: the frequent symbols have short codes)
+// the canonical code itself — counts per length and the symbols in code order — decoded bit by bit.  Every per-lane array is laid
+// out [entry][lane], so that the lanes' accesses to the same entry fall on different banks.  The bit buffer is refilled one word
+// ahead (the load's latency hides behind the symbols decoded meanwhile); literals are byte stores; a match is copied 32 / 16 / 4 / 1
+// bytes at a time from the lane's own output (requests of one wave to one address are served in order); length and distance
+// bases are computed, not looked up.  What comes out is checked on the host against the block's CRC-32 like the CPU decoder's output.
+//
+// Measured (MI355X, a run of 12.9 K blocks = 268 MB -> 844 MB, BGZF level 1): kernel 46 / 40 / 35 / 32 ms with 64 / 32 / 16 / 8
+// lanes per workgroup, H2D 5 ms, D2H into pageable memory 35 ms; the host decoder (16 threads) needs 80 ms for the same bytes.  A
+// lane spends ~1.5 us per symbol whatever the workgroup width: that is one round trip to HBM per iteration of the wave — a
+// match reads the lane's own output up to 32 KiB back, 13 K lanes x 64 KiB of output are far more than the L2 holds, and in every
+// iteration some lane of the wave has a match.  The kernel is latency-bound and its time does not depend on the number of blocks
+// until the card is full (76 lanes per CU with these tables: 19 K blocks); with the inflated bytes going back to the host the copy
+// costs more than the kernel, and runs this large (a fresh 0.9 GB buffer each) cost the host more in page faults than the inflate
+// they save: the program's record loop is slower with it (0.63 s against 0.34 s for 10 M reads).  What makes it pay is the next
+// step, not a faster copy: walk and decode the records on the card too (the inflated bytes never return), with the tables cut to
+// the canonical arrays alone (356 B per lane: 460 blocks per CU in flight, a whole 10 M-read file in one launch).
+//
+// Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
+// incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input
+// beyond the block are errors — a corrupt file is reported, never followed out of bounds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "kernels_common.h"
+#include "gpu_inflate.h"
+
+// per-lane arrays, u16 units, laid out [entry][lane]
+#define GI_LIT_ROOT 9
+#define GI_DIST_ROOT 7
+#define GI_O_LIT   0                          // [512] root table literal/length
+#define GI_O_DIST  (GI_O_LIT + 512)           // [128] root table distance
+#define GI_O_LCNT  (GI_O_DIST + 128)          // [16] codes per length, literal/length
+#define GI_O_DCNT  (GI_O_LCNT + 16)           // [16] ... distance
+#define GI_O_LSYM  (GI_O_DCNT + 16)           // [288] literal/length symbols in canonical order
+#define GI_O_DSYM  (GI_O_LSYM + 288)          // [32] distance symbols in canonical order
+#define GI_O_LENS  (GI_O_DSYM + 32)           // [80] code lengths while the tables are built, four per u16 (320 nibbles)
+#define GI_U16     (GI_O_LENS + 80)           // 1072 u16 = 2144 B per lane, 137 216 B per wave
+#define GI_AT(k) ((k) * NL) // NL: lanes (= blocks) per workgroup
+
+__constant__ uint8_t c_pre_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+typedef uint32_t __attribute__((aligned(1))) gi_u32_u;
+typedef uint32_t gi_u32x4 __attribute__((ext_vector_type(4)));
+typedef gi_u32x4 __attribute__((aligned(1))) gi_u32x4_u;
+
+namespace {
+struct Bits { // bit reader over [in, end): the word behind the buffered ones is always on its way (its latency hides behind the
+              // symbols decoded meanwhile); loads are clamped to `lim` (inside the compressed buffer), what was consumed is checked at the end
+    const uint8_t* in;  // address of the prefetched word `nw`
+    const uint8_t* lim; // last address a word may be loaded from
+    uint64_t bb;
+    uint32_t bc;
+    uint32_t nw;
+    __device__ __forceinline__ void start(const uint8_t* p, const uint8_t* end)
+    {
+        lim = end + 4; // (the buffer holds at least 64 bytes behind the last block)
+        bb = *(const gi_u32_u*)p | (uint64_t)(*(const gi_u32_u*)(p + 4)) << 32;
+        bc = 64;
+        in = p + 8;
+        nw = *(const gi_u32_u*)(in < lim ? in : lim);
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (bc <= 32u) {
+            bb |= (uint64_t)nw << bc;
+            bc += 32u;
+            in += 4;
+            nw = *(const gi_u32_u*)(in < lim ? in : lim);
+        }
+    }
+    __device__ __forceinline__ const uint8_t* byte_pos() const { return in - (bc >> 3); } // address of the first unconsumed byte (bc a multiple of 8)
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+template <int NL> __device__ __forceinline__ uint32_t lens_get(const uint16_t* L, uint32_t i) { const uint32_t v = L[GI_AT(GI_O_LENS + (i >> 2))]; return (v >> (4 * (i & 3))) & 15u; }
+template <int NL> __device__ __forceinline__ void lens_set(uint16_t* L, uint32_t i, uint32_t len)
+{
+    uint16_t& w = L[GI_AT(GI_O_LENS + (i >> 2))];
+    w = (uint16_t)((w & ~(15u << (4 * (i & 3)))) | (len << (4 * (i & 3))));
+}
+
+// Canonical code of `n` symbols whose lengths are lens[first .. first + n): counts per length, symbols in canonical order, root
+// table of `root` bits (entry = symbol << 4 | length; 0 = longer than the root or unused).  zlib's acceptance rules.
+template <int NL> __device__ bool build_code(uint16_t* L, uint32_t first, uint32_t n, uint32_t o_cnt, uint32_t o_sym, uint32_t o_root, uint32_t root)
+{
+    uint32_t count[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t len = lens_get<NL>(L, first + s);
+#pragma unroll
+        for (int l = 0; l < 16; ++l) count[l] += len == (uint32_t)l; // (a register array cannot be indexed by a variable)
+    }
+    int left = 1;
+    uint32_t maxl = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        left = (left << 1) - (int)count[l];
+        if (left < 0) return false;
+        if (count[l]) maxl = (uint32_t)l;
+    }
+    if (left > 0 && maxl > 1) return false;
+    uint32_t offs[16];
+    offs[0] = 0; offs[1] = 0;
+#pragma unroll
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) L[GI_AT(o_cnt + l)] = (uint16_t)(l ? count[l] : 0);
+    for (uint32_t k = 0; k < (1u << root); ++k) L[GI_AT(o_root + k)] = 0;
+    // symbols in canonical order; the code of a symbol = first code of its length + its rank among the symbols of that length
+    uint32_t next_code[16];
+    {
+        uint32_t code = 0;
+        next_code[0] = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; ++l) { code = (code + count[l - 1]) << 1; next_code[l] = code; }
+    }
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t len = lens_get<NL>(L, first + s);
+        if (!len) continue;
+        uint32_t pos = 0, code = 0;
+#pragma unroll
+        for (int l = 1; l <= 15; ++l)
+            if (len == (uint32_t)l) { pos = offs[l]++; code = next_code[l]++; }
+        L[GI_AT(o_sym + pos)] = (uint16_t)s;
+        if (len <= root) {
+            const uint32_t r = __brev(code) >> (32u - len); // the code's bits in stream order (LSB first)
+            const uint16_t e = (uint16_t)((s << 4) | len);
+            for (uint32_t i = r; i < (1u << root); i += 1u << len) L[GI_AT(o_root + i)] = e;
+        }
+    }
+    return true;
+}
+
+// one symbol of a canonical code: root table first, bit by bit for the longer codes; returns the symbol or 0xFFFF (invalid)
+template <int NL> __device__ __forceinline__ uint32_t decode_sym(const uint16_t* L, Bits& B, uint32_t o_cnt, uint32_t o_sym, uint32_t o_root, uint32_t root)
+{
+    const uint32_t e = L[GI_AT(o_root + B.peek(root))];
+    if (e & 15u) { B.drop(e & 15u); return e >> 4; }
+    // longer than the root (or an unused pattern): puff-style walk over the lengths
+    uint32_t code = 0, firstc = 0, index = 0;
+    uint32_t bits = (uint32_t)B.bb;
+    for (uint32_t len = 1; len <= 15; ++len) {
+        code |= bits & 1u;
+        bits >>= 1;
+        const uint32_t cnt = L[GI_AT(o_cnt + len)];
+        if (code - firstc < cnt) { B.drop(len); return L[GI_AT(o_sym + index + (code - firstc))]; }
+        index += cnt;
+        firstc = (firstc + cnt) << 1;
+        code <<= 1;
+    }
+    return 0xFFFFu;
+}
+} // namespace
+
+template <int NL> __global__ __launch_bounds__(NL) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+{
+    extern __shared__ uint16_t lds16[];
+    const uint32_t bi = blockIdx.x * NL + threadIdx.x;
+    if (bi >= n_blocks) return;
+    uint16_t* L = lds16 + threadIdx.x;
+    const GiBlock blk = blocks[bi];
+    const uint8_t* const c0 = comp + blk.coff;
+    const uint8_t* const cend = c0 + blk.csize;
+    Bits B;
+    B.start(c0, cend);
+    uint8_t* const o0 = out + blk.uoff;
+    const uint32_t usize = blk.usize;
+    uint32_t o = 0;
+    uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
+    for (;;) {
+        B.refill();
+        if (B.byte_pos() > cend) { st = GI_ERR_TRUNC; break; } // (also what ends a run of empty blocks decoded from beyond the stream)
+        const uint32_t bfinal = B.take(1), btype = B.take(2);
+        if (btype == 0u) { // stored: back to a byte boundary, LEN / NLEN, raw bytes
+            B.drop(B.bc & 7u);
+            const uint8_t* p = B.byte_pos();
+            if (p + 4 > cend) { st = GI_ERR_TRUNC; break; }
+            const uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) { st = GI_ERR_DATA; break; }
+            p += 4;
+            if (p + len > cend || o + len > usize) { st = GI_ERR_TRUNC; break; }
+            uint32_t k = 0;
+            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + o + k) = *(const gi_u32_u*)(p + k);
+            for (; k < len; ++k) o0[o + k] = p[k];
+            o += len;
+            B.start(p + len, cend);
+            if (bfinal) break;
+            continue;
+        }
+        if (btype == 3u) { st = GI_ERR_DATA; break; }
+        uint32_t hlit = 288, hdist = 30;
+        if (btype == 1u) { // fixed code
+            for (uint32_t i = 0; i < 80; ++i) L[GI_AT(GI_O_LENS + i)] = 0;
+            for (uint32_t i = 0; i < 144; ++i) lens_set<NL>(L, i, 8);
+            for (uint32_t i = 144; i < 256; ++i) lens_set<NL>(L, i, 9);
+            for (uint32_t i = 256; i < 280; ++i) lens_set<NL>(L, i, 7);
+            for (uint32_t i = 280; i < 288; ++i) lens_set<NL>(L, i, 8);
+            for (uint32_t i = 0; i < 30; ++i) lens_set<NL>(L, 288 + i, 5);
+            hdist = 30; // (the two unused 5-bit codes decode to symbols 30 / 31: rejected below)
+            for (uint32_t i = 30; i < 32; ++i) lens_set<NL>(L, 288 + i, 5);
+            hdist = 32;
+        } else {
+            B.refill();
+            hlit = B.take(5) + 257u; hdist = B.take(5) + 1u;
+            const uint32_t hclen = B.take(4) + 4u;
+            if (hlit > 286u || hdist > 30u) { st = GI_ERR_DATA; break; }
+            // code-length code: 19 symbols of up to 7 bits; its table lives where the literal/length root table will be
+            for (uint32_t i = 0; i < 80; ++i) L[GI_AT(GI_O_LENS + i)] = 0;
+            for (uint32_t i = 0; i < hclen; ++i) { B.refill(); lens_set<NL>(L, 300u + c_pre_order[i], B.take(3)); } // (precode lengths parked at 300..318)
+            if (!build_code<NL>(L, 300, 19, GI_O_LCNT, GI_O_LSYM, GI_O_LIT, 7)) { st = GI_ERR_DATA; break; }
+            {   // an incomplete precode is an error (zlib)
+                int left = 1;
+                for (uint32_t l = 1; l <= 15; ++l) left = (left << 1) - (int)L[GI_AT(GI_O_LCNT + l)];
+                if (left > 0) { st = GI_ERR_DATA; break; }
+            }
+            for (uint32_t i = 0; i < 19; ++i) lens_set<NL>(L, 300u + i, 0);
+            const uint32_t total = hlit + hdist;
+            uint32_t i = 0, prev = 0;
+            bool bad = false;
+            while (i < total) {
+                B.refill();
+                const uint32_t sym = decode_sym<NL>(L, B, GI_O_LCNT, GI_O_LSYM, GI_O_LIT, 7);
+                if (sym < 16u) { lens_set<NL>(L, i++, sym); prev = sym; continue; }
+                uint32_t rep, val = 0;
+                if (sym == 16u) { if (i == 0) { bad = true; break; } val = prev; rep = 3u + B.take(2); }
+                else if (sym == 17u) rep = 3u + B.take(3);
+                else if (sym == 18u) rep = 11u + B.take(7);
+                else { bad = true; break; }
+                if (i + rep > total) { bad = true; break; }
+                for (uint32_t k = 0; k < rep; ++k) lens_set<NL>(L, i + k, val);
+                i += rep;
+                prev = val;
+            }
+            if (bad) { st = GI_ERR_DATA; break; }
+            if (lens_get<NL>(L, 256) == 0u) { st = GI_ERR_DATA; break; } // no end-of-block code
+            // the distance lengths follow the literal/length lengths directly: move them to 288.. (from the back: the ranges may overlap)
+            for (uint32_t k = hdist; k-- > 0;) lens_set<NL>(L, 288u + k, lens_get<NL>(L, hlit + k));
+            for (uint32_t k = hlit; k < 288u; ++k) lens_set<NL>(L, k, 0);
+        }
+        if (!build_code<NL>(L, 288, hdist, GI_O_DCNT, GI_O_DSYM, GI_O_DIST, GI_DIST_ROOT)) { st = GI_ERR_DATA; break; }
+        if (!build_code<NL>(L, 0, hlit, GI_O_LCNT, GI_O_LSYM, GI_O_LIT, GI_LIT_ROOT)) { st = GI_ERR_DATA; break; }
+        // ---- symbols of one block
+        for (;;) {
+            B.refill();
+            const uint32_t sym = decode_sym<NL>(L, B, GI_O_LCNT, GI_O_LSYM, GI_O_LIT, GI_LIT_ROOT);
+            if (sym < 256u) {
+                if (o >= usize) { st = GI_ERR_SIZE; break; }
+                o0[o++] = (uint8_t)sym;
+                continue;
+            }
+            if (sym == 256u) break;
+            if (sym > 285u) { st = GI_ERR_DATA; break; }
+            B.refill();
+            // length symbols 257..264: 3..10; 265..284 in groups of four with 1..5 extra bits; 285: 258 (RFC 1951, 3.2.5) — computed, a
+            // table would be a memory access in the middle of the chain
+            const uint32_t ls = sym - 257u, le = ls < 8u || ls == 28u ? 0u : (ls - 4u) >> 2;
+            const uint32_t length = (ls < 8u ? ls + 3u : ls == 28u ? 258u : ((4u + (ls & 3u)) << le) + 3u) + B.take(le);
+            B.refill();
+            const uint32_t ds = decode_sym<NL>(L, B, GI_O_DCNT, GI_O_DSYM, GI_O_DIST, GI_DIST_ROOT);
+            if (ds > 29u) { st = GI_ERR_DATA; break; }
+            B.refill();
+            const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u; // distance symbols 0..3: 1..4; then pairs with 1..13 extra bits
+            const uint32_t dist = (ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u) + B.take(de);
+            if (dist > o || o + length > usize) { st = dist > o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
+            uint8_t* dst = o0 + o;
+            const uint8_t* src = dst - dist;
+            o += length;
+            if (dist >= 32u && o + 32u <= usize) { // 32 bytes at a time (both loads first); the overshoot stays inside this block's output
+                for (uint32_t k = 0; k < length; k += 32u) {
+                    const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
+                    *(gi_u32x4_u*)(dst + k) = a;
+                    *(gi_u32x4_u*)(dst + k + 16) = b;
+                }
+            } else if (dist >= 16u && o + 16u <= usize) {
+                for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
+            } else if (dist >= 4u && o + 4u <= usize) {
+                for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
+            } else {
+                for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
+            }
+        }
+        if (st || bfinal) break;
+    }
+    if (!st && o != usize) st = GI_ERR_SIZE;
+    if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
+    if (st) atomicOr(status, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: one object per reader thread
+// ---------------------------------------------------------------------------------------------------
+struct GpuInflater {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_comp = nullptr; size_t comp_cap = 0;
+    uint8_t* d_out = nullptr; size_t out_cap = 0;
+    GiBlock* d_blocks = nullptr; size_t blocks_cap = 0;
+    uint32_t* d_status = nullptr;
+};
+
+extern "C" GpuInflater* bqc_gpu_inflater_create(int device)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    auto* g = new GpuInflater();
+    g->device = device;
+    if (e == hipSuccess && (device < 0 || device >= ndev)) e = hipErrorInvalidDevice;
+    if (e == hipSuccess) e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&g->d_status, 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate<64>), hipFuncAttributeMaxDynamicSharedMemorySize, GI_U16 * 2 * 64);
+    if (e != hipSuccess) {
+        if (getenv("BQC_GI_TIMING")) fprintf(stderr, "[gpu inflate] not available: %s\n", hipGetErrorString(e));
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+        (void)hipFree(g->d_status);
+        delete g;
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" void bqc_gpu_inflater_destroy(GpuInflater* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    (void)hipFree(g->d_comp); (void)hipFree(g->d_out); (void)hipFree(g->d_blocks); (void)hipFree(g->d_status);
+    delete g;
+}
+
+// Inflates n_blocks blocks: comp[blocks[i].coff, + csize) -> out[blocks[i].uoff, + usize).  0 = every block inflated to exactly its
+// usize bytes; > 0: GI_ERR_* bits of the blocks that did not (corrupt data); < 0: the GPU could not be used (fall back to the CPU).
+extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_bytes, const GiBlock* blocks, size_t n_blocks, uint8_t* out, size_t out_bytes)
+{
+    if (!g) return -1;
+    if (!n_blocks) return 0;
+    if (hipSetDevice(g->device) != hipSuccess) return -1;
+    auto grow = [](auto*& p, size_t& cap, size_t need) {
+        if (cap >= need) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = need + need / 4 + 4096;
+        if (hipMalloc((void**)&p, c) != hipSuccess) { p = nullptr; return false; }
+        cap = c;
+        return true;
+    };
+    size_t bcap_bytes = g->blocks_cap * sizeof(GiBlock);
+    if (!grow(g->d_comp, g->comp_cap, comp_bytes + 64) || !grow(g->d_out, g->out_cap, out_bytes + 64)) return -1;
+    if (!grow(g->d_blocks, bcap_bytes, n_blocks * sizeof(GiBlock))) return -1;
+    g->blocks_cap = bcap_bytes / sizeof(GiBlock);
+    static const bool timing = getenv("BQC_GI_TIMING") != nullptr;
+    hipEvent_t ev[4] = {};
+    if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
+    if (timing) (void)hipEventRecord(ev[0], g->stream);
+    if (hipMemsetAsync(g->d_status, 0, 4, g->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(g->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(g->d_blocks, blocks, n_blocks * sizeof(GiBlock), hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
+    static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 16;
+    if (timing) (void)hipEventRecord(ev[1], g->stream);
+#define GI_LAUNCH(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((uint32_t)((n_blocks + NL - 1) / NL)), dim3(NL), GI_U16 * 2 * NL, g->stream, g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, g->d_status)
+    if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 8) GI_LAUNCH(8); else GI_LAUNCH(16);
+    uint32_t st = 0;
+    if (timing) (void)hipEventRecord(ev[2], g->stream);
+    if (hipMemcpyAsync(out, g->d_out, out_bytes, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&st, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
+    if (timing) (void)hipEventRecord(ev[3], g->stream);
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return -1;
+    if (timing) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+        fprintf(stderr, "[gpu inflate] %zu blocks, %.1f MB -> %.1f MB: H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", n_blocks, comp_bytes / 1e6, out_bytes / 1e6, a, b, c);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return (int)st;
+}

@@ -3,11 +3,13 @@
 #include "crc32_fast.h"
 #include "inflate_fast.h"
 #include "parallel.h"
+#include "../csrc/gpu_inflate.h"
 
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 
@@ -15,7 +17,6 @@ namespace {
 const size_t kMaxBlock = 65536;
 const size_t kWriteBlock = 65280; // uncompressed payload per block (leaves room for incompressible data)
 
-struct BlockRef { size_t off, csize, usize, uoff; };
 
 unsigned default_threads() { return bqc_host_threads(); }
 
@@ -32,39 +33,74 @@ void parallel_for(size_t n, unsigned threads, F f)
 }
 } // namespace
 
+static std::atomic<int> g_gpu_device{-1};
+static std::atomic<uint64_t> g_gpu_blocks{0};
+void bgzf_gpu_inflate_device(int device) { g_gpu_device = device; }
+uint64_t bgzf_gpu_inflated_blocks() { return g_gpu_blocks.load(); }
+
 BgzfReader::~BgzfReader()
 {
     if (ra_started_) {
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
         cv_.notify_all();
-        ra_.join();
+        for (auto& t : ra_) if (t.joinable()) t.join();
     }
     if (f_) fclose(f_);
 }
 
-void BgzfReader::read_ahead()
+// A worker of the read-ahead: plans a run (file read + block walk: one worker at a time, in file order), inflates it, and hands
+// it on in file order.  The second worker only takes part while a GPU inflates (bgzf_gpu_inflate_device): its file read then
+// overlaps the first one's copies and kernel; the CPU decoder uses every host thread for one run anyway.
+void BgzfReader::read_ahead(int worker)
 {
+    raw_vector<uint8_t> raw;
+    GpuInflater* gpu = nullptr;
+    struct Bye { GpuInflater*& g; ~Bye() { if (g) bqc_gpu_inflater_destroy(g); } } bye{gpu};
     for (;;) {
         Item it;
         { // reuse a buffer the consumer has handed back: no fresh pages to fault in for every run
             std::lock_guard<std::mutex> lk(m_);
             if (!spare_.empty()) { it.data.swap(spare_.back()); spare_.pop_back(); }
         }
-        it.ok = next_chunk_sync(it.data, it.err);
+        Run run;
+        uint64_t seq;
+        {
+            std::unique_lock<std::mutex> lk(plan_m_);
+            if (worker > 0) { // (polls: the device is switched on from outside)
+                while (!plan_done_ && !stopping() && (g_gpu_device.load() < 0 || gpu_failed_.load())) { lk.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); lk.lock(); }
+            }
+            if (plan_done_ || stopping()) return;
+            seq = plan_seq_++;
+            it.ok = plan_run(raw, run, it.err);
+            if (!it.ok) plan_done_ = true;
+        }
+        if (it.ok) it.ok = inflate_run(raw, run, it.data, it.err, gpu);
+        if (it.ok && it.data.empty() && run.last) it.ok = false; // (end of the file, nothing left)
         const bool last = !it.ok;
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return q_.size() < 3 || stop_; });
-        if (stop_) return;
+        cv_.wait(lk, [&] { return (pub_seq_ == seq && q_.size() < 3) || stop_ || ra_done_; });
+        if (stop_ || ra_done_) return; // (ra_done_: an earlier run has failed, what follows it is dropped)
         q_.push_back(std::move(it));
+        ++pub_seq_;
         if (last) ra_done_ = true;
         cv_.notify_all();
-        if (last) return;
+        if (last) {
+            std::lock_guard<std::mutex> lk2(plan_m_);
+            plan_done_ = true;
+            return;
+        }
     }
+}
+
+bool BgzfReader::stopping()
+{
+    std::lock_guard<std::mutex> lk(m_);
+    return stop_;
 }
 
 bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
 {
-    if (!ra_started_) { ra_started_ = true; ra_ = std::thread([this] { read_ahead(); }); }
+    if (!ra_started_) { ra_started_ = true; for (int w = 0; w < 2; ++w) ra_[w] = std::thread([this, w] { read_ahead(w); }); }
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [&] { return !q_.empty() || ra_done_; });
     if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
@@ -152,26 +188,35 @@ uint64_t bgzf_find_block(const char* path, uint64_t hint, std::string& err)
     return size;
 }
 
-bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
+// The next run of whole blocks: reads the file (behind what the last run left over), walks the block headers.  false: nothing
+// more to read (err empty) or a malformed stream.
+bool BgzfReader::plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err)
 {
-    out.clear();
-    if (eof_) return false;
+    run = Run();
+    if (eof_) { run.last = true; return false; }
     size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
+    // On the GPU a lane inflates a block: a run has to hold thousands of blocks to fill the card.
+    if (g_gpu_device.load() >= 0 && !gpu_failed_.load()) want = std::max<size_t>(want, gpu_run_bytes_);
     if (mark_u_.load() != UINT64_MAX) want = 4 * kMaxBlock;                          // behind the mark: only the rest of a record is wanted
-    // keep the tail of the previous round (a partial block) at the front of raw_
-    size_t have = raw_.size();
-    { const size_t cap = raw_.capacity(); raw_.resize(have + want); if (raw_.capacity() != cap) advise_huge(raw_); }
-    size_t got = fread(raw_.data() + have, 1, want, f_);
+    // the tail of the previous round (a partial block) goes to the front
+    const size_t have = tail_.size();
+    { const size_t cap = raw.capacity(); raw.resize(have + want); if (raw.capacity() != cap) advise_huge(raw); }
+    if (have) memcpy(raw.data(), tail_.data(), have);
+    const auto tt0 = std::chrono::steady_clock::now();
+    size_t got = fread(raw.data() + have, 1, want, f_);
+    run.read_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
+    run.read_bytes = got;
     cbytes_ += got;
-    raw_.resize(have + got);
+    raw.resize(have + got);
     if (got < want) eof_ = true;
-    std::vector<BlockRef> blocks;
+    run.last = eof_;
+    std::vector<BlockRef>& blocks = run.blocks;
     size_t p = 0, utotal = 0;
-    while (p + 18 <= raw_.size()) {
-        const uint8_t* h = raw_.data() + p;
+    while (p + 18 <= raw.size()) {
+        const uint8_t* h = raw.data() + p;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF stream (bad gzip member header)"; return false; }
         const size_t xlen = h[10] | (h[11] << 8);
-        if (p + 12 + xlen > raw_.size()) break;
+        if (p + 12 + xlen > raw.size()) break;
         size_t bsize = 0, x = 12;
         while (x + 4 <= 12 + xlen) {
             const size_t slen = h[x + 2] | (h[x + 3] << 8);
@@ -181,8 +226,8 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
         }
         if (!bsize) { err = "BGZF block without BC extra field"; return false; }
         if (bsize < 12 + xlen + 8) { err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; return false; } // (else csize underflows, the trailer lies before the block)
-        if (p + bsize > raw_.size()) break;
-        const uint8_t* t = raw_.data() + p + bsize - 8;
+        if (p + bsize > raw.size()) break;
+        const uint8_t* t = raw.data() + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
         if (isize > kMaxBlock) { err = "BGZF block larger than 64 KiB"; return false; }
         if (mark_u_.load() == UINT64_MAX) { // where the wanted block boundary lies in the uncompressed stream
@@ -193,25 +238,54 @@ bool BgzfReader::next_chunk_sync(raw_vector<uint8_t>& out, std::string& err)
         utotal += isize;
         p += bsize;
     }
-    if (mark_u_.load() == UINT64_MAX && eof_ && p == raw_.size() && file_pos_ + p == mark_) mark_u_ = u_total_ + utotal; // (mark = end of the file)
-    if (eof_ && p != raw_.size()) { err = "truncated BGZF file"; return false; }
-    { const size_t cap = out.capacity(); out.resize(utotal); if (out.capacity() != cap) advise_huge(out); }
+    if (mark_u_.load() == UINT64_MAX && eof_ && p == raw.size() && file_pos_ + p == mark_) mark_u_ = u_total_ + utotal; // (mark = end of the file)
+    if (eof_ && p != raw.size()) { err = "truncated BGZF file"; return false; }
+    tail_.assign(raw.begin() + p, raw.end());
+    run.consumed = p;
+    run.utotal = utotal;
+    file_pos_ += p;
+    u_total_ += utotal;
+    return true;
+}
+
+// Inflates the blocks of a planned run into `out` and checks their CRC-32.
+bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, GpuInflater*& gpu)
+{
+    static const bool gi_timing = getenv("BQC_GI_TIMING") != nullptr;
+    const auto tt1 = std::chrono::steady_clock::now();
+    const std::vector<BlockRef>& blocks = run.blocks;
+    { const size_t cap = out.capacity(); out.resize(run.utotal); if (out.capacity() != cap) advise_huge(out); }
     std::atomic<bool> bad{false};
+    bool on_gpu = false;
+    const int gpu_dev = g_gpu_device.load();
+    if (gpu_dev >= 0 && !gpu && !gpu_failed_.load()) { gpu = bqc_gpu_inflater_create(gpu_dev); if (!gpu) gpu_failed_ = true; }
+    if (gpu && gpu_dev >= 0 && blocks.size() >= 256) {
+        std::vector<GiBlock> gb;
+        gb.reserve(blocks.size());
+        for (const BlockRef& b : blocks) if (b.usize) gb.push_back(GiBlock{b.off, b.uoff, (uint32_t)b.csize, (uint32_t)b.usize});
+        const int rc = bqc_gpu_inflate(gpu, raw.data(), run.consumed, gb.data(), gb.size(), out.data(), run.utotal);
+        if (rc > 0) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
+        if (rc < 0) { bqc_gpu_inflater_destroy(gpu); gpu = nullptr; gpu_failed_ = true; } // the card cannot be used: the CPU decoder takes over
+        else { on_gpu = true; g_gpu_blocks += gb.size(); }
+    }
+    const auto tt2 = std::chrono::steady_clock::now();
     parallel_for(blocks.size(), threads_, [&](size_t i) {
         const BlockRef& b = blocks[i];
         if (b.usize == 0) return;
+        const uint8_t* t = raw.data() + b.off + b.csize;
+        const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (on_gpu) { if (bqc_crc32_fast(out.data() + b.uoff, b.usize) != crc) bad = true; return; }
         static thread_local Inflater inf;
         // (the 8 bytes after the deflate data, which the decoder may load but not use, are the block's CRC32 / ISIZE)
-        if (!inf.run(raw_.data() + b.off, b.csize, out.data() + b.uoff, b.usize)) { bad = true; return; }
-        const uint8_t* t = raw_.data() + b.off + b.csize;
-        const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (!inf.run(raw.data() + b.off, b.csize, out.data() + b.uoff, b.usize)) { bad = true; return; }
         if (bqc_crc32_fast(out.data() + b.uoff, b.usize) != crc) bad = true;
     });
     if (bad) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
-    raw_.erase(raw_.begin(), raw_.begin() + p);
-    file_pos_ += p;
-    u_total_ += utotal;
-    if (out.empty() && eof_) return false;
+    if (gi_timing) {
+        const auto tt3 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bgzf run] read %.1f MB in %.2f ms, %s %.2f ms, %s %.2f ms\n", run.read_bytes / 1e6, run.read_ms, on_gpu ? "gpu inflate" : "-",
+                std::chrono::duration<double, std::milli>(tt2 - tt1).count(), on_gpu ? "crc" : "cpu inflate + crc", std::chrono::duration<double, std::milli>(tt3 - tt2).count());
+    }
     return true;
 }
 

@@ -28,13 +28,23 @@ public:
     // On a malformed stream sets err and returns false.  A read-ahead thread inflates the following runs meanwhile.
     bool next_chunk(raw_vector<uint8_t>& out, std::string& err);
     uint64_t compressed_bytes_read() const { return cbytes_; }
+    void gpu_run_bytes(size_t n) { gpu_run_bytes_ = n; } // compressed bytes per run when the GPU inflates
     unsigned threads() const { return threads_; }
 
 private:
-    bool next_chunk_sync(raw_vector<uint8_t>& out, std::string& err);
-    void read_ahead();
+    struct BlockRef { size_t off, csize, usize, uoff; };
+    struct Run { std::vector<BlockRef> blocks; size_t consumed = 0, utotal = 0, read_bytes = 0; double read_ms = 0; bool last = false; };
+    bool plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err);
+    bool inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, struct GpuInflater*& gpu);
+    void read_ahead(int worker);
+    bool stopping();
     struct Item { raw_vector<uint8_t> data; std::string err; bool ok = false; };
-    std::thread ra_;
+    std::thread ra_[2];
+    std::mutex plan_m_;                      // plan_run: one worker at a time; guards what follows
+    uint64_t plan_seq_ = 0;
+    bool plan_done_ = false;
+    std::vector<uint8_t> tail_;              // the partial block behind the last planned run
+    uint64_t pub_seq_ = 0;                   // (under m_) runs are handed on in the order they were planned
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<Item> q_;
@@ -44,13 +54,19 @@ private:
     unsigned threads_ = 1;
     uint64_t cbytes_ = 0;
     bool eof_ = false;
-    raw_vector<uint8_t> raw_;
     uint64_t file_pos_ = 0;          // file offset of raw_[0]
     uint64_t mark_ = UINT64_MAX;     // file offset whose uncompressed position is wanted
     uint64_t u_total_ = 0;           // uncompressed bytes yielded so far
     std::atomic<uint64_t> mark_u_{UINT64_MAX};
     std::atomic<bool> mark_missed_{false};
+    std::atomic<bool> gpu_failed_{false};    // the card could not be used: the CPU decoder has taken over for good
+    size_t gpu_run_bytes_ = 256u << 20;
 };
+
+// device >= 0: readers inflate their runs on that GPU from their next run on (csrc/gpu_inflate.hip; the CRC-32 of every block is
+// still checked on the host); -1 (the default): on the CPU.  Set by the command-line driver once the card is up.
+void bgzf_gpu_inflate_device(int device);
+uint64_t bgzf_gpu_inflated_blocks(); // blocks inflated on a GPU so far in this process
 
 // The offset of the first BGZF block at or behind `hint` (a gzip member header with the BC subfield whose BSIZE leads to two
 // more such headers, or to the end of the file); the file size if there is none.  Every caller gets the same answer for the

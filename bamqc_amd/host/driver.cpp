@@ -172,6 +172,8 @@ extern "C" uint64_t bqc_bam_range_end_block(const bqc_bam* b) { return b->bam.ra
 extern "C" uint64_t bqc_bam_range_first(const bqc_bam* b) { return b->bam.range_first(); }
 extern "C" uint64_t bqc_bam_range_over(const bqc_bam* b) { return b->bam.range_over(); }
 extern "C" uint64_t bqc_file_size(const char* path) { return path ? bgzf_file_size(path) : 0; }
+extern "C" void bqc_gpu_inflate_device(int device) { bgzf_gpu_inflate_device(device); }
+extern "C" uint64_t bqc_gpu_inflated_blocks(void) { return bgzf_gpu_inflated_blocks(); }
 extern "C" int bqc_inflate_raw(const uint8_t* in, uint64_t in_n, uint8_t* out, uint64_t out_n)
 {
     static thread_local Inflater inf;
@@ -572,7 +574,11 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
         fprintf(stderr, "[timing] %s: %.3f s after launch\n", what, now - atof(getenv("BQC_T0")));
     };
     since_launch("main entered");
-    std::thread warm([dev = opt.device] { (void)bqc_warmup(dev); }); // the HIP runtime starts (~0.1 s) while the inputs are opened
+    // the HIP runtime starts (~0.1 s) while the inputs are opened; from then on the reader's runs are inflated on the card
+    const char* gi_env = getenv("BQC_GPU_INFLATE");
+    const bool gpu_inflate = gi_env && atoi(gi_env) != 0;
+    std::thread warm([dev = opt.device, gpu_inflate] { if (bqc_warmup(dev) == 0 && gpu_inflate) bgzf_gpu_inflate_device(dev); });
+    struct InflateOff { ~InflateOff() { bgzf_gpu_inflate_device(-1); } } inflate_off; // (destroyed after the joiner below has joined the thread that sets it)
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
     // "-": SAM text from stdin; everything else is opened as BAM (bamqualcheck.cpp:252-262: a .sam path fails to open there too)
     BamReader bam_rd;

@@ -63,6 +63,10 @@ uint64_t bqc_bam_range_end_block(const bqc_bam* b);   /* UINT64_MAX: end of the 
 uint64_t bqc_bam_range_first(const bqc_bam* b);       /* valid after the first bqc_bam_next */
 uint64_t bqc_bam_range_over(const bqc_bam* b);        /* valid after the last bqc_bam_next  */
 uint64_t bqc_file_size(const char* path);
+/* device >= 0: BAM readers inflate their BGZF blocks on that GPU from their next run of blocks on (the CRC-32 of every block is
+ * still checked on the host; a card that cannot be used hands the work back to the CPU decoder); -1: on the CPU (the default). */
+void bqc_gpu_inflate_device(int device);
+uint64_t bqc_gpu_inflated_blocks(void);               /* BGZF blocks inflated on a GPU so far in this process */
 void bqc_bam_close(bqc_bam* b);
 const char* bqc_bam_error(const bqc_bam* b);
 uint32_t bqc_bam_n_refs(const bqc_bam* b);

@@ -1,0 +1,177 @@
+"""GPU: raw DEFLATE of BGZF blocks on the card (csrc/gpu_inflate.hip) against zlib — stored, fixed-code and dynamic-code blocks,
+long codes, every match distance class, empty and maximal blocks, corrupt streams — and through the BAM reader."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from bamqc_amd import _lib, hostio
+
+pytestmark = pytest.mark.gpu
+
+
+class GiBlock(C.Structure):
+    _fields_ = [("coff", C.c_uint64), ("uoff", C.c_uint64), ("csize", C.c_uint32), ("usize", C.c_uint32)]
+
+
+@pytest.fixture(scope="module")
+def gi():
+    lib = _lib.load()
+    lib.bqc_gpu_inflater_create.restype = C.c_void_p
+    lib.bqc_gpu_inflater_create.argtypes = [C.c_int]
+    lib.bqc_gpu_inflater_destroy.argtypes = [C.c_void_p]
+    lib.bqc_gpu_inflate.restype = C.c_int
+    lib.bqc_gpu_inflate.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(GiBlock), C.c_size_t, C.c_void_p, C.c_size_t]
+    g = lib.bqc_gpu_inflater_create(0)
+    assert g
+    yield lib, g
+    lib.bqc_gpu_inflater_destroy(g)
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+def run(gi, streams, sizes=None):
+    lib, g = gi
+    comp = b"".join(streams) + b"\0" * 16
+    n = len(streams)
+    blocks = (GiBlock * n)()
+    co = uo = 0
+    for i, s in enumerate(streams):
+        us = sizes[i] if sizes else len(zlib.decompress(s, -15))
+        blocks[i] = GiBlock(co, uo, len(s), us)
+        co += len(s)
+        uo += us
+    out = np.zeros(uo + 64, np.uint8)
+    rc = lib.bqc_gpu_inflate(g, comp, len(comp), blocks, n, out.ctypes.data, uo)
+    return rc, out[:uo].tobytes()
+
+
+def payloads():
+    rng = np.random.default_rng(5)
+    p = []
+    p.append(b"")                                                       # empty block (the BGZF EOF marker's payload)
+    p.append(b"a")
+    p.append(b"abc" * 21000)                                            # distance 3, long matches
+    p.append(b"\x07" * 65536)                                           # distance 1, maximal block
+    p.append(bytes(rng.integers(0, 256, 65536, dtype=np.uint8)))        # incompressible
+    p.append(bytes(rng.integers(0, 4, 60000, dtype=np.uint8)))          # short codes
+    p.append(bytes((rng.geometric(0.02, 65000) % 256).astype(np.uint8)))  # skewed: long codes for the rare symbols
+    txt = b"".join(b"read%07d\tACGT%s\t%d\n" % (i, b"ACGTTGCA"[i % 5:], i * 37) for i in range(2600))
+    p.append(txt[:65000])                                               # text with matches at every distance
+    a = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    p.append(a + a)                                                     # distance 30000
+    p.append(a[:17] * 1000)                                             # distance 17
+    p.append(a[:5] * 3000)                                              # distance 5
+    return p
+
+
+def test_against_zlib_all_block_kinds(gi):
+    streams, want = [], []
+    for data in payloads():
+        for level, strategy in [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (1, zlib.Z_FILTERED)]:
+            s = raw_deflate(data, level, strategy)
+            if len(s) > 65536 + 64:
+                continue
+            streams.append(s)
+            want.append(data)
+    # several deflate blocks inside one stream (Z_FULL_FLUSH between the parts: stored / dynamic / fixed mixed)
+    rng = np.random.default_rng(9)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = [bytes(rng.integers(0, 7, 9000, dtype=np.uint8)), b"xyz" * 2000, bytes(rng.integers(0, 256, 3000, dtype=np.uint8))]
+    s = b"".join(c.compress(x) + c.flush(zlib.Z_FULL_FLUSH) for x in parts) + c.flush()
+    streams.append(s)
+    want.append(b"".join(parts))
+    rc, got = run(gi, streams)
+    assert rc == 0
+    o = 0
+    for i, w in enumerate(want):
+        assert got[o:o + len(w)] == w, "stream %d differs" % i
+        o += len(w)
+
+
+def test_many_blocks_fill_the_card(gi):
+    rng = np.random.default_rng(11)
+    base = [bytes(rng.integers(0, 1 + 3 * (k % 80), 20000 + 500 * (k % 90), dtype=np.uint8)) for k in range(200)]
+    streams = [raw_deflate(b, 1 + k % 9) for k, b in enumerate(base)] * 40       # 8000 blocks
+    rc, got = run(gi, streams, [len(b) for b in base] * 40)
+    assert rc == 0
+    assert got == b"".join(base) * 40
+
+
+@pytest.mark.parametrize("kind", ["truncated", "flipped", "wrong_size_short", "wrong_size_long", "bad_type", "bad_stored_len", "far_distance"])
+def test_corrupt_streams_are_reported(gi, kind):
+    rng = np.random.default_rng(3)
+    data = bytes(rng.integers(0, 9, 30000, dtype=np.uint8))
+    good = raw_deflate(data)
+    ok = [good] * 70
+    size = len(data)
+    if kind == "truncated":
+        bad = good[:len(good) // 2]
+    elif kind == "flipped":
+        bad = bytearray(good)
+        for k in range(40, len(bad), 97):
+            bad[k] ^= 0x5A
+        bad = bytes(bad)
+        if zlib_ok(bad, size):
+            pytest.skip("the flipped stream is still a valid one")
+    elif kind == "wrong_size_short":
+        bad, size = good, len(data) - 1
+    elif kind == "wrong_size_long":
+        bad, size = good, len(data) + 1
+    elif kind == "bad_type":
+        bad = bytes([0x07]) + good[1:]           # BFINAL = 1, BTYPE = 3
+    elif kind == "bad_stored_len":
+        bad = bytes([0x01, 0x10, 0x00, 0x10, 0x00]) + b"x" * 16  # NLEN is not ~LEN
+        size = 16
+    else:  # a fixed-code block whose first symbol is a match: distance 1 before the start of the output
+        # BFINAL=1 BTYPE=01, length code 257 (7 bits 0000001), distance code 0 (5 bits), end of block (7 bits 0)
+        bits = "1" + "10" + "0000001" + "00000" + "0000000"
+        v = int(bits[::-1], 2)
+        bad, size = v.to_bytes(4, "little"), 3
+    sizes = [len(data)] * 70
+    streams = list(ok)
+    streams[33] = bad
+    sizes[33] = size
+    rc, _ = run(gi, streams, sizes)
+    assert rc > 0
+
+
+def zlib_ok(s, size):
+    try:
+        return len(zlib.decompress(s, -15)) == size
+    except zlib.error:
+        return False
+
+
+@pytest.mark.parametrize("level", [1, 6])
+def test_reader_on_the_gpu_matches_the_cpu_decoder(tmp_path, level):
+    lib = _lib.load()
+    path = str(tmp_path / "x.bam")
+    hostio.synth_stream(path, None, seed=21, n_reads=1_500_000, ref_names=["chr1", "chr2"], ref_lens=[3_000_000, 2_000_000], n_lanes=3, level=level)
+
+    def columns():
+        out = []
+        b = hostio.BamFile(path)
+        for batch in b.batches(400_000):
+            out.append({k: np.array(v, copy=True) for k, v in batch.items() if isinstance(v, np.ndarray)})
+        b.close()
+        return out
+    cpu = columns()
+    before = lib.bqc_gpu_inflated_blocks()
+    lib.bqc_gpu_inflate_device(0)
+    try:
+        gpu = columns()
+    finally:
+        lib.bqc_gpu_inflate_device(-1)
+    assert lib.bqc_gpu_inflated_blocks() - before > 3000  # the card did the work, not the fallback
+    assert len(cpu) == len(gpu) and sum(len(a["flag"]) for a in cpu) == 1_500_000
+    for a, b in zip(cpu, gpu):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
