@@ -15,12 +15,15 @@
 // lanes per workgroup, H2D 5 ms, D2H into pageable memory 35 ms; the host decoder (16 threads) needs 80 ms for the same bytes.  A
 // lane spends ~1.5 us per symbol whatever the workgroup width: that is one round trip to HBM per iteration of the wave — a
 // match reads the lane's own output up to 32 KiB back, 13 K lanes x 64 KiB of output are far more than the L2 holds, and in every
-// iteration some lane of the wave has a match.  The kernel is latency-bound and its time does not depend on the number of blocks
-// until the card is full (76 lanes per CU with these tables: 19 K blocks); with the inflated bytes going back to the host the copy
-// costs more than the kernel, and runs this large (a fresh 0.9 GB buffer each) cost the host more in page faults than the inflate
-// they save: the program's record loop is slower with it (0.63 s against 0.34 s for 10 M reads).  What makes it pay is the next
-// step, not a faster copy: walk and decode the records on the card too (the inflated bytes never return), with the tables cut to
-// the canonical arrays alone (356 B per lane: 460 blocks per CU in flight, a whole 10 M-read file in one launch).
+// iteration some lane of the wave has a match.  The kernel is latency-bound: its time is the time of one block (22 ms for 3.4 K
+// blocks, 32 ms for 13 K) until the card is full (76 lanes per CU with these tables: 19 K blocks), so the reader keeps several
+// moderate runs in flight (host/bgzf.cpp: one worker, stream and pair of page-locked buffers each).  End to end the program is
+// still SLOWER with it than with the host decoder: 10 M reads 0.86 s against 0.52 s, 40 M reads 2.09 s against 1.49 s — the
+// inflated bytes go back to the host (page-locking and first touch of the buffers they land in, the runtime's locks shared
+// with the batch pipeline's own copies), and the record decode that follows is host work either way.  What makes it pay is the
+// next step, not a faster copy: walk and decode the records on the card too (the inflated bytes never return), with the tables
+// cut to the canonical arrays alone (356 B per lane: 460 blocks per CU in flight, a whole 10 M-read file in one launch), and the
+// matches of a block resolved after its symbols are decoded (one round trip per match instead of one per symbol).
 //
 // Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
 // incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input
@@ -305,10 +308,12 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate(const uint8_t*
 struct GpuInflater {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr; // blocking: the waiting host thread sleeps (several readers wait at once)
     uint8_t* d_comp = nullptr; size_t comp_cap = 0;
     uint8_t* d_out = nullptr; size_t out_cap = 0;
     GiBlock* d_blocks = nullptr; size_t blocks_cap = 0;
     uint32_t* d_status = nullptr;
+    uint32_t* h_status = nullptr; // page-locked
 };
 
 extern "C" GpuInflater* bqc_gpu_inflater_create(int device)
@@ -320,12 +325,16 @@ extern "C" GpuInflater* bqc_gpu_inflater_create(int device)
     if (e == hipSuccess && (device < 0 || device >= ndev)) e = hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&g->d_status, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&g->h_status, 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate<64>), hipFuncAttributeMaxDynamicSharedMemorySize, GI_U16 * 2 * 64);
     if (e != hipSuccess) {
         if (getenv("BQC_GI_TIMING")) fprintf(stderr, "[gpu inflate] not available: %s\n", hipGetErrorString(e));
         if (g->stream) (void)hipStreamDestroy(g->stream);
+        if (g->done) (void)hipEventDestroy(g->done);
         (void)hipFree(g->d_status);
+        if (g->h_status) (void)hipHostFree(g->h_status);
         delete g;
         return nullptr;
     }
@@ -337,7 +346,9 @@ extern "C" void bqc_gpu_inflater_destroy(GpuInflater* g)
     if (!g) return;
     (void)hipSetDevice(g->device);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->done) (void)hipEventDestroy(g->done);
     (void)hipFree(g->d_comp); (void)hipFree(g->d_out); (void)hipFree(g->d_blocks); (void)hipFree(g->d_status);
+    if (g->h_status) (void)hipHostFree(g->h_status);
     delete g;
 }
 
@@ -368,21 +379,20 @@ extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_
     if (hipMemsetAsync(g->d_status, 0, 4, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->d_blocks, blocks, n_blocks * sizeof(GiBlock), hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
-    static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 16;
+    static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 8;
     if (timing) (void)hipEventRecord(ev[1], g->stream);
 #define GI_LAUNCH(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((uint32_t)((n_blocks + NL - 1) / NL)), dim3(NL), GI_U16 * 2 * NL, g->stream, g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, g->d_status)
-    if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 8) GI_LAUNCH(8); else GI_LAUNCH(16);
-    uint32_t st = 0;
+    if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 16) GI_LAUNCH(16); else GI_LAUNCH(8);
     if (timing) (void)hipEventRecord(ev[2], g->stream);
     if (hipMemcpyAsync(out, g->d_out, out_bytes, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
-    if (hipMemcpyAsync(&st, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(g->h_status, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
     if (timing) (void)hipEventRecord(ev[3], g->stream);
-    if (hipStreamSynchronize(g->stream) != hipSuccess) return -1;
+    if (hipEventRecord(g->done, g->stream) != hipSuccess || hipEventSynchronize(g->done) != hipSuccess) return -1;
     if (timing) {
         float a = 0, b = 0, c = 0;
         (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
         fprintf(stderr, "[gpu inflate] %zu blocks, %.1f MB -> %.1f MB: H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", n_blocks, comp_bytes / 1e6, out_bytes / 1e6, a, b, c);
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
-    return (int)st;
+    return (int)*g->h_status;
 }

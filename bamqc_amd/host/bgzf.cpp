@@ -49,8 +49,10 @@ BgzfReader::~BgzfReader()
 }
 
 // A worker of the read-ahead: plans a run (file read + block walk: one worker at a time, in file order), inflates it, and hands
-// it on in file order.  The second worker only takes part while a GPU inflates (bgzf_gpu_inflate_device): its file read then
-// overlaps the first one's copies and kernel; the CPU decoder uses every host thread for one run anyway.
+// it on in file order.  Workers other than the first only take part while a GPU inflates (bgzf_gpu_inflate_device): the kernel's
+// time is the time a lane needs for its block whatever the number of blocks, so several moderate runs in flight (each with
+// its own stream and buffers) fill the card like one huge run would, with bounded, reusable host buffers; the CPU decoder uses
+// every host thread for one run anyway.
 void BgzfReader::read_ahead(int worker)
 {
     raw_vector<uint8_t> raw;
@@ -100,7 +102,11 @@ bool BgzfReader::stopping()
 
 bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
 {
-    if (!ra_started_) { ra_started_ = true; for (int w = 0; w < 2; ++w) ra_[w] = std::thread([this, w] { read_ahead(w); }); }
+    if (!ra_started_) {
+        ra_started_ = true;
+        static const int workers = getenv("BQC_GI_WORKERS") ? std::max(1, atoi(getenv("BQC_GI_WORKERS"))) : 6;
+        for (int w = 0; w < workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
+    }
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [&] { return !q_.empty() || ra_done_; });
     if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
@@ -260,6 +266,10 @@ bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw
     const int gpu_dev = g_gpu_device.load();
     if (gpu_dev >= 0 && !gpu && !gpu_failed_.load()) { gpu = bqc_gpu_inflater_create(gpu_dev); if (!gpu) gpu_failed_ = true; }
     if (gpu && gpu_dev >= 0 && blocks.size() >= 256) {
+        if (bqc_raw_vector_pin_hook) { // page-locked: the copies run at the link's speed and without a staging pass
+            bqc_raw_vector_pin_hook(raw.data(), raw.capacity());
+            bqc_raw_vector_pin_hook(out.data(), out.capacity());
+        }
         std::vector<GiBlock> gb;
         gb.reserve(blocks.size());
         for (const BlockRef& b : blocks) if (b.usize) gb.push_back(GiBlock{b.off, b.uoff, (uint32_t)b.csize, (uint32_t)b.usize});
@@ -269,7 +279,7 @@ bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw
         else { on_gpu = true; g_gpu_blocks += gb.size(); }
     }
     const auto tt2 = std::chrono::steady_clock::now();
-    parallel_for(blocks.size(), threads_, [&](size_t i) {
+    parallel_for(blocks.size(), on_gpu ? std::min(threads_, 4u) : threads_, [&](size_t i) { // (on the GPU path several workers are at it at once)
         const BlockRef& b = blocks[i];
         if (b.usize == 0) return;
         const uint8_t* t = raw.data() + b.off + b.csize;

@@ -39,7 +39,7 @@ private:
     void read_ahead(int worker);
     bool stopping();
     struct Item { raw_vector<uint8_t> data; std::string err; bool ok = false; };
-    std::thread ra_[2];
+    std::vector<std::thread> ra_;
     std::mutex plan_m_;                      // plan_run: one worker at a time; guards what follows
     uint64_t plan_seq_ = 0;
     bool plan_done_ = false;
@@ -60,7 +60,7 @@ private:
     std::atomic<uint64_t> mark_u_{UINT64_MAX};
     std::atomic<bool> mark_missed_{false};
     std::atomic<bool> gpu_failed_{false};    // the card could not be used: the CPU decoder has taken over for good
-    size_t gpu_run_bytes_ = 256u << 20;
+    size_t gpu_run_bytes_ = 64u << 20;
 };
 
 // device >= 0: readers inflate their runs on that GPU from their next run on (csrc/gpu_inflate.hip; the CRC-32 of every block is

@@ -537,6 +537,7 @@ struct PinRegistry {
 };
 PinRegistry g_pins;
 void pin_free_hook(void* p) { g_pins.release(p); }
+void pin_hook(const void* p, size_t bytes) { g_pins.pin(p, bytes); }
 template <typename V> void pin_column(const V& v) { g_pins.pin(v.data(), v.capacity() * sizeof(typename V::value_type)); }
 void pin_batch(const HostBatch& hb)
 {
@@ -577,8 +578,13 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
     // the HIP runtime starts (~0.1 s) while the inputs are opened; from then on the reader's runs are inflated on the card
     const char* gi_env = getenv("BQC_GPU_INFLATE");
     const bool gpu_inflate = gi_env && atoi(gi_env) != 0;
-    std::thread warm([dev = opt.device, gpu_inflate] { if (bqc_warmup(dev) == 0 && gpu_inflate) bgzf_gpu_inflate_device(dev); });
-    struct InflateOff { ~InflateOff() { bgzf_gpu_inflate_device(-1); } } inflate_off; // (destroyed after the joiner below has joined the thread that sets it)
+    std::thread warm([dev = opt.device, gpu_inflate] {
+        if (bqc_warmup(dev) != 0 || !gpu_inflate) return;
+        bqc_raw_vector_free_hook = pin_free_hook; // the reader page-locks the buffers the card copies into
+        bqc_raw_vector_pin_hook = pin_hook;
+        bgzf_gpu_inflate_device(dev);
+    });
+    struct InflateOff { ~InflateOff() { bgzf_gpu_inflate_device(-1); bqc_raw_vector_pin_hook = nullptr; } } inflate_off; // (destroyed after the joiner below has joined the thread that sets it)
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } warm_joiner{warm};
     // "-": SAM text from stdin; everything else is opened as BAM (bamqualcheck.cpp:252-262: a .sam path fails to open there too)
     BamReader bam_rd;

@@ -7,6 +7,9 @@
 // Called with every block a raw_vector gives back, before it is freed: the program page-locks the columns it decodes into
 // (driver.cpp) and must release the lock of a block that a growing vector is about to free.
 inline void (*bqc_raw_vector_free_hook)(void*) = nullptr;
+// The other direction: a producer that fills a buffer by copies from the device (the BGZF reader when the GPU inflates) asks for
+// the block to be page-locked; whoever sets this hook sets the one above too.
+inline void (*bqc_raw_vector_pin_hook)(const void*, size_t) = nullptr;
 
 template <typename T>
 struct no_init_alloc : std::allocator<T> {
