@@ -41,7 +41,7 @@ uint64_t bgzf_gpu_inflated_blocks() { return g_gpu_blocks.load(); }
 BgzfReader::~BgzfReader()
 {
     if (ra_started_) {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; } // (from here on no worker is added)
         cv_.notify_all();
         for (auto& t : ra_) if (t.joinable()) t.join();
     }
@@ -64,11 +64,16 @@ void BgzfReader::read_ahead(int worker)
             std::lock_guard<std::mutex> lk(m_);
             if (!spare_.empty()) { it.data.swap(spare_.back()); spare_.pop_back(); }
         }
+        if (worker == 0 && g_gpu_device.load() >= 0 && !gpu_failed_.load()) { // a GPU has been switched on: the other workers start
+            static const int workers = getenv("BQC_GI_WORKERS") ? std::min(32, std::max(1, atoi(getenv("BQC_GI_WORKERS")))) : 6;
+            std::lock_guard<std::mutex> lk(m_);
+            if (!stop_ && ra_.size() == 1) for (int w = 1; w < workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
+        }
         Run run;
         uint64_t seq;
         {
             std::unique_lock<std::mutex> lk(plan_m_);
-            if (worker > 0) { // (polls: the device is switched on from outside)
+            if (worker > 0) { // (they only take part while the card inflates)
                 while (!plan_done_ && !stopping() && (g_gpu_device.load() < 0 || gpu_failed_.load())) { lk.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); lk.lock(); }
             }
             if (plan_done_ || stopping()) return;
@@ -102,11 +107,7 @@ bool BgzfReader::stopping()
 
 bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
 {
-    if (!ra_started_) {
-        ra_started_ = true;
-        static const int workers = getenv("BQC_GI_WORKERS") ? std::max(1, atoi(getenv("BQC_GI_WORKERS"))) : 6;
-        for (int w = 0; w < workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
-    }
+    if (!ra_started_) { ra_started_ = true; ra_.reserve(32); ra_.emplace_back([this] { read_ahead(0); }); }
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [&] { return !q_.empty() || ra_done_; });
     if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
