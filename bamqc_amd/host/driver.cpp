@@ -4,6 +4,7 @@
 // (replaces Genome / SequenceStream, src/TripletCounting.hpp:60-104) and the C wrappers of
 // include/bamqc_host.h around the BAM reader.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -32,7 +33,7 @@
 // ---------------------------------------------------------------------------------------------------
 // FASTA
 // ---------------------------------------------------------------------------------------------------
-struct FastaRecord { std::string name; std::vector<uint8_t> codes; };
+struct FastaRecord { std::string name; raw_vector<uint8_t> codes; };
 
 static inline uint8_t dna5_of_char(char c)
 {
@@ -47,8 +48,130 @@ static inline uint8_t dna5_of_char(char c)
 
 // Loads every record; the id is cut at the first space or tab (TripletCounting.hpp:99-102).
 // `want` (optional) limits which sequences are kept in memory; all records keep their FASTA position.
+// An uncompressed FASTA file is mapped and parsed by all host threads (a human genome is 3 GB of text: 2.2 s on one thread):
+// header lines are found first ('>' outside a header line, in parallel; a few thousand at most), then the sequence between two
+// headers is counted (bytes other than '\n' / '\r') and encoded chunk by chunk straight into the record's array.  Same rules as
+// the sequential loader below.  1: loaded, 0: not this kind of file (compressed, a pipe, empty), -1: error.
+static int load_fasta_mapped(const char* path, const std::vector<std::string>* want, std::vector<FastaRecord>& out)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) { close(fd); return 0; }
+    const size_t size = (size_t)st.st_size;
+    void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) return 0;
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{mp, size};
+    const char* const m = (const char*)mp;
+    if ((uint8_t)m[0] == 0x1f && (uint8_t)m[1] == 0x8b) return 0; // gzip: the sequential loader inflates it
+    (void)madvise(mp, size, MADV_WILLNEED);
+    const unsigned nt = bqc_host_threads();
+    const bool ft = getenv("BQC_FASTA_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!ft) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fasta] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
+    // 1. every '>' of the file
+    const size_t n_chunks = std::max<size_t>(1, std::min<size_t>((size + (1u << 20) - 1) >> 20, (size_t)nt * 4));
+    std::vector<std::vector<size_t>> gts(n_chunks);
+    parallel_ranges(n_chunks, nt, 1, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            const char* p = m + size * c / n_chunks;
+            const char* const e = m + size * (c + 1) / n_chunks;
+            while (p < e) {
+                const char* g = (const char*)memchr(p, '>', (size_t)(e - p));
+                if (!g) break;
+                gts[c].push_back((size_t)(g - m));
+                p = g + 1;
+            }
+        }
+    });
+    lap("find '>'");
+    // 2. those outside a header line start one; the line ends at the next '\n' (or with the file)
+    struct Hdr { size_t gt, nl; };
+    std::vector<Hdr> hdrs;
+    size_t limit = 0;
+    for (const auto& v : gts)
+        for (size_t g : v) {
+            if (g < limit) continue;
+            const char* nl = (const char*)memchr(m + g, '\n', size - g);
+            const size_t e = nl ? (size_t)(nl - m) : size;
+            hdrs.push_back(Hdr{g, e});
+            limit = e + 1;
+        }
+    // 3. records; the sequence of the kept ones is cut into tasks
+    struct Task { size_t rec, lo, hi, count, at; };
+    std::vector<Task> tasks;
+    out.clear();
+    out.reserve(hdrs.size());
+    const size_t kTask = 4u << 20;
+    for (size_t i = 0; i < hdrs.size(); ++i) {
+        std::string hdr(m + hdrs[i].gt + 1, hdrs[i].nl - hdrs[i].gt - 1);
+        const size_t cut = hdr.find_first_of(" \t");
+        std::string name = hdr.substr(0, cut);
+        if (!name.empty() && name.back() == '\r') name.pop_back();
+        bool keep = true;
+        if (want) {
+            keep = false;
+            for (const auto& w : *want) if (w == name) { keep = true; break; }
+        }
+        out.push_back(FastaRecord{name, {}});
+        const size_t lo = std::min(size, hdrs[i].nl + 1), hi = i + 1 < hdrs.size() ? hdrs[i + 1].gt : size;
+        if (keep)
+            for (size_t a = lo; a < hi; a += kTask) tasks.push_back(Task{i, a, std::min(hi, a + kTask), 0, 0});
+    }
+    // 4. count, place, encode
+    parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; ++t) {
+            size_t n = 0;
+            for (const char* q = m + tasks[t].lo; q < m + tasks[t].hi; ++q) n += (*q != '\n') & (*q != '\r');
+            tasks[t].count = n;
+        }
+    });
+    lap("count");
+    std::vector<size_t> total(out.size(), 0);
+    for (auto& t : tasks) { t.at = total[t.rec]; total[t.rec] += t.count; }
+    try {
+        for (size_t i = 0; i < out.size(); ++i) if (total[i]) { out[i].codes.resize(total[i]); advise_huge(out[i].codes); }
+    } catch (const std::bad_alloc&) { return -1; }
+    lap("allocate");
+    uint8_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = dna5_of_char((char)i);
+    parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; ++t) {
+            uint8_t* w = out[tasks[t].rec].codes.data() + tasks[t].at;
+            const char* q = m + tasks[t].lo;
+            const char* const hi_q = m + tasks[t].hi;
+            while (q < hi_q) { // line by line: a run without '\n' is translated as a whole; a '\r' inside it (rare) takes the byte-wise path
+                const char* nl = (const char*)memchr(q, '\n', (size_t)(hi_q - q));
+                const char* const e = nl ? nl : hi_q;
+                const size_t n = (size_t)(e - q);
+                if (n && memchr(q, '\r', n)) {
+                    for (size_t i = 0; i < n; ++i) if (q[i] != '\r') *w++ = lut[(uint8_t)q[i]];
+                } else {
+                    for (size_t i = 0; i < n; ++i) w[i] = lut[(uint8_t)q[i]];
+                    w += n;
+                }
+                q = e + 1;
+            }
+        }
+    });
+    lap("encode");
+    return 1;
+}
+
 static bool load_fasta(const char* path, const std::vector<std::string>* want, std::vector<FastaRecord>& out, std::string& err)
 {
+    if (!getenv("BQC_FASTA_SEQUENTIAL")) {
+        const int rc = load_fasta_mapped(path, want, out);
+        if (rc > 0) return true;
+        if (rc < 0) { err = std::string("ERROR: out of memory while loading ") + path; return false; }
+        out.clear();
+    }
     gzFile f = gzopen(path, "rb");
     if (!f) { err = std::string("ERROR: Could not open fasta file ") + path; return false; }
     gzbuffer(f, 1 << 20);
@@ -99,7 +222,7 @@ static bool load_fasta(const char* path, const std::vector<std::string>* want, s
             const char* gt = (const char*)memchr(p, '>', (size_t)(end - p));
             const char* stop = gt ? gt : end;
             if (cur && keep && stop > p) {
-                std::vector<uint8_t>& codes = cur->codes;
+                raw_vector<uint8_t>& codes = cur->codes;
                 const size_t at = codes.size();
                 codes.resize(at + (size_t)(stop - p));
                 uint8_t* w = codes.data() + at;

@@ -316,3 +316,77 @@ def test_rid_filter_releases_skipped_records(tmp_path):
         res[mode] = (int(n), int(rss))
     assert res["all"][0] == 1_500_000 and 0 < res["last"][0] < 40_000
     assert res["last"][1] < res["all"][1] + 100_000, res  # KiB: the inflated file is ~450 MB
+
+
+def _fasta_rules(data):
+    """The loader's rules, byte by byte: '>' outside a header line starts one (anywhere, not only at a line start), the name is
+    the header up to the first space or tab without a trailing CR, LF and CR are dropped from sequence, what precedes the first
+    header is ignored."""
+    out, i, n = [], 0, len(data)
+    cur = None
+    while i < n:
+        c = data[i:i + 1]
+        if c == b">":
+            j = data.find(b"\n", i)
+            j = n if j < 0 else j
+            hdr = data[i + 1:j].decode("latin-1")
+            name = hdr
+            for k, ch in enumerate(hdr):
+                if ch in " \t":
+                    name = hdr[:k]
+                    break
+            if name.endswith("\r"):
+                name = name[:-1]
+            cur = [name, bytearray()]
+            out.append(cur)
+            i = j + 1
+            continue
+        if cur is not None and c not in (b"\n", b"\r"):
+            cur[1].append({65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3, 85: 3, 117: 3}.get(data[i], 4))
+        i += 1
+    return [(nm, bytes(s)) for nm, s in out]
+
+
+@pytest.mark.parametrize("shape", ["plain", "crlf", "no_final_newline", "gt_inside", "junk_first", "empty_records", "big", "header_only_tail"])
+def test_fasta_loaders_agree_on_awkward_files(tmp_path, shape, monkeypatch):
+    rng = np.random.default_rng(17)
+    def seq(n, width=60, eol=b"\n"):
+        s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtnRYKMU", np.uint8), n))
+        return eol.join(s[i:i + width] for i in range(0, n, width)) + (eol if n else b"")
+    if shape == "plain":
+        data = b">chr1 first contig\n" + seq(1000) + b">chr2\tother\n" + seq(77, 10)
+    elif shape == "crlf":
+        data = b">chr1 x\r\n" + seq(500, 50, b"\r\n") + b">chr2\r\n" + seq(123, 50, b"\r\n")
+    elif shape == "no_final_newline":
+        data = (b">a\n" + seq(130))[:-1]
+    elif shape == "gt_inside":
+        data = b">a des>cription > with more\nACGT>b mid-line header\nGGCC\n>c\n" + seq(200)
+    elif shape == "junk_first":
+        data = b"ACGTACGT\n\n>a\n" + seq(90) + b"\n\n>b\n\n" + seq(61)
+    elif shape == "empty_records":
+        data = b">a\n>b\n>c x\n" + seq(10) + b">d\n"
+    elif shape == "header_only_tail":
+        data = b">a\n" + seq(100) + b">tail without newline"
+    else:  # several MB: many tasks and chunks, headers at chunk edges
+        parts = []
+        for k in range(40):
+            parts.append(b">ctg%d some text\n" % k + seq(int(rng.integers(1, 700_000)), int(rng.integers(20, 200))))
+        data = b"".join(parts)
+    path = str(tmp_path / "x.fa")
+    open(path, "wb").write(data)
+    want = _fasta_rules(data)
+    for sequential in (False, True):
+        if sequential:
+            monkeypatch.setenv("BQC_FASTA_SEQUENTIAL", "1")
+        got = hostio.load_fasta(path)
+        assert [n for n, _ in got] == [n for n, _ in want]
+        for (n, codes), (_, w) in zip(got, want):
+            assert codes.tobytes() == w, (shape, sequential, n)
+    # a gzip-compressed copy goes through the sequential loader on its own
+    monkeypatch.delenv("BQC_FASTA_SEQUENTIAL")
+    import gzip
+    gz = str(tmp_path / "x.fa.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(data)
+    got = hostio.load_fasta(gz)
+    assert [(n, c.tobytes()) for n, c in got] == want
