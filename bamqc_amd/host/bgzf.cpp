@@ -48,49 +48,63 @@ BgzfReader::~BgzfReader()
     if (f_) fclose(f_);
 }
 
-// A worker of the read-ahead: plans a run (file read + block walk: one worker at a time, in file order), inflates it, and hands
-// it on in file order.  Workers other than the first only take part while a GPU inflates (bgzf_gpu_inflate_device): the kernel's
-// time is the time a lane needs for its block whatever the number of blocks, so several moderate runs in flight (each with
-// its own stream and buffers) fill the card like one huge run would, with bounded, reusable host buffers; the CPU decoder uses
-// every host thread for one run anyway.
+// A worker of the read-ahead: plans a run (file read + block walk: one worker at a time, in file order), inflates it, and files
+// it; runs reach the consumer in file order whatever order they finish in.  Worker 0 inflates on the host (every host thread
+// on one run).  While a GPU inflates (bgzf_gpu_inflate_device) further workers run beside it, each with its own stream, device
+// buffers and page-locked bounce buffers: the card's share comes ON TOP of the host's — the kernel's time is the time a lane
+// needs for its block whatever the number of blocks, so several moderate runs in flight fill the card, and the waiting workers
+// sleep.  (The card alone is not faster than 16 host threads once the inflated bytes have to come back: csrc/gpu_inflate.hip.)
 void BgzfReader::read_ahead(int worker)
 {
-    raw_vector<uint8_t> raw;
+    raw_vector<uint8_t> raw, bounce;
     GpuInflater* gpu = nullptr;
     struct Bye { GpuInflater*& g; ~Bye() { if (g) bqc_gpu_inflater_destroy(g); } } bye{gpu};
+    const bool on_card = worker > 0;
     for (;;) {
         Item it;
         { // reuse a buffer the consumer has handed back: no fresh pages to fault in for every run
             std::lock_guard<std::mutex> lk(m_);
             if (!spare_.empty()) { it.data.swap(spare_.back()); spare_.pop_back(); }
         }
-        if (worker == 0 && g_gpu_device.load() >= 0 && !gpu_failed_.load()) { // a GPU has been switched on: the other workers start
-            static const int workers = getenv("BQC_GI_WORKERS") ? std::min(32, std::max(1, atoi(getenv("BQC_GI_WORKERS")))) : 6;
+        if (worker == 0 && g_gpu_device.load() >= 0 && !gpu_failed_.load()) { // a GPU has been switched on: its workers start
+            static const int workers = getenv("BQC_GI_WORKERS") ? std::min(31, std::max(0, atoi(getenv("BQC_GI_WORKERS")))) : 3;
             std::lock_guard<std::mutex> lk(m_);
-            if (!stop_ && ra_.size() == 1) for (int w = 1; w < workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
+            if (!stop_ && ra_.size() == 1) for (int w = 1; w <= workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
+        }
+        { // not too far ahead of the consumer (memory: every run in flight is ~100-200 MB)
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || ra_done_ || planned_ - popped_ < (ra_.size() > 1 ? kMaxAhead : 4u); });
+            if (stop_ || ra_done_) return;
         }
         Run run;
         uint64_t seq;
         {
             std::unique_lock<std::mutex> lk(plan_m_);
-            if (worker > 0) { // (they only take part while the card inflates)
+            if (on_card) { // (they only take part while the card inflates)
                 while (!plan_done_ && !stopping() && (g_gpu_device.load() < 0 || gpu_failed_.load())) { lk.unlock(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); lk.lock(); }
             }
             if (plan_done_ || stopping()) return;
             seq = plan_seq_++;
-            it.ok = plan_run(raw, run, it.err);
+            { std::lock_guard<std::mutex> lk2(m_); planned_ = plan_seq_; }
+            it.ok = plan_run(raw, run, it.err, on_card);
             if (!it.ok) plan_done_ = true;
         }
-        if (it.ok) it.ok = inflate_run(raw, run, it.data, it.err, gpu);
+        if (it.ok) it.ok = inflate_run(raw, run, it.data, it.err, on_card ? &gpu : nullptr, bounce);
         if (it.ok && it.data.empty() && run.last) it.ok = false; // (end of the file, nothing left)
         const bool last = !it.ok;
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return (pub_seq_ == seq && q_.size() < 3) || stop_ || ra_done_; });
-        if (stop_ || ra_done_) return; // (ra_done_: an earlier run has failed, what follows it is dropped)
-        q_.push_back(std::move(it));
-        ++pub_seq_;
-        if (last) ra_done_ = true;
-        cv_.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (stop_ || ra_done_) return; // (ra_done_: an earlier run has failed, what follows it is dropped)
+            done_.emplace(seq, std::move(it));
+            while (!done_.empty() && done_.begin()->first == pub_seq_ && !ra_done_) { // in file order
+                const bool fin = !done_.begin()->second.ok;
+                q_.push_back(std::move(done_.begin()->second));
+                done_.erase(done_.begin());
+                ++pub_seq_;
+                if (fin) { ra_done_ = true; done_.clear(); }
+            }
+            cv_.notify_all();
+        }
         if (last) {
             std::lock_guard<std::mutex> lk2(plan_m_);
             plan_done_ = true;
@@ -113,12 +127,13 @@ bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
     if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
     Item it = std::move(q_.front());
     q_.pop_front();
+    ++popped_;
     cv_.notify_all();
     lk.unlock();
     out.swap(it.data);
     if (it.data.capacity()) { // the caller's previous buffer goes back to the read-ahead thread
         std::lock_guard<std::mutex> lk2(m_);
-        if (spare_.size() < 4) spare_.emplace_back(std::move(it.data));
+        if (spare_.size() < (ra_.size() > 1 ? 12u : 4u)) spare_.emplace_back(std::move(it.data));
     }
     if (!it.ok) { err = it.err; out.clear(); return false; }
     return true;
@@ -197,17 +212,22 @@ uint64_t bgzf_find_block(const char* path, uint64_t hint, std::string& err)
 
 // The next run of whole blocks: reads the file (behind what the last run left over), walks the block headers.  false: nothing
 // more to read (err empty) or a malformed stream.
-bool BgzfReader::plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err)
+bool BgzfReader::plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err, bool on_card)
 {
     run = Run();
     if (eof_) { run.last = true; return false; }
     size_t want = std::max<size_t>((size_t)threads_ * 16 * kMaxBlock, 32u << 20); // compressed bytes per round
     // On the GPU a lane inflates a block: a run has to hold thousands of blocks to fill the card.
-    if (g_gpu_device.load() >= 0 && !gpu_failed_.load()) want = std::max<size_t>(want, gpu_run_bytes_);
+    if (on_card) want = std::max<size_t>(want, gpu_run_bytes_);
     if (mark_u_.load() != UINT64_MAX) want = 4 * kMaxBlock;                          // behind the mark: only the rest of a record is wanted
     // the tail of the previous round (a partial block) goes to the front
     const size_t have = tail_.size();
-    { const size_t cap = raw.capacity(); raw.resize(have + want); if (raw.capacity() != cap) advise_huge(raw); }
+    {
+        const size_t cap = raw.capacity();
+        if (on_card && cap < have + want) raw.reserve(have + want + (1u << 20)); // (page-locked once: it should not move again)
+        raw.resize(have + want);
+        if (raw.capacity() != cap) advise_huge(raw);
+    }
     if (have) memcpy(raw.data(), tail_.data(), have);
     const auto tt0 = std::chrono::steady_clock::now();
     size_t got = fread(raw.data() + have, 1, want, f_);
@@ -255,8 +275,10 @@ bool BgzfReader::plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err)
     return true;
 }
 
-// Inflates the blocks of a planned run into `out` and checks their CRC-32.
-bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, GpuInflater*& gpu)
+// Inflates the blocks of a planned run into `out` and checks their CRC-32.  gpu != nullptr: on the card — the inflated bytes
+// arrive in the worker's page-locked bounce buffer and are copied to `out` (a buffer that circulates between the workers and
+// the consumer) while their CRC is taken.
+bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, GpuInflater** gpu, raw_vector<uint8_t>& bounce)
 {
     static const bool gi_timing = getenv("BQC_GI_TIMING") != nullptr;
     const auto tt1 = std::chrono::steady_clock::now();
@@ -265,27 +287,33 @@ bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw
     std::atomic<bool> bad{false};
     bool on_gpu = false;
     const int gpu_dev = g_gpu_device.load();
-    if (gpu_dev >= 0 && !gpu && !gpu_failed_.load()) { gpu = bqc_gpu_inflater_create(gpu_dev); if (!gpu) gpu_failed_ = true; }
-    if (gpu && gpu_dev >= 0 && blocks.size() >= 256) {
-        if (bqc_raw_vector_pin_hook) { // page-locked: the copies run at the link's speed and without a staging pass
+    if (gpu && gpu_dev >= 0 && !*gpu && !gpu_failed_.load()) { *gpu = bqc_gpu_inflater_create(gpu_dev); if (!*gpu) gpu_failed_ = true; }
+    if (gpu && *gpu && gpu_dev >= 0 && blocks.size() >= 64) {
+        if (bounce.capacity() < run.utotal + 64) { bounce.clear(); bounce.reserve(run.utotal + run.utotal / 4 + (1u << 20)); advise_huge(bounce); }
+        bounce.resize(run.utotal);
+        if (bqc_raw_vector_pin_hook) { // page-locked: the copies run at the link's speed and the waiting thread sleeps
             bqc_raw_vector_pin_hook(raw.data(), raw.capacity());
-            bqc_raw_vector_pin_hook(out.data(), out.capacity());
+            bqc_raw_vector_pin_hook(bounce.data(), bounce.capacity());
         }
         std::vector<GiBlock> gb;
         gb.reserve(blocks.size());
         for (const BlockRef& b : blocks) if (b.usize) gb.push_back(GiBlock{b.off, b.uoff, (uint32_t)b.csize, (uint32_t)b.usize});
-        const int rc = bqc_gpu_inflate(gpu, raw.data(), run.consumed, gb.data(), gb.size(), out.data(), run.utotal);
+        const int rc = bqc_gpu_inflate(*gpu, raw.data(), run.consumed, gb.data(), gb.size(), bounce.data(), run.utotal);
         if (rc > 0) { err = "BGZF block failed to inflate (corrupt data)"; return false; }
-        if (rc < 0) { bqc_gpu_inflater_destroy(gpu); gpu = nullptr; gpu_failed_ = true; } // the card cannot be used: the CPU decoder takes over
+        if (rc < 0) { bqc_gpu_inflater_destroy(*gpu); *gpu = nullptr; gpu_failed_ = true; } // the card cannot be used: the CPU decoder takes over
         else { on_gpu = true; g_gpu_blocks += gb.size(); }
     }
     const auto tt2 = std::chrono::steady_clock::now();
-    parallel_for(blocks.size(), on_gpu ? std::min(threads_, 4u) : threads_, [&](size_t i) { // (on the GPU path several workers are at it at once)
+    parallel_for(blocks.size(), on_gpu ? std::min(threads_, 2u) : threads_, [&](size_t i) { // (the host's threads belong to worker 0)
         const BlockRef& b = blocks[i];
         if (b.usize == 0) return;
         const uint8_t* t = raw.data() + b.off + b.csize;
         const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
-        if (on_gpu) { if (bqc_crc32_fast(out.data() + b.uoff, b.usize) != crc) bad = true; return; }
+        if (on_gpu) {
+            if (bqc_crc32_fast(bounce.data() + b.uoff, b.usize) != crc) bad = true;
+            memcpy(out.data() + b.uoff, bounce.data() + b.uoff, b.usize);
+            return;
+        }
         static thread_local Inflater inf;
         // (the 8 bytes after the deflate data, which the decoder may load but not use, are the block's CRC32 / ISIZE)
         if (!inf.run(raw.data() + b.off, b.csize, out.data() + b.uoff, b.usize)) { bad = true; return; }
@@ -295,7 +323,7 @@ bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw
     if (gi_timing) {
         const auto tt3 = std::chrono::steady_clock::now();
         fprintf(stderr, "[bgzf run] read %.1f MB in %.2f ms, %s %.2f ms, %s %.2f ms\n", run.read_bytes / 1e6, run.read_ms, on_gpu ? "gpu inflate" : "-",
-                std::chrono::duration<double, std::milli>(tt2 - tt1).count(), on_gpu ? "crc" : "cpu inflate + crc", std::chrono::duration<double, std::milli>(tt3 - tt2).count());
+                std::chrono::duration<double, std::milli>(tt2 - tt1).count(), on_gpu ? "crc + copy" : "cpu inflate + crc", std::chrono::duration<double, std::milli>(tt3 - tt2).count());
     }
     return true;
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -34,8 +35,8 @@ public:
 private:
     struct BlockRef { size_t off, csize, usize, uoff; };
     struct Run { std::vector<BlockRef> blocks; size_t consumed = 0, utotal = 0, read_bytes = 0; double read_ms = 0; bool last = false; };
-    bool plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err);
-    bool inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, struct GpuInflater*& gpu);
+    bool plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err, bool on_card);
+    bool inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw_vector<uint8_t>& out, std::string& err, struct GpuInflater** gpu, raw_vector<uint8_t>& bounce);
     void read_ahead(int worker);
     bool stopping();
     struct Item { raw_vector<uint8_t> data; std::string err; bool ok = false; };
@@ -45,6 +46,9 @@ private:
     bool plan_done_ = false;
     std::vector<uint8_t> tail_;              // the partial block behind the last planned run
     uint64_t pub_seq_ = 0;                   // (under m_) runs are handed on in the order they were planned
+    std::map<uint64_t, Item> done_;          // (under m_) inflated runs waiting for their turn
+    uint64_t planned_ = 0, popped_ = 0;      // (under m_) runs planned / taken by the consumer
+    static const uint64_t kMaxAhead = 10;
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<Item> q_;
