@@ -17,13 +17,14 @@
 // match reads the lane's own output up to 32 KiB back, 13 K lanes x 64 KiB of output are far more than the L2 holds, and in every
 // iteration some lane of the wave has a match.  The kernel is latency-bound: its time is the time of one block (22 ms for 3.4 K
 // blocks, 32 ms for 13 K) until the card is full (76 lanes per CU with these tables: 19 K blocks), so the reader keeps several
-// moderate runs in flight (host/bgzf.cpp: one worker, stream and pair of page-locked buffers each).  End to end the program is
-// still SLOWER with it than with the host decoder: 10 M reads 0.86 s against 0.52 s, 40 M reads 2.09 s against 1.49 s — the
-// inflated bytes go back to the host (page-locking and first touch of the buffers they land in, the runtime's locks shared
-// with the batch pipeline's own copies), and the record decode that follows is host work either way.  What makes it pay is the
-// next step, not a faster copy: walk and decode the records on the card too (the inflated bytes never return), with the tables
-// cut to the canonical arrays alone (356 B per lane: 460 blocks per CU in flight, a whole 10 M-read file in one launch), and the
-// matches of a block resolved after its symbols are decoded (one round trip per match instead of one per symbol).
+// moderate runs in flight (host/bgzf.cpp: workers with a stream and page-locked bounce buffers each, beside the host's decoder).
+// End to end the program does NOT get faster with it: 10 M reads 0.59-0.69 s against 0.51-0.53 s, 40 M reads 1.62 s (two workers
+// on the card beside the host's 16 threads) against 1.52 s, 1.88 s with four — the inflated bytes go back to the host (copies,
+// the runtime's locks shared with the batch pipeline's own copies and allocations), and the record decode that follows is host
+// work either way.  What makes it pay is the next step, not a faster copy: walk and decode the records on the card too (the
+// inflated bytes never return), with the tables cut to the canonical arrays alone (356 B per lane: 460 blocks per CU in
+// flight, a whole 10 M-read file in one launch), and the matches of a block resolved after its symbols are decoded (one round
+// trip per match instead of one per symbol).
 //
 // Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
 // incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input

@@ -53,7 +53,8 @@ BgzfReader::~BgzfReader()
 // on one run).  While a GPU inflates (bgzf_gpu_inflate_device) further workers run beside it, each with its own stream, device
 // buffers and page-locked bounce buffers: the card's share comes ON TOP of the host's — the kernel's time is the time a lane
 // needs for its block whatever the number of blocks, so several moderate runs in flight fill the card, and the waiting workers
-// sleep.  (The card alone is not faster than 16 host threads once the inflated bytes have to come back: csrc/gpu_inflate.hip.)
+// sleep.  Measured, it does not pay yet (csrc/gpu_inflate.hip): the inflated bytes have to come back, and what the card's
+// workers add the host's lose to them (runtime locks, copies); the switch stays off by default.
 void BgzfReader::read_ahead(int worker)
 {
     raw_vector<uint8_t> raw, bounce;
@@ -67,7 +68,7 @@ void BgzfReader::read_ahead(int worker)
             if (!spare_.empty()) { it.data.swap(spare_.back()); spare_.pop_back(); }
         }
         if (worker == 0 && g_gpu_device.load() >= 0 && !gpu_failed_.load()) { // a GPU has been switched on: its workers start
-            static const int workers = getenv("BQC_GI_WORKERS") ? std::min(31, std::max(0, atoi(getenv("BQC_GI_WORKERS")))) : 3;
+            static const int workers = getenv("BQC_GI_WORKERS") ? std::min(31, std::max(0, atoi(getenv("BQC_GI_WORKERS")))) : 2;
             std::lock_guard<std::mutex> lk(m_);
             if (!stop_ && ra_.size() == 1) for (int w = 1; w <= workers; ++w) ra_.emplace_back([this, w] { read_ahead(w); });
         }
