@@ -57,6 +57,7 @@ _SIGNATURES = {
     "bqc_bam_write": (C.c_int, [C.c_char_p, C.POINTER(_abi.Batch), C.c_uint32, C.POINTER(C.c_char_p), _abi.u32p, C.c_uint32, C.c_uint64, C.c_int]),
     "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bqc_bam_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "bqc_bam_open_gpu": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "bqc_bam_range_begin_block": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_end_block": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_first": (C.c_uint64, [C.c_void_p]),

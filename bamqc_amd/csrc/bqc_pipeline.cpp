@@ -615,7 +615,7 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
     hipError_t he = hipSuccess;
     if (pinned_columns) {
         for (int k = 0; k < 13 && he == hipSuccess; ++k)
-            if (m.col_bytes[k]) he = hipMemcpyAsync(base + m.o_col[k], column_ptr(b, k), m.col_bytes[k], hipMemcpyHostToDevice, c->copy_stream);
+            if (m.col_bytes[k]) he = hipMemcpyAsync(base + m.o_col[k], column_ptr(b, k), m.col_bytes[k], hipMemcpyDefault, c->copy_stream); // (page-locked host memory or device memory)
     } else { // stage the columns: the caller may reuse its buffers on return
         struct Piece { char* dst; const char* src; size_t n; };
         Piece pc[13];

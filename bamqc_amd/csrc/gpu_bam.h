@@ -1,0 +1,35 @@
+// gpu_bam.h — BAM input decoded on the GPU (gpu_bam.hip): the compressed file goes to the card, the inflated bytes never come
+// back.  Same interface as the host reader (host/bam_io.h: RecordReader), same columns: the fixed ones arrive in the batch's
+// host arrays (the host pass of the aggregation needs them), the payload (bases, qualities, CIGARs) stays in device memory
+// (HostBatch::d_seq / d_qual / d_cigar — bqc_submit_async copies from wherever the columns live).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../host/bam_io.h"
+
+class GpuBamReader : public RecordReader {
+public:
+    // err_code of next_batch when this input needs the host reader instead (a read group that is not in the header, a record the
+    // host reader would report, a record walk that cannot be verified, ...): nothing has been reported to the user, the caller
+    // starts over with BamReader, which decides what is an error and what is not.
+    static const int kUnsupported = -1000;
+    GpuBamReader();
+    ~GpuBamReader() override;
+    // hdr / first_record_u: the header as the host reader parsed it, and the offset of the first record in the uncompressed stream
+    bool open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, std::string& err);
+    BamHeader& header() override { return hdr_; }
+    void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
+    int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
+    uint64_t records() const { return nrec_; }
+    double seconds_reading() const { return t_read_; } // time spent in fread
+
+private:
+    struct Impl;
+    Impl* p_ = nullptr;
+    BamHeader hdr_;
+    std::vector<uint8_t> main_;
+    uint64_t nrec_ = 0;
+    double t_read_ = 0;
+};

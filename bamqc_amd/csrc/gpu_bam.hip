@@ -1,0 +1,571 @@
+// gpu_bam.hip — BAM input decoded on the GPU (row N2 of the scope table, step 2: see gpu_bam.h).
+//
+//   file --fread--> page-locked buffer --H2D--> k_inflate + k_gi_crc (gpu_inflate.hip) --> the uncompressed stream, in device memory
+//        --> k_gb_walk: where the records are        --> k_gb_decode: the fixed columns + where each record's payload goes
+//        --> k_gb_copy: bases / qualities / CIGARs into packed columns (device)   --> D2H of the fixed columns only (26 B per read)
+//
+// The record chain (every record's start follows from the previous one's block_size) is walked the way the host reader walks it
+// in parallel (host/bam_io.cpp: parallel_prewalk): the window is cut into 16 KiB segments, a lane per segment GUESSES the first
+// record start in its segment (the first offset at which three records in a row look like records) and walks from there to the
+// segment's end; the host then checks, segment by segment, that every guess is exactly where the previous segment's walk
+// arrived — by induction from the known first record the chain is then the serial walk's.  A guess that is not (or a record
+// the host reader would report: corrupt, a read group that is not in the header, a second NM tag, ...) makes next_batch return
+// kUnsupported: the caller starts over with the host reader, which is the one to decide what the user is told.
+//
+// Record layout, tag types: the public SAM/BAM specification; the rules applied to a record are those of the host reader
+// (bam_io.cpp: next_batch, citing bamqualcheck.cpp:72-100 getLane, QualityCheck.hpp:201-209 NM, TripletCounting.hpp:113-127 AS).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "../../include/bamqc.h"
+#include "gpu_bam.h"
+#include "gpu_inflate.h"
+#include "../host/parallel.h"
+
+#define GB_SEG 16384u
+#define GB_MAXR (GB_SEG / 36u + 1u)
+
+enum { GB_INCOMPLETE = 1, GB_CORRUPT = 2, GB_NO_START = 4 };
+// exceptions a record can raise (status word): the host reader handles all of them
+enum { GBX_TAGS = 1 << 8, GBX_RG_MISSING = 1 << 9, GBX_RG_TYPE = 1 << 10, GBX_RG_UNKNOWN = 1 << 11, GBX_NM_EXTRA = 1 << 12, GBX_NM_VALUE = 1 << 13, GBX_LANE = 1 << 14 };
+
+struct GbSeg { uint32_t first, exit, count, flags, seq_bytes, qual_bytes, cigar_words, pad; }; // offsets relative to the window
+struct GbRec { uint32_t off, so, qo, co; };                                                     // payload prefix inside the segment
+struct GbBase { uint64_t so, qo, co; uint32_t rec, take; };                                    // where a taken segment's records / payload start in the batch
+struct GbCols { // device copies of the fixed columns + per-record payload placement
+    uint16_t* flag; uint8_t* mapq; uint8_t* lane; int32_t* rid; int32_t* pos; int32_t* tlen; int32_t* nm; int32_t* as; uint32_t* l_seq; uint16_t* n_cigar;
+    uint32_t* rec_off; uint64_t* so; uint64_t* qo; uint64_t* co;
+};
+struct GbLanes { const uint8_t* blob; const uint32_t* off; const uint32_t* len; const uint32_t* index; uint32_t n, lane_count; };
+
+typedef uint32_t __attribute__((aligned(1))) gb_u32_u;
+typedef uint16_t __attribute__((aligned(1))) gb_u16_u;
+
+namespace {
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *(const gb_u32_u*)p; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return *(const gb_u16_u*)p; }
+
+// host/bam_io.cpp: plausible_record
+__device__ bool gb_plausible(const uint8_t* base, uint64_t avail, uint64_t p, int32_t n_ref, uint64_t& next)
+{
+    if (p + 36 > avail) return false;
+    const uint32_t bs = ld32(base + p);
+    if (bs < 32u || bs > (1u << 28)) return false;
+    const uint8_t* r = base + p + 4;
+    const int32_t rid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4), rnext = (int32_t)ld32(r + 20), pnext = (int32_t)ld32(r + 24);
+    if (rid < -1 || rid >= n_ref || rnext < -1 || rnext >= n_ref || pos < -1 || pnext < -1) return false;
+    const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+    if (l_name == 0 || l_seq > (1u << 28)) return false;
+    const uint64_t var = 32ull + l_name + 4ull * n_cig + (l_seq + 1u) / 2u + l_seq;
+    if (var > bs) return false;
+    if (p + 4 + 32 + l_name <= avail && r[32 + l_name - 1] != 0) return false; // read name is NUL-terminated
+    next = p + 4 + bs;
+    return true;
+}
+} // namespace
+
+// lane per segment: first record start (segment 0: the window's start, which is one), then the chain up to the segment's end
+// (seg0, exact: the segments from seg0 on, the first of them from the known record start `exact` — the whole window is
+// (0, 0); a segment whose guess turned out wrong is walked again alone from where the chain arrives)
+__global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base, uint64_t avail, uint32_t seg0, uint32_t nseg, uint64_t exact, int32_t n_ref,
+                                                 GbSeg* __restrict__ segs, GbRec* __restrict__ recs)
+{
+    const uint32_t s = seg0 + blockIdx.x * 64 + threadIdx.x;
+    if (s >= seg0 + nseg) return;
+    const uint64_t a = (uint64_t)s * GB_SEG, b = min(avail, a + GB_SEG);
+    GbSeg S{};
+    uint64_t p = s == seg0 ? exact : a;
+    if (s != seg0) {
+        for (; p < b; ++p) {
+            uint64_t q1, q2, q3;
+            if (gb_plausible(base, avail, p, n_ref, q1) && gb_plausible(base, avail, q1, n_ref, q2) && gb_plausible(base, avail, q2, n_ref, q3)) break;
+        }
+        if (p >= b) { S.first = S.exit = 0xFFFFFFFFu; S.flags = GB_NO_START; segs[s] = S; return; }
+    }
+    S.first = (uint32_t)p;
+    GbRec* out = recs + (size_t)s * GB_MAXR;
+    uint32_t so = 0, qo = 0, co = 0, n = 0;
+    while (p < b) {
+        if (p + 36 > avail) { S.flags |= GB_INCOMPLETE; break; }
+        const uint32_t bs = ld32(base + p);
+        if (bs < 32u) { S.flags |= GB_CORRUPT; break; }
+        const uint8_t* r = base + p + 4;
+        const uint32_t l_name = r[8], n_cig = ld16(r + 12), l_seq = ld32(r + 16);
+        const uint64_t var = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1u) / 2u + l_seq;
+        if (var > bs) { S.flags |= GB_CORRUPT; break; }
+        if (p + 4 + bs > avail) { S.flags |= GB_INCOMPLETE; break; }
+        out[n] = GbRec{(uint32_t)p, so, qo, co};
+        so += (l_seq + 1u) / 2u; qo += l_seq; co += n_cig;
+        ++n;
+        p += 4ull + bs;
+    }
+    S.exit = (uint32_t)min(p, (uint64_t)0xFFFFFFFEu);
+    S.count = n; S.seq_bytes = so; S.qual_bytes = qo; S.cigar_words = co;
+    segs[s] = S;
+}
+
+// workgroup per taken segment, thread per record: the fixed columns and the tag scan of host/bam_io.cpp
+__global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ base, const GbSeg* __restrict__ segs, const GbRec* __restrict__ recs,
+                                                   const GbBase* __restrict__ bases, GbCols C, GbLanes LN, const uint8_t* __restrict__ main_chrom, uint32_t n_main,
+                                                   uint32_t* __restrict__ status)
+{
+    const uint32_t s = blockIdx.x;
+    const GbBase B = bases[s];
+    if (!B.take) return;
+    const uint32_t count = segs[s].count;
+    uint32_t exc = 0;
+    for (uint32_t slot = threadIdx.x; slot < count; slot += 64) {
+        const GbRec R = recs[(size_t)s * GB_MAXR + slot];
+        const uint32_t i = B.rec + slot;
+        const uint8_t* r = base + R.off + 4;
+        const uint32_t bs = ld32(r - 4);
+        const int32_t rid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+        const uint32_t l_name = r[8], mapq = r[9], n_cig = ld16(r + 12), flag = ld16(r + 14), l_seq = ld32(r + 16);
+        const int32_t rnext = (int32_t)ld32(r + 20), tlen = (int32_t)ld32(r + 28);
+        const uint8_t* ql = r + 32 + l_name + 4ull * n_cig + (l_seq + 1u) / 2u;
+        const uint8_t* tg = ql + l_seq;
+        const uint8_t* te = r + bs;
+        int lane = -1;
+        bool rg_seen = false, as_seen = false, nm_seen = false;
+        int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
+        while (tg + 3 <= te) {
+            const char k0 = (char)tg[0], k1 = (char)tg[1], ty = (char)tg[2];
+            const uint8_t* v = tg + 3;
+            uint64_t len = 0;
+            switch (ty) {
+            case 'A': case 'c': case 'C': len = 1; break;
+            case 's': case 'S': len = 2; break;
+            case 'i': case 'I': case 'f': len = 4; break;
+            case 'Z': case 'H': {
+                const uint8_t* z = v;
+                while (z < te && *z) ++z;
+                len = z < te ? (uint64_t)(z - v) + 1 : (uint64_t)(te - v);
+                break;
+            }
+            case 'B': {
+                if (v + 5 > te) { len = (uint64_t)(te - v); break; }
+                const char st = (char)v[0];
+                const uint64_t cnt = ld32(v + 1);
+                const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                len = 5 + cnt * es;
+                break;
+            }
+            default: len = (uint64_t)(te - v); break;
+            }
+            if (len > (uint64_t)(te - v)) { exc |= GBX_TAGS; break; }
+            if (k0 == 'R' && k1 == 'G' && !rg_seen) {
+                rg_seen = true;
+                if (ty == 'Z') {
+                    const uint32_t idl = len ? (uint32_t)len - 1 : 0;
+                    for (uint32_t l = 0; l < LN.n && lane < 0; ++l) {
+                        if (LN.len[l] != idl) continue;
+                        const uint8_t* id = LN.blob + LN.off[l];
+                        uint32_t k = 0;
+                        while (k < idl && id[k] == v[k]) ++k;
+                        if (k == idl) lane = (int)LN.index[l];
+                    }
+                    if (lane < 0) { exc |= GBX_RG_UNKNOWN; lane = 0; }
+                } else exc |= GBX_RG_TYPE;
+            } else if (k0 == 'N' && k1 == 'M' && (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I')) {
+                uint32_t x;
+                switch (ty) {
+                case 'c': x = (uint32_t)(int32_t)(int8_t)v[0]; break;
+                case 'C': x = v[0]; break;
+                case 's': x = (uint32_t)(int32_t)(int16_t)ld16(v); break;
+                case 'S': x = ld16(v); break;
+                default: x = ld32(v); break;
+                }
+                if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
+                else exc |= GBX_NM_EXTRA;
+            } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
+                as_seen = true;
+                switch (ty) {
+                case 'A': as = (int32_t)(char)v[0]; break;
+                case 'c': as = (int8_t)v[0]; break;
+                case 'C': as = v[0]; break;
+                case 's': as = (int16_t)ld16(v); break;
+                case 'S': as = (int32_t)ld16(v); break;
+                case 'i': case 'I': as = (int32_t)ld32(v); break;
+                case 'f': as = (int32_t)__uint_as_float(ld32(v)); break;
+                default: as = BQC_AS_ABSENT; break;
+                }
+            }
+            tg = v + len;
+        }
+        if (!rg_seen) exc |= GBX_RG_MISSING;
+        else if ((uint32_t)lane >= LN.lane_count) exc |= GBX_LANE;
+        if (nm_seen && nm == BQC_NM_ABSENT) exc |= GBX_NM_VALUE;
+        uint32_t f = flag & 0x0FFFu;
+        if (rnext >= 0 && (uint32_t)rnext < n_main && main_chrom[rnext]) f |= BQC_FLAG_MATE_MAIN;
+        if (l_seq > 0 && ql[0] == 0xFF) f |= BQC_FLAG_NO_QUAL;
+        C.flag[i] = (uint16_t)f; C.mapq[i] = (uint8_t)mapq; C.lane[i] = (uint8_t)(lane < 0 ? 0 : lane); C.rid[i] = rid; C.pos[i] = pos; C.tlen[i] = tlen;
+        C.nm[i] = nm; C.as[i] = as; C.l_seq[i] = l_seq; C.n_cigar[i] = (uint16_t)n_cig;
+        C.rec_off[i] = R.off; C.so[i] = B.so + R.so; C.qo[i] = B.qo + R.qo; C.co[i] = B.co + R.co;
+    }
+    if (exc) atomicOr(status, exc);
+}
+
+// wave per record: CIGAR words, packed bases and qualities into the batch's packed columns
+__global__ __launch_bounds__(256) void k_gb_copy(const uint8_t* __restrict__ base, GbCols C, uint32_t n, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
+                                                  uint8_t* __restrict__ cigar /* bytes */)
+{
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= n) return;
+    const uint8_t* r = base + C.rec_off[i] + 4;
+    const uint32_t l_name = r[8], n_cig = C.n_cigar[i], l_seq = C.l_seq[i];
+    const uint8_t* cg = r + 32 + l_name;
+    const uint8_t* sq = cg + 4ull * n_cig;
+    const uint8_t* ql = sq + (l_seq + 1u) / 2u;
+    uint8_t* dc = cigar + 4ull * C.co[i];
+    uint8_t* ds = seq + C.so[i];
+    uint8_t* dq = qual + C.qo[i];
+    for (uint32_t k = lane; k < 4u * n_cig; k += 64) dc[k] = cg[k];
+    for (uint32_t k = lane; k < (l_seq + 1u) / 2u; k += 64) ds[k] = sq[k];
+    for (uint32_t k = lane; k < l_seq; k += 64) dq[k] = ql[k];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+namespace {
+template <typename T> struct DevBuf { // grows, never shrinks
+    T* p = nullptr;
+    size_t cap = 0;
+    bool need(size_t n)
+    {
+        if (cap >= n) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = n + n / 4 + 64;
+        if (hipMalloc((void**)&p, c * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
+        cap = c;
+        return true;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool need(size_t n)
+    {
+        if (cap >= n) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = n + n / 4 + 64;
+        if (hipHostMalloc((void**)&p, c * sizeof(T), hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = c;
+        return true;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+void dev_free_hook(void* p) { (void)hipFree(p); }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+} // namespace
+
+struct GpuBamReader::Impl {
+    int device = 0;
+    hipStream_t s = nullptr;
+    hipEvent_t ev = nullptr, ev_copy = nullptr; // blocking
+    FILE* f = nullptr;
+    bool file_eof = false;
+    uint64_t skip_u = 0;                 // uncompressed bytes in front of the first record, still to be dropped
+    size_t run_bytes = 128u << 20;       // compressed bytes per run
+    PinBuf<uint8_t> raw;                 // the run's compressed bytes (tail of the previous read in front)
+    size_t raw_have = 0;                 // bytes of a partial block kept from the previous read
+    DevBuf<uint8_t> d_comp;
+    PinBuf<GiBlock> h_blocks; DevBuf<GiBlock> d_blocks;
+    PinBuf<uint32_t> h_crc; DevBuf<uint32_t> d_crc;
+    DevBuf<uint8_t> d_stream;            // the uncompressed stream: valid bytes [cur, end)
+    size_t cur = 0, end = 0;
+    uint32_t* d_status = nullptr;
+    uint32_t* h_status = nullptr;
+    DevBuf<GbSeg> d_seg; PinBuf<GbSeg> h_seg;
+    DevBuf<GbRec> d_rec;
+    DevBuf<GbBase> d_base; PinBuf<GbBase> h_base;
+    // fixed columns on the device, one allocation
+    DevBuf<uint8_t> d_cols;
+    // lanes / main chromosomes
+    DevBuf<uint8_t> d_lane_blob; DevBuf<uint32_t> d_lane_tab; uint32_t n_lane_ids = 0, lane_count = 0;
+    DevBuf<uint8_t> d_main; uint32_t n_main = 0; bool main_set = false;
+    int32_t n_ref = 0;
+    double avg_rec_bytes = 0, avg_rec_bases = 0;
+    bool timing = false;
+    double t_read = 0;
+    uint64_t n_rewalk = 0;
+
+    ~Impl()
+    {
+        (void)hipSetDevice(device);
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (ev) (void)hipEventDestroy(ev);
+        if (ev_copy) (void)hipEventDestroy(ev_copy);
+        if (d_status) (void)hipFree(d_status);
+        if (h_status) (void)hipHostFree(h_status);
+        if (f) fclose(f);
+    }
+    bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
+    // reads the next run of whole BGZF blocks, inflates it behind `end`; 1: done, 0: end of the file, -1: I/O error / malformed (err), -2: device
+    int add_run(std::string& err);
+};
+
+GpuBamReader::GpuBamReader() {}
+GpuBamReader::~GpuBamReader() { delete p_; }
+
+bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, std::string& err)
+{
+    hdr_ = hdr;
+    delete p_;
+    p_ = new Impl();
+    Impl& I = *p_;
+    I.device = device;
+    I.timing = getenv("BQC_GB_TIMING") != nullptr;
+    if (const char* e = getenv("BQC_GB_RUN_MB")) I.run_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev_copy, hipEventBlockingSync | hipEventDisableTiming);
+    if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
+    if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
+    I.f = fopen(path, "rb");
+    if (!I.f) { err = std::string("could not open ") + path; return false; }
+    setvbuf(I.f, nullptr, _IONBF, 0);
+    I.skip_u = first_record_u;
+    I.n_ref = (int32_t)hdr.ref_names.size();
+    // read-group ids -> lane index
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> tab; // [off][len][index] x n
+    for (const auto& kv : hdr.lane_names) {
+        tab.push_back((uint32_t)blob.size()); tab.push_back((uint32_t)kv.first.size()); tab.push_back(kv.second);
+        blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+    }
+    I.n_lane_ids = (uint32_t)hdr.lane_names.size();
+    I.lane_count = hdr.lane_count;
+    // stored column-wise: off[n] len[n] index[n]
+    std::vector<uint32_t> cols(3 * (size_t)I.n_lane_ids + 1);
+    for (uint32_t l = 0; l < I.n_lane_ids; ++l) { cols[l] = tab[3 * l]; cols[I.n_lane_ids + l] = tab[3 * l + 1]; cols[2 * I.n_lane_ids + l] = tab[3 * l + 2]; }
+    if (!I.d_lane_blob.need(blob.size() + 1) || !I.d_lane_tab.need(cols.size())) { err = "GPU reader: out of device memory"; return false; }
+    if (!blob.empty()) (void)hipMemcpy(I.d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
+    return true;
+}
+
+int GpuBamReader::Impl::add_run(std::string& err)
+{
+    if (file_eof && raw_have == 0) return 0;
+    const size_t kMaxBlock = 65536;
+    if (!raw.need(raw_have + run_bytes + 64)) return -2;
+    size_t got = 0;
+    if (!file_eof) {
+        const double t0 = now_s();
+        got = fread(raw.p + raw_have, 1, run_bytes, f);
+        t_read += now_s() - t0;
+        if (got < run_bytes) file_eof = true;
+    }
+    const size_t have = raw_have + got;
+    // block headers (host/bgzf.cpp: plan_run — same checks)
+    if (!h_blocks.need(have / 28 + 2) || !h_crc.need(have / 28 + 2)) return -2;
+    size_t p = 0, utotal = 0, nb = 0;
+    while (p + 18 <= have) {
+        const uint8_t* h = raw.p + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF stream (bad gzip member header)"; return -1; }
+        const size_t xlen = h[10] | (h[11] << 8);
+        if (p + 12 + xlen > have) break;
+        size_t bsize = 0, x = 12;
+        while (x + 4 <= 12 + xlen) {
+            const size_t slen = h[x + 2] | (h[x + 3] << 8);
+            if (x + 4 + slen > 12 + xlen) { err = "corrupt BGZF block (extra subfield runs past the extra field)"; return -1; }
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize) { err = "BGZF block without BC extra field"; return -1; }
+        if (bsize < 12 + xlen + 8) { err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; return -1; }
+        if (p + bsize > have) break;
+        const uint8_t* t = raw.p + p + bsize - 8;
+        const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
+        if (isize > kMaxBlock) { err = "BGZF block larger than 64 KiB"; return -1; }
+        if (isize) {
+            h_blocks.p[nb] = GiBlock{p + 12 + xlen, utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
+            h_crc.p[nb] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            ++nb;
+        }
+        utotal += isize;
+        p += bsize;
+    }
+    if (file_eof && p != have) { err = "truncated BGZF file"; return -1; }
+    if (p == 0 && !file_eof) { err = "BGZF block larger than the read window"; return -1; }
+    // room behind `end`: move what is left to the front first, grow if that is not enough
+    if (end + utotal + 64 > d_stream.cap) {
+        const size_t live = end - cur;
+        if (live + utotal + 64 <= d_stream.cap && cur >= live) { // (non-overlapping copy)
+            if (live && hipMemcpyAsync(d_stream.p, d_stream.p + cur, live, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
+        } else {
+            uint8_t* np = nullptr;
+            const size_t ncap = std::max<size_t>(2 * (live + utotal), (size_t)3 << 29) + 64;
+            if (hipMalloc((void**)&np, ncap) != hipSuccess) return -2;
+            if (live && hipMemcpyAsync(np, d_stream.p + cur, live, hipMemcpyDeviceToDevice, s) != hipSuccess) { (void)hipFree(np); return -2; }
+            if (!sync()) { (void)hipFree(np); return -2; }
+            if (d_stream.p) (void)hipFree(d_stream.p);
+            d_stream.p = np; d_stream.cap = ncap;
+        }
+        cur = 0; end = live;
+    }
+    for (size_t i = 0; i < nb; ++i) h_blocks.p[i].uoff += end;
+    if (!d_comp.need(p + 64) || !d_blocks.need(nb + 1) || !d_crc.need(nb + 1)) return -2;
+    hipError_t he = hipSuccess;
+    if (p) he = hipMemcpyAsync(d_comp.p, raw.p, p, hipMemcpyHostToDevice, s);
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(d_blocks.p, h_blocks.p, nb * sizeof(GiBlock), hipMemcpyHostToDevice, s);
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(d_crc.p, h_crc.p, nb * 4, hipMemcpyHostToDevice, s);
+    if (he == hipSuccess) he = hipEventRecord(ev_copy, s);
+    if (he != hipSuccess) return -2;
+    bqc_gpu_inflate_launch(d_comp.p, d_blocks.p, (uint32_t)nb, d_stream.p, d_crc.p, d_status, s);
+    // the host buffers are reused by the next run: wait for the copies (the kernels go on)
+    if (hipEventSynchronize(ev_copy) != hipSuccess) return -2;
+    end += utotal;
+    if (skip_u) { const size_t k = (size_t)std::min<uint64_t>(skip_u, end - cur); cur += k; skip_u -= k; }
+    raw_have = have - p;
+    if (raw_have) memmove(raw.p, raw.p + p, raw_have);
+    return 1;
+}
+
+int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std::string& err, int& err_code)
+{
+    o.clear();
+    err_code = 0;
+    Impl& I = *p_;
+    if (hipSetDevice(I.device) != hipSuccess) { err = "GPU reader: device lost"; err_code = BQC_ERR_DEVICE; return -1; }
+    auto fail_dev = [&](const char* what) { err = std::string("GPU reader: ") + what; err_code = BQC_ERR_DEVICE; return -1; };
+    auto unsupported = [&](const char* why) { err = std::string("GPU reader hands over to the host reader: ") + why; err_code = kUnsupported; return -1; };
+    if (!I.main_set) {
+        I.n_main = (uint32_t)main_.size();
+        if (!I.d_main.need(main_.size() + 1)) return fail_dev("out of device memory");
+        if (!main_.empty() && hipMemcpy(I.d_main.p, main_.data(), main_.size(), hipMemcpyHostToDevice) != hipSuccess) return fail_dev("copy failed");
+        I.main_set = true;
+    }
+    const double t0 = now_s();
+    double want = (double)std::min<size_t>(max_reads, 1u << 22) * (I.avg_rec_bytes > 0 ? I.avg_rec_bytes : 340.0) * 1.03;
+    if (I.avg_rec_bases > 0) want = std::min(want, ((double)max_bases / I.avg_rec_bases + 1.0) * I.avg_rec_bytes * 1.03);
+    want = std::min(want, 2.5e9);
+    for (int attempt = 0;; ++attempt) {
+        while ((double)(I.end - I.cur) < want + (I.skip_u ? (double)I.skip_u : 0.0)) {
+            const int rc = I.add_run(err);
+            if (rc == 0) break;
+            if (rc == -1) { err_code = BQC_ERR_IO; return -1; }
+            if (rc == -2) return fail_dev("out of memory or a failed copy");
+        }
+        const uint64_t avail = I.end - I.cur;
+        if (avail == 0) {
+            if (!I.sync()) return fail_dev("synchronisation failed");
+            if (hipMemcpy(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail_dev("copy failed");
+            if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
+            return I.skip_u ? unsupported("the file ends inside its header") : 0;
+        }
+        if (avail > 0xFFFF0000ull) return unsupported("window too large");
+        const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
+        if (!I.d_seg.need(nseg) || !I.h_seg.need(nseg) || !I.d_rec.need((size_t)nseg * GB_MAXR) || !I.d_base.need(nseg) || !I.h_base.need(nseg)) return fail_dev("out of device memory");
+        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, I.d_stream.p + I.cur, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
+        if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess ||
+            hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync())
+            return fail_dev("walk failed");
+        if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
+        // the chain, segment by segment; whole segments are taken while the batch has room
+        uint64_t pos = 0, n = 0, bases = 0, so = 0, qo = 0, co = 0;
+        uint32_t last_taken = 0;
+        bool open_end = false; // the chain stopped at a record that is not complete yet (or the batch is full)
+        for (uint32_t s = 0; s < nseg; ++s) {
+            GbBase& B = I.h_base.p[s];
+            B = GbBase{so, qo, co, (uint32_t)n, 0};
+            const uint64_t seg_end = std::min<uint64_t>(avail, (uint64_t)(s + 1) * GB_SEG);
+            if (pos >= seg_end) continue; // the previous record runs through this segment
+            GbSeg& S = I.h_seg.p[s];
+            if ((S.flags & GB_NO_START) || S.first != pos) { // the guess is not where the chain arrives (or there was none): this segment again, from there
+                ++I.n_rewalk;
+                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, I.d_stream.p + I.cur, avail, s, 1u, pos, I.n_ref, I.d_seg.p, I.d_rec.p);
+                if (hipMemcpyAsync(&S, I.d_seg.p + s, sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
+                if (S.first != pos) return unsupported("the record walk could not be verified");
+            }
+            if (S.flags & GB_CORRUPT) return unsupported("a record the host reader will report");
+            if (n && (n + S.count > max_reads || bases >= max_bases)) { open_end = true; break; }
+            B.take = 1;
+            last_taken = s + 1;
+            n += S.count; bases += S.qual_bytes; so += S.seq_bytes; qo += S.qual_bytes; co += S.cigar_words;
+            pos = S.exit;
+            if (S.flags & GB_INCOMPLETE) { open_end = true; break; }
+        }
+        (void)open_end;
+        if (n == 0) { // not one complete record in the window: more data (a batch may be smaller than asked for, never empty)
+            if ((I.file_eof && I.raw_have == 0) || attempt > 16) return unsupported("the file ends inside a record");
+            want = (double)avail + (double)I.run_bytes;
+            continue;
+        }
+        if (n > 0xFFFFFFF0ull) return unsupported("batch too large");
+        // columns
+        const size_t N = (size_t)n;
+        o.flag.resize(N); o.mapq.resize(N); o.lane.resize(N); o.rid.resize(N); o.pos.resize(N); o.tlen.resize(N);
+        o.nm.resize(N); o.as.resize(N); o.l_seq.resize(N); o.n_cigar.resize(N);
+        if (bqc_raw_vector_pin_hook) {
+            bqc_raw_vector_pin_hook(o.flag.data(), o.flag.capacity() * 2); bqc_raw_vector_pin_hook(o.mapq.data(), o.mapq.capacity()); bqc_raw_vector_pin_hook(o.lane.data(), o.lane.capacity());
+            bqc_raw_vector_pin_hook(o.rid.data(), o.rid.capacity() * 4); bqc_raw_vector_pin_hook(o.pos.data(), o.pos.capacity() * 4); bqc_raw_vector_pin_hook(o.tlen.data(), o.tlen.capacity() * 4);
+            bqc_raw_vector_pin_hook(o.nm.data(), o.nm.capacity() * 4); bqc_raw_vector_pin_hook(o.as.data(), o.as.capacity() * 4); bqc_raw_vector_pin_hook(o.l_seq.data(), o.l_seq.capacity() * 4);
+            bqc_raw_vector_pin_hook(o.n_cigar.data(), o.n_cigar.capacity() * 2);
+        }
+        // device columns: [rid pos tlen nm as l_seq rec_off](4 B) [so qo co](8 B) [flag n_cigar](2 B) [mapq lane](1 B)
+        const size_t Np = (N + 63) & ~(size_t)63;
+        if (!I.d_cols.need(Np * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256)) return fail_dev("out of device memory");
+        GbCols C;
+        {
+            uint8_t* q = I.d_cols.p;
+            C.so = (uint64_t*)q; q += Np * 8; C.qo = (uint64_t*)q; q += Np * 8; C.co = (uint64_t*)q; q += Np * 8;
+            C.rid = (int32_t*)q; q += Np * 4; C.pos = (int32_t*)q; q += Np * 4; C.tlen = (int32_t*)q; q += Np * 4; C.nm = (int32_t*)q; q += Np * 4;
+            C.as = (int32_t*)q; q += Np * 4; C.l_seq = (uint32_t*)q; q += Np * 4; C.rec_off = (uint32_t*)q; q += Np * 4;
+            C.flag = (uint16_t*)q; q += Np * 2; C.n_cigar = (uint16_t*)q; q += Np * 2;
+            C.mapq = q; q += Np; C.lane = q;
+        }
+        // the batch's payload buffer on the device: [seq][qual][cigar], 512 spare bytes behind each (the kernels' vector loads)
+        const size_t o_seq = 0, o_qual = (so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255), total = o_cig + 4 * co + 512;
+        if (o.dev_cap < total) {
+            if (o.dev_mem) (void)hipFree(o.dev_mem);
+            o.dev_mem = nullptr; o.dev_cap = 0;
+            const size_t cap = total + total / 8 + 4096;
+            if (hipMalloc(&o.dev_mem, cap) != hipSuccess) { o.dev_mem = nullptr; return fail_dev("out of device memory"); }
+            o.dev_cap = cap;
+            o.dev_free = dev_free_hook;
+        }
+        uint8_t* pay = (uint8_t*)o.dev_mem;
+        const uint8_t* base = I.d_stream.p + I.cur;
+        GbLanes LN{I.d_lane_blob.p, I.d_lane_tab.p, I.d_lane_tab.p + I.n_lane_ids, I.d_lane_tab.p + 2 * (size_t)I.n_lane_ids, I.n_lane_ids, I.lane_count};
+        hipError_t he = hipMemcpyAsync(I.d_base.p, I.h_base.p, (size_t)last_taken * sizeof(GbBase), hipMemcpyHostToDevice, I.s);
+        if (he != hipSuccess) return fail_dev("copy failed");
+        hipLaunchKernelGGL(k_gb_decode, dim3(last_taken), dim3(64), 0, I.s, base, I.d_seg.p, I.d_rec.p, I.d_base.p, C, LN, I.d_main.p, I.n_main, I.d_status);
+        hipLaunchKernelGGL(k_gb_copy, dim3((uint32_t)((N + 3) / 4)), dim3(256), 0, I.s, base, C, (uint32_t)N, pay + o_seq, pay + o_qual, pay + o_cig);
+        he = hipMemcpyAsync(o.flag.data(), C.flag, N * 2, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.n_cigar.data(), C.n_cigar, N * 2, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.mapq.data(), C.mapq, N, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.lane.data(), C.lane, N, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.rid.data(), C.rid, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.pos.data(), C.pos, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.tlen.data(), C.tlen, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.nm.data(), C.nm, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.as.data(), C.as, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(o.l_seq.data(), C.l_seq, N * 4, hipMemcpyDeviceToHost, I.s);
+        if (he == hipSuccess) he = hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s);
+        if (he != hipSuccess || !I.sync()) return fail_dev("decode failed");
+        if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
+        if (*I.h_status & ~15u) return unsupported("a record the host reader handles (read group / tags)");
+        o.d_seq = pay + o_seq; o.d_qual = pay + o_qual; o.d_cigar = (const uint32_t*)(pay + o_cig);
+        I.cur += pos;
+        nrec_ += n;
+        I.avg_rec_bytes = (double)pos / (double)n;
+        I.avg_rec_bases = (double)bases / (double)n;
+        t_read_ = I.t_read;
+        if (I.timing) fprintf(stderr, "[gpu reader] batch of %zu records (%.1f MB of the stream): %.1f ms (reading so far %.3f s)\n", N, pos / 1e6, (now_s() - t0) * 1e3, I.t_read);
+        return 1;
+    }
+}

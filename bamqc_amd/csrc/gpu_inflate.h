@@ -10,12 +10,15 @@ struct GiBlock {      // one BGZF block's deflate stream
     uint32_t usize;   // ISIZE: the bytes it must inflate to
 };
 
-enum { GI_ERR_DATA = 1, GI_ERR_TRUNC = 2, GI_ERR_SIZE = 4 };
+enum { GI_ERR_DATA = 1, GI_ERR_TRUNC = 2, GI_ERR_SIZE = 4, GI_ERR_CRC = 8 };
 
 struct GpuInflater;
 extern "C" {
 GpuInflater* bqc_gpu_inflater_create(int device); // nullptr: no such device
 void bqc_gpu_inflater_destroy(GpuInflater* g);
 // 0: every block inflated to exactly its usize bytes; > 0: GI_ERR_* bits (corrupt data); < 0: the GPU could not be used
+// device-resident operands, asynchronous on `stream` (a hipStream_t): inflates, and with d_crc (the blocks' expected CRC-32s) checks;
+// *d_status collects GI_ERR_* bits
+void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, void* stream);
 int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_bytes, const GiBlock* blocks, size_t n_blocks, uint8_t* out, size_t out_bytes);
 }

@@ -304,6 +304,81 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate(const uint8_t*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// CRC-32 of the inflated blocks on the card (for readers that keep the inflated bytes there: csrc/gpu_bam.hip)
+// ---------------------------------------------------------------------------------------------------
+// A wave per block: lane 0 takes the first usize - 63 L bytes, every other lane L = usize / 64 bytes; each computes the standard
+// CRC-32 of its piece (table in LDS), then the pieces are joined pairwise — crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)
+// (the identity behind zlib's crc32_combine; reflected polynomial arithmetic) — where every right-hand piece has the length
+// L * 2^level, so one squaring per level gives the multiplier.
+namespace {
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+    }
+    return p;
+}
+__device__ uint32_t crc_xpow8(uint32_t n) // x^(8 n) mod P
+{
+    uint32_t p = 0x80000000u, base = 0x00800000u;
+    while (n) { // (n is the same for the whole wave)
+        if (n & 1u) p = crc_mulmod(p, base);
+        base = crc_mulmod(base, base);
+        n >>= 1;
+    }
+    return p;
+}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out, const GiBlock* __restrict__ blocks, const uint32_t* __restrict__ expect,
+                                                  uint32_t n_blocks, uint32_t* __restrict__ status)
+{
+    __shared__ uint32_t tab[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (bi >= n_blocks) return;
+    const GiBlock blk = blocks[bi];
+    const uint32_t L = blk.usize >> 6, first = blk.usize - 63u * L;
+    const uint8_t* p = out + blk.uoff + (lane ? first + (lane - 1u) * L : 0u);
+    const uint32_t n = lane ? L : first;
+    uint32_t c = 0xFFFFFFFFu, k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const uint32_t w = *(const gi_u32_u*)(p + k);
+        c = tab[(c ^ w) & 255u] ^ (c >> 8);
+        c = tab[(c ^ (w >> 8)) & 255u] ^ (c >> 8);
+        c = tab[(c ^ (w >> 16)) & 255u] ^ (c >> 8);
+        c = tab[(c ^ (w >> 24)) & 255u] ^ (c >> 8);
+    }
+    for (; k < n; ++k) c = tab[(c ^ p[k]) & 255u] ^ (c >> 8);
+    c = ~c;
+    uint32_t x = crc_xpow8(L); // x^(8 L): the multiplier for a right-hand piece of L bytes; squared level by level
+#pragma unroll
+    for (int lv = 0; lv < 6; ++lv) {
+        const uint32_t right = __shfl_down(c, 1u << lv, 64);
+        c = crc_mulmod(c, x) ^ right; // (only the lanes whose index is a multiple of 2 << lv hold a joined piece; the others' values are not used)
+        x = crc_mulmod(x, x);
+    }
+    if (lane == 0 && c != expect[bi]) atomicOr(status, (uint32_t)GI_ERR_CRC);
+}
+
+// launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out
+extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, void* stream)
+{
+    if (!n_blocks) return;
+    const int NL = 8;
+    hipLaunchKernelGGL(k_inflate<8>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status);
+    if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side: one object per reader thread
 // ---------------------------------------------------------------------------------------------------
 struct GpuInflater {

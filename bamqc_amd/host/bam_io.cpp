@@ -17,7 +17,7 @@ bqc_batch HostBatch::view() const
     b.n_reads = (uint32_t)flag.size();
     b.flag = flag.data(); b.mapq = mapq.data(); b.lane = lane.data(); b.rid = rid.data(); b.pos = pos.data();
     b.tlen = tlen.data(); b.nm = nm.data(); b.as = as.data(); b.l_seq = l_seq.data(); b.n_cigar = n_cigar.data();
-    b.seq = seq.data(); b.qual = qual.data(); b.cigar = cigar.data();
+    b.seq = d_seq ? d_seq : seq.data(); b.qual = d_qual ? d_qual : qual.data(); b.cigar = d_cigar ? d_cigar : cigar.data();
     b.n_nm_extra = (uint32_t)nm_extra_read.size();
     b.nm_extra_read = nm_extra_read.data(); b.nm_extra_val = nm_extra_val.data();
     return b;
@@ -26,6 +26,7 @@ void HostBatch::clear()
 {
     flag.clear(); n_cigar.clear(); mapq.clear(); lane.clear(); seq.clear(); qual.clear(); rid.clear(); pos.clear();
     tlen.clear(); nm.clear(); as.clear(); nm_extra_val.clear(); l_seq.clear(); cigar.clear(); nm_extra_read.clear();
+    d_seq = d_qual = nullptr; d_cigar = nullptr; // (dev_mem stays: the next batch reuses it)
 }
 
 static inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }

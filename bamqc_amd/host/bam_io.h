@@ -31,6 +31,18 @@ struct HostBatch { // owning storage behind a bqc_batch
     raw_vector<uint32_t> l_seq, cigar;
     std::vector<int32_t> nm_extra_val;
     std::vector<uint32_t> nm_extra_read;
+    // A batch decoded on the GPU (csrc/gpu_bam.hip) keeps its payload in device memory: these replace seq / qual / cigar in the
+    // view.  dev_mem is the batch's device buffer (kept when the batch is recycled), released through dev_free.
+    const uint8_t* d_seq = nullptr;
+    const uint8_t* d_qual = nullptr;
+    const uint32_t* d_cigar = nullptr;
+    void* dev_mem = nullptr;
+    size_t dev_cap = 0;
+    void (*dev_free)(void*) = nullptr;
+    HostBatch() = default;
+    HostBatch(const HostBatch&) = delete;
+    HostBatch& operator=(const HostBatch&) = delete;
+    ~HostBatch() { if (dev_mem && dev_free) dev_free(dev_mem); }
     bqc_batch view() const;
     void clear();
     size_t n() const { return flag.size(); }
@@ -72,6 +84,7 @@ public:
     // -1 = error (err set; code in err_code: BQC_ERR_IO for a corrupt file, BQC_ERR_ARG for the RG-tag rule).
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
+    uint64_t stream_pos() const { return base_u_ + cur_; } // offset of the next record in the uncompressed stream (after open: the first record's)
 
 private:
     bool fill(size_t need, std::string& err); // ensure `need` bytes are available at cur_

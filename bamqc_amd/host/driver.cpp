@@ -29,6 +29,8 @@
 #include "crc32_fast.h"
 #include "inflate_fast.h"
 #include "host_tools.h"
+#include "../csrc/gpu_bam.h"
+#include <hip/hip_runtime_api.h>
 
 // ---------------------------------------------------------------------------------------------------
 // FASTA
@@ -251,7 +253,8 @@ struct bqc_bam {
     SamReader sam;
     bool is_sam = false;
     FILE* sam_file = nullptr;
-    RecordReader& rd() { return is_sam ? static_cast<RecordReader&>(sam) : static_cast<RecordReader&>(bam); }
+    std::unique_ptr<GpuBamReader> gpu; // bqc_bam_open_gpu: records decoded on the card
+    RecordReader& rd() { return gpu ? static_cast<RecordReader&>(*gpu) : is_sam ? static_cast<RecordReader&>(sam) : static_cast<RecordReader&>(bam); }
     const BamHeader& hdr() const { return const_cast<bqc_bam*>(this)->rd().header(); }
     ~bqc_bam() { if (sam_file && sam_file != stdin) fclose(sam_file); }
     HostBatch hb;
@@ -279,6 +282,17 @@ extern "C" int bqc_bam_open(const char* path, bqc_bam** out)
     } else if (!b->bam.open(path, b->err)) { *out = b; return BQC_ERR_IO; }
     b->refresh_lanes();
     *out = b;
+    return 0;
+}
+extern "C" int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out)
+{
+    if (!path || !out) return BQC_ERR_ARG;
+    auto* b = new bqc_bam();
+    *out = b;
+    if (!b->bam.open(path, b->err)) return BQC_ERR_IO; // the header, on the host
+    b->gpu.reset(new GpuBamReader());
+    if (!b->gpu->open(path, device, b->bam.header(), b->bam.stream_pos(), b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
+    b->refresh_lanes();
     return 0;
 }
 extern "C" int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out)
@@ -331,7 +345,16 @@ extern "C" int bqc_bam_next(bqc_bam* b, uint32_t max_reads, uint64_t max_bases, 
     if (!b || !out) return -BQC_ERR_ARG;
     int code = 0;
     const int rc = b->rd().next_batch(b->hb, max_reads, max_bases, b->err, code);
-    if (rc < 0) return -code;
+    if (rc < 0) return code < 0 ? code : -code; // (GpuBamReader::kUnsupported is negative already)
+    if (b->gpu && b->hb.d_seq) { // callers of this wrapper read the columns on the host: fetch the payload
+        HostBatch& h = b->hb;
+        uint64_t so = 0, qo = 0, co = 0;
+        for (size_t i = 0; i < h.n(); ++i) { so += (h.l_seq[i] + 1u) / 2u; qo += h.l_seq[i]; co += h.n_cigar[i]; }
+        h.seq.resize(so); h.qual.resize(qo); h.cigar.resize(co);
+        if ((so && hipMemcpy(h.seq.data(), h.d_seq, so, hipMemcpyDeviceToHost) != hipSuccess) || (qo && hipMemcpy(h.qual.data(), h.d_qual, qo, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (co && hipMemcpy(h.cigar.data(), h.d_cigar, 4 * co, hipMemcpyDeviceToHost) != hipSuccess)) { b->err = "copy from the device failed"; return -BQC_ERR_DEVICE; }
+        h.d_seq = h.d_qual = nullptr; h.d_cigar = nullptr;
+    }
     b->view = b->hb.view();
     *out = &b->view;
     return rc;

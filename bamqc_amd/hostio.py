@@ -30,11 +30,14 @@ def batch_to_cols(b):
 
 
 class BamFile:
-    def __init__(self, path, begin_hint=None, end_hint=None):
-        """The whole file, or (begin_hint / end_hint: compressed byte offsets) one shard of its record stream."""
+    def __init__(self, path, begin_hint=None, end_hint=None, gpu=None):
+        """The whole file, or (begin_hint / end_hint: compressed byte offsets) one shard of its record stream.
+        gpu: a device index — the file is inflated and decoded on that GPU (batches are fetched back)."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
-        if begin_hint is None and end_hint is None:
+        if gpu is not None:
+            rc = self.lib.bqc_bam_open_gpu(path.encode(), gpu, C.byref(self.h))
+        elif begin_hint is None and end_hint is None:
             rc = self.lib.bqc_bam_open(path.encode(), C.byref(self.h))
         else:
             rc = self.lib.bqc_bam_open_range(path.encode(), begin_hint or 0, 2 ** 64 - 1 if end_hint is None else end_hint, C.byref(self.h))

@@ -205,7 +205,8 @@ int bqc_submit(bqc_ctx* ctx, const bqc_batch* batch);
 
 /* The same without the staging copy, for callers whose columns live in page-locked memory (bqc_host_register, or
  * hipHostMalloc): the columns are copied to the device straight from the caller's memory and must stay untouched until
- * bqc_batch_uploaded(ctx, ticket, ...) returns 1. */
+ * bqc_batch_uploaded(ctx, ticket, ...) returns 1.  The payload columns (seq, qual, cigar) may also live in the device's own
+ * memory (a caller that inflates and decodes there); the fixed columns are read by the host as well and stay host pointers. */
 int bqc_submit_async(bqc_ctx* ctx, const bqc_batch* batch, uint64_t* ticket);
 /* 1: the batch's columns have been copied to the device (or the ticket is older than every batch in flight), 0: not yet
  * (only with wait == 0), < 0: -(BQC_ERR_*). */

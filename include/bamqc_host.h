@@ -58,6 +58,10 @@ int bqc_bam_open(const char* path, bqc_bam** out);  /* on failure *out still hol
  * shard in the middle of a file locates its first record by a plausibility test; shards verify each other afterwards:
  * bqc_bam_range_over of a shard must equal bqc_bam_range_first of its successor (else: process the file unsharded). */
 int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out);
+/* The same reader with the file inflated and its records decoded on GPU `device` (the batches of bqc_bam_next are fetched back for
+ * the caller).  bqc_bam_next returns -1000 when the file needs the host reader (a read group missing from the header, a record
+ * the host reader would report, ...): open it with bqc_bam_open then. */
+int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out);
 uint64_t bqc_bam_range_begin_block(const bqc_bam* b);
 uint64_t bqc_bam_range_end_block(const bqc_bam* b);   /* UINT64_MAX: end of the file */
 uint64_t bqc_bam_range_first(const bqc_bam* b);       /* valid after the first bqc_bam_next */

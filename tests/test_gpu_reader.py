@@ -1,0 +1,80 @@
+"""GPU: the BAM reader on the card (csrc/gpu_bam.hip: inflate, CRC, record walk, column decode) against the host reader —
+identical columns whatever the batch size; inputs it must hand over to the host reader instead of decoding."""
+import numpy as np
+import pytest
+
+from bamqc_amd import hostio
+
+pytestmark = pytest.mark.gpu
+
+
+def all_columns(path, batch_reads, batch_bases=1 << 28, **kw):
+    b = hostio.BamFile(path, **kw)
+    cols = {}
+    n_batches = 0
+    for batch in b.batches(batch_reads, batch_bases):
+        n_batches += 1
+        for k, v in batch.items():
+            if isinstance(v, np.ndarray):
+                cols.setdefault(k, []).append(np.array(v, copy=True))
+    b.close()
+    return {k: np.concatenate(v) for k, v in cols.items()}, n_batches
+
+
+def same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert len(a[k]) == len(b[k]), k
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("shape", ["short_pe", "lanes", "long_reads", "level6"])
+def test_gpu_reader_matches_host_reader(tmp_path, shape):
+    path = str(tmp_path / "x.bam")
+    kw = dict(seed=31, n_reads=700_000, ref_names=["chr1", "chr2", "chrM"], ref_lens=[4_000_000, 2_500_000, 16_000])
+    if shape == "lanes":
+        kw.update(n_lanes=5, n_reads=400_000)
+    if shape == "long_reads":
+        kw.update(long_reads=True, n_reads=12_000, read_len=9000)
+    if shape == "level6":
+        kw.update(level=6, n_reads=300_000)
+    hostio.synth_stream(path, None, **kw)
+    host, _ = all_columns(path, 250_000)
+    for batch_reads in (250_000, 1 << 20, 3001):
+        if shape == "long_reads" and batch_reads == 3001:
+            continue
+        gpu, nb = all_columns(path, batch_reads, gpu=0)
+        assert nb >= 1
+        same(host, gpu)
+    if shape == "long_reads":  # the base limit of a batch
+        gpu, nb = all_columns(path, 1 << 20, 20_000_000, gpu=0)
+        assert nb >= 4
+        same(host, gpu)
+
+
+def test_wild_records_every_tag_type(tmp_path):
+    """Python-written BAM: records straddling BGZF blocks of random size and compression level (stored blocks too), every tag
+    type around RG / NM / AS, reads without bases or qualities."""
+    from tests.test_host_io import _wild_bam
+    path = str(tmp_path / "wild.bam")
+    _wild_bam(path, 23, 4000, extra_nm=False)
+    host, _ = all_columns(path, 777)
+    for batch_reads in (777, 100_000):
+        gpu, _ = all_columns(path, batch_reads, gpu=0)
+        same(host, gpu)
+
+
+def test_gpu_reader_hands_over_what_the_host_reader_decides(tmp_path):
+    """A record with a second NM tag (an extra value in the host reader's batch) is not decoded on the card: the reader says so
+    (code 1000) before anything is reported, and the host reader takes the file."""
+    from tests.test_host_io import _wild_bam
+    path = str(tmp_path / "wild.bam")
+    _, extra = _wild_bam(path, 21, 3000)
+    assert extra
+    b = hostio.BamFile(path, gpu=0)
+    with pytest.raises(IOError) as e:
+        list(b.batches(100_000))
+    assert "1000" in str(e.value)
+    b.close()
+    host, _ = all_columns(path, 100_000)
+    assert len(host["flag"]) == 3000
