@@ -18,7 +18,8 @@ public:
     GpuBamReader();
     ~GpuBamReader() override;
     // hdr / first_record_u: the header as the host reader parsed it, and the offset of the first record in the uncompressed stream
-    bool open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, std::string& err);
+    // batch_reads / batch_bases: the limits next_batch will be called with (buffers are allocated once, for full batches)
+    bool open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err);
     BamHeader& header() override { return hdr_; }
     void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;

@@ -22,6 +22,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "../../include/bamqc.h"
 #include "gpu_bam.h"
@@ -264,60 +267,122 @@ template <typename T> struct PinBuf {
     }
     ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
-void dev_free_hook(void* p) { (void)hipFree(p); }
+// The batches' payload buffers: allocated when a reader opens (before its first kernel runs: hipMalloc and hipFree behind a running
+// 30 ms inflate kernel were measured to wait for it), all of one size, handed back here when a batch object dies.
+struct PayloadPool {
+    std::mutex m;
+    std::vector<void*> free_list;
+    size_t cap = 0;
+    void* take(size_t need)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (need > cap || free_list.empty()) return nullptr;
+        void* p = free_list.back();
+        free_list.pop_back();
+        return p;
+    }
+    void fill(size_t bytes, int n)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (bytes > cap) { for (void* p : free_list) (void)hipFree(p); free_list.clear(); cap = bytes; }
+        while ((int)free_list.size() < n) { void* p = nullptr; if (hipMalloc(&p, cap) != hipSuccess) break; free_list.push_back(p); }
+    }
+    void give(void* p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (bytes == cap && free_list.size() < 16) free_list.push_back(p); else (void)hipFree(p);
+    }
+};
+PayloadPool g_pool;
+size_t g_pool_cap_of_live = 0; // (capacity of the buffers handed out: all the same while one reader is open)
+void dev_free_hook(void* p) { g_pool.give(p, g_pool_cap_of_live); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
 
-struct GpuBamReader::Impl {
-    int device = 0;
+// One run of BGZF blocks in flight: its own stream, page-locked input buffer and device buffers.  The uncompressed bytes land behind
+// `head` spare bytes, which take the unfinished record of the run before (the record stream is walked run by run).
+struct GbRun {
     hipStream_t s = nullptr;
-    hipEvent_t ev = nullptr, ev_copy = nullptr; // blocking
-    FILE* f = nullptr;
-    bool file_eof = false;
-    uint64_t skip_u = 0;                 // uncompressed bytes in front of the first record, still to be dropped
-    size_t run_bytes = 128u << 20;       // compressed bytes per run
-    PinBuf<uint8_t> raw;                 // the run's compressed bytes (tail of the previous read in front)
-    size_t raw_have = 0;                 // bytes of a partial block kept from the previous read
+    hipEvent_t ready = nullptr, copied = nullptr;
+    raw_vector<uint8_t> rawv;
     DevBuf<uint8_t> d_comp;
     PinBuf<GiBlock> h_blocks; DevBuf<GiBlock> d_blocks;
     PinBuf<uint32_t> h_crc; DevBuf<uint32_t> d_crc;
-    DevBuf<uint8_t> d_stream;            // the uncompressed stream: valid bytes [cur, end)
-    size_t cur = 0, end = 0;
+    DevBuf<uint8_t> d_out;
     uint32_t* d_status = nullptr;
+    size_t utotal = 0;
+    int state = 0;       // 0 free, 1 being filled, 2 ready (under Impl::m)
+    bool final = false;  // nothing follows (this one may be empty)
+    int rc = 1;          // 1 ok, -1 malformed (err), -2 device
+    std::string err;
+};
+
+struct GpuBamReader::Impl {
+    int device = 0;
+    hipStream_t s = nullptr;    // the consumer's: walk, decode, copies
+    hipStream_t ps = nullptr;   // the producer's: copies and inflate kernels of every run
+    hipEvent_t ev = nullptr;    // blocking
+    FILE* f = nullptr;
+    uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
+    size_t run_bytes = 256u << 20; // (the inflate kernel's time hardly depends on the number of blocks until the card is full: ~18 K blocks)
+    size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
+    static const int kRuns = 3; // one being walked, one being inflated, one being read
+    GbRun runs[kRuns];
+    // producer thread: file -> runs
+    std::thread producer;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    uint64_t produced = 0, taken = 0, freed = 0; // runs handed over / taken by the consumer / given back (run k lives in runs[k % kRuns])
+    std::vector<uint8_t> tail;           // partial block behind the last run
+    bool file_eof = false;
+    // consumer: the window [cur, end) of the current run's buffer
+    GbRun* cur_run = nullptr;
+    uint8_t* win = nullptr;
+    size_t cur = 0, end = 0;
+    bool stream_done = false;
     uint32_t* h_status = nullptr;
     DevBuf<GbSeg> d_seg; PinBuf<GbSeg> h_seg;
     DevBuf<GbRec> d_rec;
     DevBuf<GbBase> d_base; PinBuf<GbBase> h_base;
-    // fixed columns on the device, one allocation
     DevBuf<uint8_t> d_cols;
-    // lanes / main chromosomes
     DevBuf<uint8_t> d_lane_blob; DevBuf<uint32_t> d_lane_tab; uint32_t n_lane_ids = 0, lane_count = 0;
     DevBuf<uint8_t> d_main; uint32_t n_main = 0; bool main_set = false;
+    uint32_t* d_status = nullptr; // of the decode kernels
     int32_t n_ref = 0;
-    double avg_rec_bytes = 0, avg_rec_bases = 0;
     bool timing = false;
-    double t_read = 0;
+    double t_read = 0, t_wait_run = 0;
     uint64_t n_rewalk = 0;
 
     ~Impl()
     {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        if (producer.joinable()) producer.join();
         (void)hipSetDevice(device);
+        if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+        for (GbRun& R : runs) {
+            if (R.ready) (void)hipEventDestroy(R.ready);
+            if (R.copied) (void)hipEventDestroy(R.copied);
+            if (R.d_status) (void)hipFree(R.d_status);
+        }
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         if (ev) (void)hipEventDestroy(ev);
-        if (ev_copy) (void)hipEventDestroy(ev_copy);
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
         if (f) fclose(f);
     }
     bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
-    // reads the next run of whole BGZF blocks, inflates it behind `end`; 1: done, 0: end of the file, -1: I/O error / malformed (err), -2: device
-    int add_run(std::string& err);
+    void produce();
+    void fill_run(GbRun& R);
+    // the next run becomes the window (what is left of the current one goes in front of it); 1: done, 0: no more runs, -1 / -2: see GbRun::rc
+    int advance(std::string& err);
 };
 
 GpuBamReader::GpuBamReader() {}
 GpuBamReader::~GpuBamReader() { delete p_; }
 
-bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, std::string& err)
+bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err)
 {
     hdr_ = hdr;
     delete p_;
@@ -329,109 +394,185 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev_copy, hipEventBlockingSync | hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
     if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
     if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
+    // ONE stream for all runs: a process gets a handful of hardware queues, streams beyond them share one, and a 30 ms inflate
+    // kernel in a shared queue holds up whatever else is in it (measured: the reader's own 1 ms kernels waiting 50-80 ms)
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.ps, hipStreamNonBlocking);
+    for (GbRun& R : I.runs) {
+        R.s = I.ps;
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.ready, hipEventBlockingSync | hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.copied, hipEventBlockingSync | hipEventDisableTiming);
+        if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
+    }
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
     I.f = fopen(path, "rb");
     if (!I.f) { err = std::string("could not open ") + path; return false; }
     setvbuf(I.f, nullptr, _IONBF, 0);
     I.skip_u = first_record_u;
     I.n_ref = (int32_t)hdr.ref_names.size();
-    // read-group ids -> lane index
+    // read-group ids -> lane index, column-wise: off[n] len[n] index[n]
     std::vector<uint8_t> blob;
-    std::vector<uint32_t> tab; // [off][len][index] x n
-    for (const auto& kv : hdr.lane_names) {
-        tab.push_back((uint32_t)blob.size()); tab.push_back((uint32_t)kv.first.size()); tab.push_back(kv.second);
-        blob.insert(blob.end(), kv.first.begin(), kv.first.end());
-    }
     I.n_lane_ids = (uint32_t)hdr.lane_names.size();
     I.lane_count = hdr.lane_count;
-    // stored column-wise: off[n] len[n] index[n]
     std::vector<uint32_t> cols(3 * (size_t)I.n_lane_ids + 1);
-    for (uint32_t l = 0; l < I.n_lane_ids; ++l) { cols[l] = tab[3 * l]; cols[I.n_lane_ids + l] = tab[3 * l + 1]; cols[2 * I.n_lane_ids + l] = tab[3 * l + 2]; }
+    {
+        uint32_t l = 0;
+        for (const auto& kv : hdr.lane_names) {
+            cols[l] = (uint32_t)blob.size(); cols[I.n_lane_ids + l] = (uint32_t)kv.first.size(); cols[2 * I.n_lane_ids + l] = kv.second;
+            blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+            ++l;
+        }
+    }
     if (!I.d_lane_blob.need(blob.size() + 1) || !I.d_lane_tab.need(cols.size())) { err = "GPU reader: out of device memory"; return false; }
     if (!blob.empty()) (void)hipMemcpy(I.d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
+    // Everything the reader will need, now: an allocation (or a release) behind a running inflate kernel waits for that kernel.
+    {
+        const size_t out_cap = I.head + I.run_bytes / 2 * 9 + 64, nb_cap = I.run_bytes / 2048, seg_cap = (I.head + I.run_bytes / 2 * 9) / GB_SEG + 2;
+        bool ok = true;
+        for (GbRun& R : I.runs) ok = ok && R.d_comp.need(I.run_bytes + (1u << 17) + 64) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap) && R.h_blocks.need(nb_cap) && R.h_crc.need(nb_cap);
+        ok = ok && I.d_seg.need(seg_cap) && I.h_seg.need(seg_cap) && I.d_rec.need(seg_cap * GB_MAXR) && I.d_base.need(seg_cap) && I.h_base.need(seg_cap);
+        const size_t reads = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
+        ok = ok && I.d_cols.need(((reads + 63 + GB_MAXR) & ~(size_t)63) * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256);
+        if (!ok) { err = "GPU reader: out of device memory"; return false; }
+        const size_t typical = std::min<size_t>(reads * 360, batch_bases / 2 * 3 + (64u << 20)) + (1u << 20);
+        g_pool.fill(typical, 10);
+        g_pool_cap_of_live = g_pool.cap;
+    }
+    I.producer = std::thread([&I] { I.produce(); });
     return true;
 }
 
-int GpuBamReader::Impl::add_run(std::string& err)
+void GpuBamReader::Impl::produce()
 {
-    if (file_eof && raw_have == 0) return 0;
+    (void)hipSetDevice(device);
+    for (;;) {
+        GbRun* R;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return stop || produced - freed < (uint64_t)kRuns; });
+            if (stop) return;
+            R = &runs[produced % kRuns];
+            R->state = 1;
+        }
+        fill_run(*R);
+        const bool last = R->final || R->rc != 1;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            R->state = 2;
+            ++produced;
+        }
+        cv.notify_all();
+        if (last) return;
+    }
+}
+
+// reads the next run of whole BGZF blocks and starts its inflation (block headers: host/bgzf.cpp plan_run — same checks)
+void GpuBamReader::Impl::fill_run(GbRun& R)
+{
+    R.rc = 1; R.final = false; R.utotal = 0; R.err.clear();
     const size_t kMaxBlock = 65536;
-    if (!raw.need(raw_have + run_bytes + 64)) return -2;
+    const size_t want = produced == 0 ? std::min<size_t>(run_bytes, 64u << 20) : run_bytes; // (a short first run: the first batch is there when the device is)
+    if (R.rawv.size() < run_bytes + (1u << 17)) { R.rawv.resize(run_bytes + (1u << 17)); advise_huge(R.rawv); } // (pageable: the runtime stages the copy at the link's speed; page-locking 3 x 256 MB would cost 0.1 s at start-up)
+    uint8_t* const raw = R.rawv.data();
+    const size_t carried = tail.size();
+    if (carried) memcpy(raw, tail.data(), carried);
     size_t got = 0;
     if (!file_eof) {
         const double t0 = now_s();
-        got = fread(raw.p + raw_have, 1, run_bytes, f);
+        got = fread(raw + carried, 1, want, f);
         t_read += now_s() - t0;
-        if (got < run_bytes) file_eof = true;
+        if (got < want) file_eof = true;
     }
-    const size_t have = raw_have + got;
-    // block headers (host/bgzf.cpp: plan_run — same checks)
-    if (!h_blocks.need(have / 28 + 2) || !h_crc.need(have / 28 + 2)) return -2;
+    const size_t have = carried + got;
+    if (!R.h_blocks.need(have / 28 + 2) || !R.h_crc.need(have / 28 + 2)) { R.rc = -2; return; }
     size_t p = 0, utotal = 0, nb = 0;
     while (p + 18 <= have) {
-        const uint8_t* h = raw.p + p;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF stream (bad gzip member header)"; return -1; }
+        const uint8_t* h = raw + p;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { R.err = "not a BGZF stream (bad gzip member header)"; R.rc = -1; return; }
         const size_t xlen = h[10] | (h[11] << 8);
         if (p + 12 + xlen > have) break;
         size_t bsize = 0, x = 12;
         while (x + 4 <= 12 + xlen) {
             const size_t slen = h[x + 2] | (h[x + 3] << 8);
-            if (x + 4 + slen > 12 + xlen) { err = "corrupt BGZF block (extra subfield runs past the extra field)"; return -1; }
+            if (x + 4 + slen > 12 + xlen) { R.err = "corrupt BGZF block (extra subfield runs past the extra field)"; R.rc = -1; return; }
             if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
             x += 4 + slen;
         }
-        if (!bsize) { err = "BGZF block without BC extra field"; return -1; }
-        if (bsize < 12 + xlen + 8) { err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; return -1; }
+        if (!bsize) { R.err = "BGZF block without BC extra field"; R.rc = -1; return; }
+        if (bsize < 12 + xlen + 8) { R.err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; R.rc = -1; return; }
         if (p + bsize > have) break;
-        const uint8_t* t = raw.p + p + bsize - 8;
+        const uint8_t* t = raw + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
-        if (isize > kMaxBlock) { err = "BGZF block larger than 64 KiB"; return -1; }
+        if (isize > kMaxBlock) { R.err = "BGZF block larger than 64 KiB"; R.rc = -1; return; }
         if (isize) {
-            h_blocks.p[nb] = GiBlock{p + 12 + xlen, utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
-            h_crc.p[nb] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            R.h_blocks.p[nb] = GiBlock{p + 12 + xlen, head + utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
+            R.h_crc.p[nb] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
             ++nb;
         }
         utotal += isize;
         p += bsize;
     }
-    if (file_eof && p != have) { err = "truncated BGZF file"; return -1; }
-    if (p == 0 && !file_eof) { err = "BGZF block larger than the read window"; return -1; }
-    // room behind `end`: move what is left to the front first, grow if that is not enough
-    if (end + utotal + 64 > d_stream.cap) {
-        const size_t live = end - cur;
-        if (live + utotal + 64 <= d_stream.cap && cur >= live) { // (non-overlapping copy)
-            if (live && hipMemcpyAsync(d_stream.p, d_stream.p + cur, live, hipMemcpyDeviceToDevice, s) != hipSuccess) return -2;
-        } else {
-            uint8_t* np = nullptr;
-            const size_t ncap = std::max<size_t>(2 * (live + utotal), (size_t)3 << 29) + 64;
-            if (hipMalloc((void**)&np, ncap) != hipSuccess) return -2;
-            if (live && hipMemcpyAsync(np, d_stream.p + cur, live, hipMemcpyDeviceToDevice, s) != hipSuccess) { (void)hipFree(np); return -2; }
-            if (!sync()) { (void)hipFree(np); return -2; }
-            if (d_stream.p) (void)hipFree(d_stream.p);
-            d_stream.p = np; d_stream.cap = ncap;
-        }
-        cur = 0; end = live;
+    if (file_eof && p != have) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+    tail.assign(raw + p, raw + have);
+    R.final = file_eof;
+    R.utotal = utotal;
+    // sized for a full run from the first (short) one on: growing means hipFree, and hipFree waits for every kernel on the device
+    const size_t nb_cap = std::max(nb + 1, run_bytes / 2048), out_cap = head + std::max(utotal, run_bytes / 2 * 9) + 64;
+    if (!R.d_comp.need(std::max(p, run_bytes + (1u << 17)) + 64) || !R.d_blocks.need(nb_cap) || !R.d_crc.need(nb_cap) || !R.d_out.need(out_cap)) { R.rc = -2; return; }
+    hipError_t he = hipMemsetAsync(R.d_status, 0, 4, R.s);
+    if (he == hipSuccess && p) he = hipMemcpyAsync(R.d_comp.p, raw, p, hipMemcpyHostToDevice, R.s);
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.h_blocks.p, nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s);
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_crc.p, R.h_crc.p, nb * 4, hipMemcpyHostToDevice, R.s);
+    if (he != hipSuccess) { R.rc = -2; return; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, R.s); }
+    bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, R.d_out.p, R.d_crc.p, R.d_status, R.s);
+    if (timing) (void)hipEventRecord(e1, R.s);
+    if (hipEventRecord(R.ready, R.s) != hipSuccess) R.rc = -2;
+    if (timing) { // (waits: only with BQC_GB_TIMING)
+        float ms = 0;
+        (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[gpu reader] run of %zu blocks, %.1f MB -> %.1f MB: inflate + crc %.1f ms, done at %.3f\n", nb, p / 1e6, utotal / 1e6, ms, now_s());
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
-    for (size_t i = 0; i < nb; ++i) h_blocks.p[i].uoff += end;
-    if (!d_comp.need(p + 64) || !d_blocks.need(nb + 1) || !d_crc.need(nb + 1)) return -2;
-    hipError_t he = hipSuccess;
-    if (p) he = hipMemcpyAsync(d_comp.p, raw.p, p, hipMemcpyHostToDevice, s);
-    if (he == hipSuccess && nb) he = hipMemcpyAsync(d_blocks.p, h_blocks.p, nb * sizeof(GiBlock), hipMemcpyHostToDevice, s);
-    if (he == hipSuccess && nb) he = hipMemcpyAsync(d_crc.p, h_crc.p, nb * 4, hipMemcpyHostToDevice, s);
-    if (he == hipSuccess) he = hipEventRecord(ev_copy, s);
-    if (he != hipSuccess) return -2;
-    bqc_gpu_inflate_launch(d_comp.p, d_blocks.p, (uint32_t)nb, d_stream.p, d_crc.p, d_status, s);
-    // the host buffers are reused by the next run: wait for the copies (the kernels go on)
-    if (hipEventSynchronize(ev_copy) != hipSuccess) return -2;
-    end += utotal;
+}
+
+int GpuBamReader::Impl::advance(std::string& err)
+{
+    if (stream_done) return 0;
+    GbRun* N;
+    {
+        const double t0 = now_s();
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return produced > taken; });
+        N = &runs[taken % kRuns];
+        t_wait_run += now_s() - t0;
+    }
+    if (N->rc != 1) { err = N->err; stream_done = true; return N->rc; }
+    const size_t left = end - cur;
+    if (left > head) { err = "a record larger than the reader's spare room"; stream_done = true; return -3; }
+    // behind the run's kernels, on the consumer's stream: what is left of the old window goes in front of the new run's bytes
+    hipError_t he = hipStreamWaitEvent(s, N->ready, 0);
+    if (he == hipSuccess && left) he = hipMemcpyAsync(N->d_out.p + head - left, win + cur, left, hipMemcpyDeviceToDevice, s);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_status, N->d_status, 4, hipMemcpyDeviceToHost, s);
+    if (he != hipSuccess || !sync()) { stream_done = true; return -2; }
+    if (*h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; stream_done = true; return -1; }
+    GbRun* old = cur_run;
+    cur_run = N;
+    win = N->d_out.p;
+    cur = head - left;
+    end = head + N->utotal;
+    if (N->final) stream_done = true; // (no run follows this one)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        ++taken;
+        if (old) { old->state = 0; ++freed; } // the OLD buffer is free now; the new one stays the consumer's until the next advance
+    }
+    cv.notify_all();
     if (skip_u) { const size_t k = (size_t)std::min<uint64_t>(skip_u, end - cur); cur += k; skip_u -= k; }
-    raw_have = have - p;
-    if (raw_have) memmove(raw.p, raw.p + p, raw_have);
     return 1;
 }
 
@@ -450,35 +591,29 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         I.main_set = true;
     }
     const double t0 = now_s();
-    double want = (double)std::min<size_t>(max_reads, 1u << 22) * (I.avg_rec_bytes > 0 ? I.avg_rec_bytes : 340.0) * 1.03;
-    if (I.avg_rec_bases > 0) want = std::min(want, ((double)max_bases / I.avg_rec_bases + 1.0) * I.avg_rec_bytes * 1.03);
-    want = std::min(want, 2.5e9);
-    for (int attempt = 0;; ++attempt) {
-        while ((double)(I.end - I.cur) < want + (I.skip_u ? (double)I.skip_u : 0.0)) {
-            const int rc = I.add_run(err);
-            if (rc == 0) break;
+    double t_adv = 0, t_walk = 0, t_dec = 0;
+    for (;;) {
+        const double ta = now_s();
+        if (I.cur == I.end || I.skip_u) { // nothing (left) in the window
+            const bool was_done = I.stream_done;
+            const int rc = I.advance(err);
+            if (rc == 0) return (I.skip_u && was_done) ? unsupported("the file ends inside its header") : 0;
             if (rc == -1) { err_code = BQC_ERR_IO; return -1; }
-            if (rc == -2) return fail_dev("out of memory or a failed copy");
+            if (rc == -2) return fail_dev("a failed copy or out of memory");
+            if (rc == -3) return unsupported(err.c_str());
+            t_adv += now_s() - ta;
+            continue;
         }
         const uint64_t avail = I.end - I.cur;
-        if (avail == 0) {
-            if (!I.sync()) return fail_dev("synchronisation failed");
-            if (hipMemcpy(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail_dev("copy failed");
-            if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
-            return I.skip_u ? unsupported("the file ends inside its header") : 0;
-        }
-        if (avail > 0xFFFF0000ull) return unsupported("window too large");
+        const uint8_t* base = I.win + I.cur;
         const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
-        if (!I.d_seg.need(nseg) || !I.h_seg.need(nseg) || !I.d_rec.need((size_t)nseg * GB_MAXR) || !I.d_base.need(nseg) || !I.h_base.need(nseg)) return fail_dev("out of device memory");
-        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, I.d_stream.p + I.cur, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
-        if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess ||
-            hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync())
-            return fail_dev("walk failed");
-        if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
+        const size_t seg_cap = std::max<size_t>(nseg, (I.head + I.run_bytes / 2 * 9) / GB_SEG + 2); // (for a full run's window at once: see fill_run)
+        if (!I.d_seg.need(seg_cap) || !I.h_seg.need(seg_cap) || !I.d_rec.need(seg_cap * GB_MAXR) || !I.d_base.need(seg_cap) || !I.h_base.need(seg_cap)) return fail_dev("out of device memory");
+        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
+        if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
         // the chain, segment by segment; whole segments are taken while the batch has room
         uint64_t pos = 0, n = 0, bases = 0, so = 0, qo = 0, co = 0;
         uint32_t last_taken = 0;
-        bool open_end = false; // the chain stopped at a record that is not complete yet (or the batch is full)
         for (uint32_t s = 0; s < nseg; ++s) {
             GbBase& B = I.h_base.p[s];
             B = GbBase{so, qo, co, (uint32_t)n, 0};
@@ -487,38 +622,37 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             GbSeg& S = I.h_seg.p[s];
             if ((S.flags & GB_NO_START) || S.first != pos) { // the guess is not where the chain arrives (or there was none): this segment again, from there
                 ++I.n_rewalk;
-                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, I.d_stream.p + I.cur, avail, s, 1u, pos, I.n_ref, I.d_seg.p, I.d_rec.p);
+                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, I.n_ref, I.d_seg.p, I.d_rec.p);
                 if (hipMemcpyAsync(&S, I.d_seg.p + s, sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
                 if (S.first != pos) return unsupported("the record walk could not be verified");
             }
             if (S.flags & GB_CORRUPT) return unsupported("a record the host reader will report");
-            if (n && (n + S.count > max_reads || bases >= max_bases)) { open_end = true; break; }
+            if (n && (n + S.count > max_reads || bases >= max_bases)) break;
             B.take = 1;
             last_taken = s + 1;
             n += S.count; bases += S.qual_bytes; so += S.seq_bytes; qo += S.qual_bytes; co += S.cigar_words;
             pos = S.exit;
-            if (S.flags & GB_INCOMPLETE) { open_end = true; break; }
+            if (S.flags & GB_INCOMPLETE) break;
         }
-        (void)open_end;
-        if (n == 0) { // not one complete record in the window: more data (a batch may be smaller than asked for, never empty)
-            if ((I.file_eof && I.raw_have == 0) || attempt > 16) return unsupported("the file ends inside a record");
-            want = (double)avail + (double)I.run_bytes;
+        if (n == 0) { // not one complete record in the window: the next run's bytes behind it
+            if (I.stream_done) return unsupported("the file ends inside a record");
+            const int rc = I.advance(err);
+            if (rc == 0) return unsupported("the file ends inside a record");
+            if (rc == -1) { err_code = BQC_ERR_IO; return -1; }
+            if (rc == -2) return fail_dev("a failed copy or out of memory");
+            if (rc == -3) return unsupported(err.c_str());
             continue;
         }
         if (n > 0xFFFFFFF0ull) return unsupported("batch too large");
+        t_walk += now_s() - ta;
+        const double td = now_s();
         // columns
         const size_t N = (size_t)n;
         o.flag.resize(N); o.mapq.resize(N); o.lane.resize(N); o.rid.resize(N); o.pos.resize(N); o.tlen.resize(N);
         o.nm.resize(N); o.as.resize(N); o.l_seq.resize(N); o.n_cigar.resize(N);
-        if (bqc_raw_vector_pin_hook) {
-            bqc_raw_vector_pin_hook(o.flag.data(), o.flag.capacity() * 2); bqc_raw_vector_pin_hook(o.mapq.data(), o.mapq.capacity()); bqc_raw_vector_pin_hook(o.lane.data(), o.lane.capacity());
-            bqc_raw_vector_pin_hook(o.rid.data(), o.rid.capacity() * 4); bqc_raw_vector_pin_hook(o.pos.data(), o.pos.capacity() * 4); bqc_raw_vector_pin_hook(o.tlen.data(), o.tlen.capacity() * 4);
-            bqc_raw_vector_pin_hook(o.nm.data(), o.nm.capacity() * 4); bqc_raw_vector_pin_hook(o.as.data(), o.as.capacity() * 4); bqc_raw_vector_pin_hook(o.l_seq.data(), o.l_seq.capacity() * 4);
-            bqc_raw_vector_pin_hook(o.n_cigar.data(), o.n_cigar.capacity() * 2);
-        }
-        // device columns: [rid pos tlen nm as l_seq rec_off](4 B) [so qo co](8 B) [flag n_cigar](2 B) [mapq lane](1 B)
-        const size_t Np = (N + 63) & ~(size_t)63;
-        if (!I.d_cols.need(Np * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256)) return fail_dev("out of device memory");
+        // device columns: [so qo co](8 B) [rid pos tlen nm as l_seq rec_off](4 B) [flag n_cigar](2 B) [mapq lane](1 B)
+        const size_t Np = (N + 63) & ~(size_t)63, Np_cap = std::max(Np, (std::min<size_t>(max_reads, 1u << 22) + 63 + GB_MAXR) & ~(size_t)63);
+        if (!I.d_cols.need(Np_cap * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256)) return fail_dev("out of device memory");
         GbCols C;
         {
             uint8_t* q = I.d_cols.p;
@@ -531,15 +665,17 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         // the batch's payload buffer on the device: [seq][qual][cigar], 512 spare bytes behind each (the kernels' vector loads)
         const size_t o_seq = 0, o_qual = (so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255), total = o_cig + 4 * co + 512;
         if (o.dev_cap < total) {
-            if (o.dev_mem) (void)hipFree(o.dev_mem);
-            o.dev_mem = nullptr; o.dev_cap = 0;
-            const size_t cap = total + total / 8 + 4096;
-            if (hipMalloc(&o.dev_mem, cap) != hipSuccess) { o.dev_mem = nullptr; return fail_dev("out of device memory"); }
-            o.dev_cap = cap;
+            if (o.dev_mem) dev_free_hook(o.dev_mem);
+            o.dev_mem = g_pool.take(total);
+            o.dev_cap = o.dev_mem ? g_pool.cap : 0;
+            if (!o.dev_mem) { // larger than the pool's buffers (or the pool is empty): its own allocation
+                const size_t cap = total + total / 8 + 4096;
+                if (hipMalloc(&o.dev_mem, cap) != hipSuccess) { o.dev_mem = nullptr; return fail_dev("out of device memory"); }
+                o.dev_cap = cap;
+            }
             o.dev_free = dev_free_hook;
         }
         uint8_t* pay = (uint8_t*)o.dev_mem;
-        const uint8_t* base = I.d_stream.p + I.cur;
         GbLanes LN{I.d_lane_blob.p, I.d_lane_tab.p, I.d_lane_tab.p + I.n_lane_ids, I.d_lane_tab.p + 2 * (size_t)I.n_lane_ids, I.n_lane_ids, I.lane_count};
         hipError_t he = hipMemcpyAsync(I.d_base.p, I.h_base.p, (size_t)last_taken * sizeof(GbBase), hipMemcpyHostToDevice, I.s);
         if (he != hipSuccess) return fail_dev("copy failed");
@@ -557,15 +693,15 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         if (he == hipSuccess) he = hipMemcpyAsync(o.l_seq.data(), C.l_seq, N * 4, hipMemcpyDeviceToHost, I.s);
         if (he == hipSuccess) he = hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s);
         if (he != hipSuccess || !I.sync()) return fail_dev("decode failed");
-        if (*I.h_status & 15u) { err = "BGZF block failed to inflate (corrupt data)"; err_code = BQC_ERR_IO; return -1; }
-        if (*I.h_status & ~15u) return unsupported("a record the host reader handles (read group / tags)");
+        if (*I.h_status) return unsupported("a record the host reader handles (read group / tags)");
         o.d_seq = pay + o_seq; o.d_qual = pay + o_qual; o.d_cigar = (const uint32_t*)(pay + o_cig);
         I.cur += pos;
         nrec_ += n;
-        I.avg_rec_bytes = (double)pos / (double)n;
-        I.avg_rec_bases = (double)bases / (double)n;
         t_read_ = I.t_read;
-        if (I.timing) fprintf(stderr, "[gpu reader] batch of %zu records (%.1f MB of the stream): %.1f ms (reading so far %.3f s)\n", N, pos / 1e6, (now_s() - t0) * 1e3, I.t_read);
+        t_dec = now_s() - td;
+        if (I.timing)
+            fprintf(stderr, "[gpu reader] batch of %zu records (%.1f MB): %.1f ms = next run %.1f + walk %.1f + decode %.1f (reading so far %.3f s, waiting for runs %.3f s, rewalked %llu) at %.3f\n", N,
+                    pos / 1e6, (now_s() - t0) * 1e3, t_adv * 1e3, t_walk * 1e3, t_dec * 1e3, I.t_read, I.t_wait_run, (unsigned long long)I.n_rewalk, now_s());
         return 1;
     }
 }

@@ -168,7 +168,7 @@ template <int NL> __device__ __forceinline__ uint32_t decode_sym(const uint16_t*
 }
 } // namespace
 
-template <int NL> __global__ __launch_bounds__(NL) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
+template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgpr(96))) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
                                                        uint8_t* __restrict__ out, uint32_t* __restrict__ status)
 {
     extern __shared__ uint16_t lds16[];

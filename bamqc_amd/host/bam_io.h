@@ -84,6 +84,7 @@ public:
     // -1 = error (err set; code in err_code: BQC_ERR_IO for a corrupt file, BQC_ERR_ARG for the RG-tag rule).
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
+    void close() { bg_.stop(); raw_vector<uint8_t>().swap(buf_); raw_vector<uint8_t>().swap(chunk_); eof_ = true; } // the header stays; no more records
     uint64_t stream_pos() const { return base_u_ + cur_; } // offset of the next record in the uncompressed stream (after open: the first record's)
 
 private:

@@ -38,7 +38,9 @@ static std::atomic<uint64_t> g_gpu_blocks{0};
 void bgzf_gpu_inflate_device(int device) { g_gpu_device = device; }
 uint64_t bgzf_gpu_inflated_blocks() { return g_gpu_blocks.load(); }
 
-BgzfReader::~BgzfReader()
+BgzfReader::~BgzfReader() { stop(); }
+
+void BgzfReader::stop()
 {
     if (ra_started_) {
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; } // (from here on no worker is added)
@@ -46,6 +48,10 @@ BgzfReader::~BgzfReader()
         for (auto& t : ra_) if (t.joinable()) t.join();
     }
     if (f_) fclose(f_);
+    f_ = nullptr;
+    std::lock_guard<std::mutex> lk(m_);
+    ra_done_ = true; // (a next_chunk after this finds the end of the stream)
+    q_.clear(); done_.clear(); spare_.clear();
 }
 
 // A worker of the read-ahead: plans a run (file read + block walk: one worker at a time, in file order), inflates it, and files

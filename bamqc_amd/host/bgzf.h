@@ -18,6 +18,7 @@
 class BgzfReader {
 public:
     ~BgzfReader();
+    void stop(); // ends the read-ahead and closes the file (what the destructor does); the reader yields nothing more
     bool open(const char* path, std::string& err, unsigned threads = 0);
     // Start at `begin` (the file offset of a BGZF block, see bgzf_find_block) instead of the file's start.  `mark` (a later block
     // boundary, or UINT64_MAX): mark_u() becomes the number of uncompressed bytes this reader yields before that block once it

@@ -291,7 +291,7 @@ extern "C" int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out)
     *out = b;
     if (!b->bam.open(path, b->err)) return BQC_ERR_IO; // the header, on the host
     b->gpu.reset(new GpuBamReader());
-    if (!b->gpu->open(path, device, b->bam.header(), b->bam.stream_pos(), b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
+    if (!b->gpu->open(path, device, b->bam.header(), b->bam.stream_pos(), 1u << 20, 256u << 20, b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
     b->refresh_lanes();
     return 0;
 }
@@ -706,7 +706,7 @@ namespace {
 struct ShardArgs { uint32_t index, count; bqc_shard_hook hook; void* user; };
 }
 
-static int run_program(int argc, const char** argv, const ShardArgs* shard)
+static int run_program(int argc, const char** argv, const ShardArgs* shard, bool host_reader_only = false)
 {
     ProgramOptions opt;
     std::string perr;
@@ -721,6 +721,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
         fprintf(stderr, "[timing] %s: %.3f s after launch\n", what, now - atof(getenv("BQC_T0")));
     };
     since_launch("main entered");
+    setenv("GPU_MAX_HW_QUEUES", "8", 0); // (before the runtime starts: the batch pipeline, the reader and its producer each keep a hardware queue of their own)
     // the HIP runtime starts (~0.1 s) while the inputs are opened; from then on the reader's runs are inflated on the card
     const char* gi_env = getenv("BQC_GPU_INFLATE");
     const bool gpu_inflate = gi_env && atoi(gi_env) != 0;
@@ -751,7 +752,22 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
         fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
         return shard_abort();
     }
-    RecordReader& rd = from_stdin ? static_cast<RecordReader&>(sam_rd) : static_cast<RecordReader&>(bam_rd);
+    // A BAM file read as a whole is inflated and decoded on the GPU (csrc/gpu_bam.hip): the host reader has read the header, the
+    // records come from the card.  Whatever that reader does not decode itself (a read group that is not in the header, a record
+    // the host reader would report, ...) ends this pass before anything has been reported, and the program starts over with the
+    // host reader (host_reader_only).  BQC_GPU_DECODE=0: the host reader from the start.
+    GpuBamReader gpu_rd;
+    const char* gd_env = getenv("BQC_GPU_DECODE");
+    const bool use_gpu_reader = !from_stdin && !shard && !host_reader_only && gd_env && atoi(gd_env) != 0 && bam_rd.header().lane_count != 0;
+    uint64_t first_record_u = 0;
+    if (use_gpu_reader) {
+        first_record_u = bam_rd.stream_pos();
+        bam_rd.close(); // (its read-ahead has inflated the first run of blocks for the header; no more)
+        bqc_raw_vector_free_hook = pin_free_hook;
+        bqc_raw_vector_pin_hook = pin_hook;
+    }
+    RecordReader& rd = from_stdin ? static_cast<RecordReader&>(sam_rd) : use_gpu_reader ? static_cast<RecordReader&>(gpu_rd) : static_cast<RecordReader&>(bam_rd);
+    if (use_gpu_reader) gpu_rd.header() = bam_rd.header(); // (complete once opened, in the decode thread: the device is not up yet)
     if (!shard || shard->index == 0) {
         FILE* of = fopen(opt.outputFile.c_str(), "wb"); // opened (truncated) before the scan, :278-283
         if (!of) { fprintf(stderr, "ERROR: Could not open output file %s\n", opt.outputFile.c_str()); return shard_abort(); }
@@ -787,6 +803,15 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
         dec.join();
     };
     if (H.lane_count != 0) dec = std::thread([&]() {
+        if (use_gpu_reader) {
+            std::string e;
+            if (!gpu_rd.open(opt.bamFile.c_str(), opt.device, bam_rd.header(), first_record_u, opt.batch_reads, 256ull << 20, e)) {
+                std::lock_guard<std::mutex> lk(Q.m);
+                Q.err = e; Q.err_code = GpuBamReader::kUnsupported; Q.done = true; Q.cv.notify_all();
+                return;
+            }
+            gpu_rd.set_main_chrom(main_chrom);
+        }
         for (;;) {
             std::unique_ptr<HostBatch> hb;
             {
@@ -865,6 +890,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
     const auto t_setup = clk::now();
 
     int status = 0;
+    uint64_t n_noqual_deferred = 0;
     const bool pinned = !(getenv("BQC_NO_PINNED") && getenv("BQC_NO_PINNED")[0] == '1'); // (1: the staging path of bqc_submit, for comparison)
     if (pinned) bqc_raw_vector_free_hook = pin_free_hook;
     struct InFlight { uint64_t ticket; std::unique_ptr<HostBatch> hb; };
@@ -874,7 +900,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
             const int up = bqc_batch_uploaded(ctx, inflight.front().ticket, wait_all || inflight.size() > 3 ? 1 : 0);
             if (up == 0) break;
             std::lock_guard<std::mutex> lk(Q.m);
-            if (Q.spare.size() < 4) Q.spare.push_back(std::move(inflight.front().hb));
+            if (Q.spare.size() < 8) Q.spare.push_back(std::move(inflight.front().hb));
             inflight.pop_front();
         }
     };
@@ -894,6 +920,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
           // record with a first / last flag whose quality string is empty while its sequence is not
             size_t n_noqual = 0;
             for (uint16_t f : hb->flag) n_noqual += (f & BQC_FLAG_NO_QUAL) && !(f & 0x900) && (f & 0xC0);
+            if (use_gpu_reader) { n_noqual_deferred += n_noqual; n_noqual = 0; } // (printed once the pass is known to be the one that counts)
             if (n_noqual) {
                 static const char msg[] = "ERROR: length of sequence and quality is not the same\n";
                 std::string out;
@@ -910,7 +937,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
         t_wait += secs(w0, s0);
         n_total += v.n_reads;
         if (pinned) {
-            pin_batch(*hb);
+            if (!hb->d_seq) pin_batch(*hb); // (a batch decoded on the card: its payload is there already, its small fixed columns are copied staged)
             uint64_t ticket = 0;
             if ((rc = bqc_submit_async(ctx, &v, &ticket))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
             inflight.push_back(InFlight{ticket, std::move(hb)});
@@ -928,6 +955,14 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard)
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
                 (unsigned long long)n_total, t_decode, g_pins.t_register, t_submit, t_wait, secs(t_setup, clk::now()));
+    if (Q.err_code == GpuBamReader::kUnsupported && status) Q.err_code = 0; // (an error of the records before it has been reported: that is the run's result)
+    if (Q.err_code == GpuBamReader::kUnsupported) { // nothing has been reported yet: the same file again, through the host reader
+        if (timing) fprintf(stderr, "[timing] %s\n", Q.err.c_str());
+        bqc_destroy(ctx);
+        g_pins.release_all();
+        return run_program(argc, argv, shard, true);
+    }
+    for (uint64_t k = 0; k < n_noqual_deferred; ++k) fputs("ERROR: length of sequence and quality is not the same\n", stderr);
     if (!status && Q.err_code) {
         if (Q.err_code == BQC_ERR_IO) fprintf(stderr, "ERROR: Could not read record from BAM File %s\n", opt.bamFile.c_str()); // :308
         else fprintf(Q.err == "Read does not have Z" ? stdout : stderr, "%s\n", Q.err.c_str());
