@@ -240,12 +240,12 @@ namespace {
 template <typename T> struct DevBuf { // grows, never shrinks
     T* p = nullptr;
     size_t cap = 0;
-    bool need(size_t n)
+    bool need(size_t n, bool exact = false)
     {
         if (cap >= n) return true;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        const size_t c = n + n / 4 + 64;
+        const size_t c = exact ? n : n + n / 4 + 64;
         if (hipMalloc((void**)&p, c * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
         cap = c;
         return true;
@@ -304,10 +304,9 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 struct GbRun {
     hipStream_t s = nullptr;
     hipEvent_t ready = nullptr, copied = nullptr;
-    raw_vector<uint8_t> rawv;
     DevBuf<uint8_t> d_comp;
-    PinBuf<GiBlock> h_blocks; DevBuf<GiBlock> d_blocks;
-    PinBuf<uint32_t> h_crc; DevBuf<uint32_t> d_crc;
+    std::vector<GiBlock> hb; DevBuf<GiBlock> d_blocks; // block table, host / device
+    std::vector<uint32_t> hc; DevBuf<uint32_t> d_crc;  // expected CRC-32s
     DevBuf<uint8_t> d_out;
     uint32_t* d_status = nullptr;
     size_t utotal = 0;
@@ -324,7 +323,7 @@ struct GpuBamReader::Impl {
     hipEvent_t ev = nullptr;    // blocking
     FILE* f = nullptr;
     uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
-    size_t run_bytes = 256u << 20; // (the inflate kernel's time hardly depends on the number of blocks until the card is full: ~18 K blocks)
+    size_t run_bytes = 192u << 20; // (the inflate kernel's time hardly depends on the number of blocks until the card is full: ~18 K blocks)
     size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
     static const int kRuns = 3; // one being walked, one being inflated, one being read
     GbRun runs[kRuns];
@@ -361,6 +360,7 @@ struct GpuBamReader::Impl {
         if (producer.joinable()) producer.join();
         (void)hipSetDevice(device);
         if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+        for (PinChunk& C : chunks) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) (void)hipHostFree(C.p); }
         for (GbRun& R : runs) {
             if (R.ready) (void)hipEventDestroy(R.ready);
             if (R.copied) (void)hipEventDestroy(R.copied);
@@ -373,8 +373,18 @@ struct GpuBamReader::Impl {
         if (f) fclose(f);
     }
     bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
+    // page-locked chunks the file is read into (from the second run on)
+    struct PinChunk { uint8_t* p = nullptr; hipEvent_t done = nullptr; bool used = false; };
+    static const int kChunks = 3;
+    PinChunk chunks[kChunks];
+    size_t chunk_bytes = 32u << 20;
+    int chunk_i = 0;
+    raw_vector<uint8_t> first_raw; // the first run: read while the device is still starting
+    bool dev_ready = false;        // (under m) streams and buffers exist: the producer may touch the device
     void produce();
     void fill_run(GbRun& R);
+    size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal);
+    bool wait_ready();
     // the next run becomes the window (what is left of the current one goes in front of it); 1: done, 0: no more runs, -1 / -2: see GbRun::rc
     int advance(std::string& err);
 };
@@ -384,6 +394,7 @@ GpuBamReader::~GpuBamReader() { delete p_; }
 
 bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err)
 {
+    const double t_open0 = now_s();
     hdr_ = hdr;
     delete p_;
     p_ = new Impl();
@@ -391,14 +402,21 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.device = device;
     I.timing = getenv("BQC_GB_TIMING") != nullptr;
     if (const char* e = getenv("BQC_GB_RUN_MB")) I.run_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    I.f = fopen(path, "rb");
+    if (!I.f) { err = std::string("could not open ") + path; return false; }
+    setvbuf(I.f, nullptr, _IONBF, 0);
+    I.skip_u = first_record_u;
+    I.n_ref = (int32_t)hdr.ref_names.size();
+    I.producer = std::thread([&I] { I.produce(); }); // reads the first run of the file while the device is set up below
     hipError_t he = hipSetDevice(device);
+    const double t_open1 = now_s();
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
     if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
     if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
     // ONE stream for all runs: a process gets a handful of hardware queues, streams beyond them share one, and a 30 ms inflate
-    // kernel in a shared queue holds up whatever else is in it (measured: the reader's own 1 ms kernels waiting 50-80 ms)
+    // kernel in a shared queue holds up whatever else is in it
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.ps, hipStreamNonBlocking);
     for (GbRun& R : I.runs) {
         R.s = I.ps;
@@ -406,12 +424,13 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipEventCreateWithFlags(&R.copied, hipEventBlockingSync | hipEventDisableTiming);
         if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
     }
+    const double t_open2 = now_s();
+    for (Impl::PinChunk& C : I.chunks) {
+        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, I.chunk_bytes + (1u << 17), hipHostMallocDefault);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
+    }
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
-    I.f = fopen(path, "rb");
-    if (!I.f) { err = std::string("could not open ") + path; return false; }
-    setvbuf(I.f, nullptr, _IONBF, 0);
-    I.skip_u = first_record_u;
-    I.n_ref = (int32_t)hdr.ref_names.size();
+    const double t_open3 = now_s();
     // read-group ids -> lane index, column-wise: off[n] len[n] index[n]
     std::vector<uint8_t> blob;
     I.n_lane_ids = (uint32_t)hdr.lane_names.size();
@@ -430,24 +449,30 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
     // Everything the reader will need, now: an allocation (or a release) behind a running inflate kernel waits for that kernel.
     {
-        const size_t out_cap = I.head + I.run_bytes / 2 * 9 + 64, nb_cap = I.run_bytes / 2048, seg_cap = (I.head + I.run_bytes / 2 * 9) / GB_SEG + 2;
+        // (a run inflates to ~3.3 x its size with BGZF level 1-6 on BAM records; a run that needs more grows its buffer, once)
+        const size_t out_cap = I.head + I.run_bytes / 5 * 18 + 64, nb_cap = I.run_bytes / 2048, seg_cap = out_cap / GB_SEG + 2;
         bool ok = true;
-        for (GbRun& R : I.runs) ok = ok && R.d_comp.need(I.run_bytes + (1u << 17) + 64) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap) && R.h_blocks.need(nb_cap) && R.h_crc.need(nb_cap);
-        ok = ok && I.d_seg.need(seg_cap) && I.h_seg.need(seg_cap) && I.d_rec.need(seg_cap * GB_MAXR) && I.d_base.need(seg_cap) && I.h_base.need(seg_cap);
+        const double t_a = now_s();
+        for (GbRun& R : I.runs) ok = ok && R.d_comp.need(I.run_bytes + I.chunk_bytes + (1u << 17) + 64, true) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap, true);
+        const double t_b = now_s();
+        ok = ok && I.d_seg.need(seg_cap) && I.h_seg.need(seg_cap) && I.d_rec.need(seg_cap * GB_MAXR, true) && I.d_base.need(seg_cap) && I.h_base.need(seg_cap);
         const size_t reads = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
         ok = ok && I.d_cols.need(((reads + 63 + GB_MAXR) & ~(size_t)63) * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256);
         if (!ok) { err = "GPU reader: out of device memory"; return false; }
         const size_t typical = std::min<size_t>(reads * 360, batch_bases / 2 * 3 + (64u << 20)) + (1u << 20);
-        g_pool.fill(typical, 10);
+        const double t_c = now_s();
+        g_pool.fill(typical, 6);
         g_pool_cap_of_live = g_pool.cap;
+        if (I.timing) fprintf(stderr, "[gpu reader] open: streams %.1f, page-locked chunks %.1f, run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_open2 - t_open1) * 1e3, (t_open3 - t_open2) * 1e3, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
     }
-    I.producer = std::thread([&I] { I.produce(); });
+    { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
+    I.cv.notify_all();
+    if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3);
     return true;
 }
 
 void GpuBamReader::Impl::produce()
 {
-    (void)hipSetDevice(device);
     for (;;) {
         GbRun* R;
         {
@@ -470,64 +495,110 @@ void GpuBamReader::Impl::produce()
 }
 
 // reads the next run of whole BGZF blocks and starts its inflation (block headers: host/bgzf.cpp plan_run — same checks)
-void GpuBamReader::Impl::fill_run(GbRun& R)
+// whole BGZF blocks of raw[0, have): appended to the run's block table (their deflate data will lie at d_off + ... in the run's
+// compressed buffer); returns the bytes they span, SIZE_MAX on a malformed stream (host/bgzf.cpp plan_run — same checks)
+size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal)
 {
-    R.rc = 1; R.final = false; R.utotal = 0; R.err.clear();
     const size_t kMaxBlock = 65536;
-    const size_t want = produced == 0 ? std::min<size_t>(run_bytes, 64u << 20) : run_bytes; // (a short first run: the first batch is there when the device is)
-    if (R.rawv.size() < run_bytes + (1u << 17)) { R.rawv.resize(run_bytes + (1u << 17)); advise_huge(R.rawv); } // (pageable: the runtime stages the copy at the link's speed; page-locking 3 x 256 MB would cost 0.1 s at start-up)
-    uint8_t* const raw = R.rawv.data();
-    const size_t carried = tail.size();
-    if (carried) memcpy(raw, tail.data(), carried);
-    size_t got = 0;
-    if (!file_eof) {
-        const double t0 = now_s();
-        got = fread(raw + carried, 1, want, f);
-        t_read += now_s() - t0;
-        if (got < want) file_eof = true;
-    }
-    const size_t have = carried + got;
-    if (!R.h_blocks.need(have / 28 + 2) || !R.h_crc.need(have / 28 + 2)) { R.rc = -2; return; }
-    size_t p = 0, utotal = 0, nb = 0;
+    size_t p = 0;
     while (p + 18 <= have) {
         const uint8_t* h = raw + p;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { R.err = "not a BGZF stream (bad gzip member header)"; R.rc = -1; return; }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { R.err = "not a BGZF stream (bad gzip member header)"; return SIZE_MAX; }
         const size_t xlen = h[10] | (h[11] << 8);
         if (p + 12 + xlen > have) break;
         size_t bsize = 0, x = 12;
         while (x + 4 <= 12 + xlen) {
             const size_t slen = h[x + 2] | (h[x + 3] << 8);
-            if (x + 4 + slen > 12 + xlen) { R.err = "corrupt BGZF block (extra subfield runs past the extra field)"; R.rc = -1; return; }
+            if (x + 4 + slen > 12 + xlen) { R.err = "corrupt BGZF block (extra subfield runs past the extra field)"; return SIZE_MAX; }
             if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
             x += 4 + slen;
         }
-        if (!bsize) { R.err = "BGZF block without BC extra field"; R.rc = -1; return; }
-        if (bsize < 12 + xlen + 8) { R.err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; R.rc = -1; return; }
+        if (!bsize) { R.err = "BGZF block without BC extra field"; return SIZE_MAX; }
+        if (bsize < 12 + xlen + 8) { R.err = "corrupt BGZF block (BSIZE smaller than header + trailer)"; return SIZE_MAX; }
         if (p + bsize > have) break;
         const uint8_t* t = raw + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
-        if (isize > kMaxBlock) { R.err = "BGZF block larger than 64 KiB"; R.rc = -1; return; }
+        if (isize > kMaxBlock) { R.err = "BGZF block larger than 64 KiB"; return SIZE_MAX; }
         if (isize) {
-            R.h_blocks.p[nb] = GiBlock{p + 12 + xlen, head + utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
-            R.h_crc.p[nb] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (nb + 1 > R.hb.size()) { R.hb.resize(2 * nb + 1024); R.hc.resize(2 * nb + 1024); }
+            R.hb[nb] = GiBlock{d_off + p + 12 + xlen, head + utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
+            R.hc[nb] = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
             ++nb;
         }
         utotal += isize;
         p += bsize;
     }
-    if (file_eof && p != have) { R.err = "truncated BGZF file"; R.rc = -1; return; }
-    tail.assign(raw + p, raw + have);
-    R.final = file_eof;
+    return p;
+}
+
+bool GpuBamReader::Impl::wait_ready()
+{
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return stop || dev_ready; });
+    if (stop) return false;
+    lk.unlock();
+    return hipSetDevice(device) == hipSuccess;
+}
+
+// Reads the next run of whole BGZF blocks and starts its inflation.  The first run is read before the device is up (into pageable
+// memory, copied staged); the others go through page-locked chunks, the read of one overlapping the copy of the one before.
+void GpuBamReader::Impl::fill_run(GbRun& R)
+{
+    R.rc = 1; R.final = false; R.utotal = 0; R.err.clear();
+    size_t nb = 0, utotal = 0, d_off = 0;
+    hipError_t he = hipSuccess;
+    if (produced == 0) {
+        const size_t want = std::min<size_t>(run_bytes, 64u << 20); // (a short first run: the first batch is there when the device is)
+        first_raw.resize(want + 64);
+        const double t0 = now_s();
+        const size_t got = fread(first_raw.data(), 1, want, f);
+        t_read += now_s() - t0;
+        if (got < want) file_eof = true;
+        const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal);
+        if (p == SIZE_MAX) { R.rc = -1; return; }
+        if (file_eof && p != got) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        tail.assign(first_raw.data() + p, first_raw.data() + got);
+        if (!wait_ready()) { R.rc = -2; return; }
+        if (!R.d_comp.need(p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; }
+        he = hipMemsetAsync(R.d_status, 0, 4, R.s);
+        if (he == hipSuccess && p) he = hipMemcpyAsync(R.d_comp.p, first_raw.data(), p, hipMemcpyHostToDevice, R.s);
+        d_off = p;
+    } else {
+        if (!wait_ready()) { R.rc = -2; return; }
+        he = hipMemsetAsync(R.d_status, 0, 4, R.s);
+        while (he == hipSuccess && d_off < run_bytes && !(file_eof && tail.empty())) {
+            PinChunk& C = chunks[chunk_i++ % kChunks];
+            if (C.used && hipEventSynchronize(C.done) != hipSuccess) { R.rc = -2; return; }
+            const size_t carried = tail.size();
+            if (carried) memcpy(C.p, tail.data(), carried);
+            size_t got = 0;
+            if (!file_eof) {
+                const double t0 = now_s();
+                got = fread(C.p + carried, 1, chunk_bytes, f);
+                t_read += now_s() - t0;
+                if (got < chunk_bytes) file_eof = true;
+            }
+            const size_t have = carried + got;
+            const size_t p = parse_blocks(R, C.p, have, d_off, nb, utotal);
+            if (p == SIZE_MAX) { R.rc = -1; return; }
+            if (file_eof && p != have) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+            tail.assign(C.p + p, C.p + have);
+            if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
+            if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, C.p, p, hipMemcpyHostToDevice, R.s);
+            if (he == hipSuccess) he = hipEventRecord(C.done, R.s);
+            C.used = true;
+            d_off += p;
+            if (p == 0 && got == 0) break;
+        }
+    }
+    R.final = file_eof && tail.empty();
     R.utotal = utotal;
-    // sized for a full run from the first (short) one on: growing means hipFree, and hipFree waits for every kernel on the device
-    const size_t nb_cap = std::max(nb + 1, run_bytes / 2048), out_cap = head + std::max(utotal, run_bytes / 2 * 9) + 64;
-    if (!R.d_comp.need(std::max(p, run_bytes + (1u << 17)) + 64) || !R.d_blocks.need(nb_cap) || !R.d_crc.need(nb_cap) || !R.d_out.need(out_cap)) { R.rc = -2; return; }
-    hipError_t he = hipMemsetAsync(R.d_status, 0, 4, R.s);
-    if (he == hipSuccess && p) he = hipMemcpyAsync(R.d_comp.p, raw, p, hipMemcpyHostToDevice, R.s);
-    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.h_blocks.p, nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s);
-    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_crc.p, R.h_crc.p, nb * 4, hipMemcpyHostToDevice, R.s);
+    if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1))) { R.rc = -2; return; }
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.hb.data(), nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s); // (pageable, small: staged at once)
+    if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_crc.p, R.hc.data(), nb * 4, hipMemcpyHostToDevice, R.s);
     if (he != hipSuccess) { R.rc = -2; return; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timing = this->timing && atoi(getenv("BQC_GB_TIMING")) >= 2; // (2: the kernels of every run, waited for)
     if (timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, R.s); }
     bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, R.d_out.p, R.d_crc.p, R.d_status, R.s);
     if (timing) (void)hipEventRecord(e1, R.s);
@@ -535,7 +606,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     if (timing) { // (waits: only with BQC_GB_TIMING)
         float ms = 0;
         (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "[gpu reader] run of %zu blocks, %.1f MB -> %.1f MB: inflate + crc %.1f ms, done at %.3f\n", nb, p / 1e6, utotal / 1e6, ms, now_s());
+        fprintf(stderr, "[gpu reader] run of %zu blocks, %.1f MB -> %.1f MB: inflate + crc %.1f ms, done at %.3f\n", nb, d_off / 1e6, utotal / 1e6, ms, now_s());
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
 }
@@ -607,7 +678,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         const uint64_t avail = I.end - I.cur;
         const uint8_t* base = I.win + I.cur;
         const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
-        const size_t seg_cap = std::max<size_t>(nseg, (I.head + I.run_bytes / 2 * 9) / GB_SEG + 2); // (for a full run's window at once: see fill_run)
+        const size_t seg_cap = std::max<size_t>(nseg, (I.head + I.run_bytes / 5 * 18 + 64) / GB_SEG + 2); // (for a full run's window at once: see open)
         if (!I.d_seg.need(seg_cap) || !I.h_seg.need(seg_cap) || !I.d_rec.need(seg_cap * GB_MAXR) || !I.d_base.need(seg_cap) || !I.h_base.need(seg_cap)) return fail_dev("out of device memory");
         hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
         if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");

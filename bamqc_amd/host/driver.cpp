@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -757,8 +758,12 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // the host reader would report, ...) ends this pass before anything has been reported, and the program starts over with the
     // host reader (host_reader_only).  BQC_GPU_DECODE=0: the host reader from the start.
     GpuBamReader gpu_rd;
-    const char* gd_env = getenv("BQC_GPU_DECODE");
-    const bool use_gpu_reader = !from_stdin && !shard && !host_reader_only && gd_env && atoi(gd_env) != 0 && bam_rd.header().lane_count != 0;
+    const char* gd_env = getenv("BQC_GPU_DECODE"); // 1: whenever possible, 0: never; unset: files of 256 MB and more (its set-up costs ~50 ms)
+    bool use_gpu_reader = !from_stdin && !shard && !host_reader_only && bam_rd.header().lane_count != 0 && !(gd_env && atoi(gd_env) == 0);
+    if (use_gpu_reader) { // a regular file: the reader opens it a second time
+        struct stat st;
+        use_gpu_reader = stat(opt.bamFile.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (gd_env || (uint64_t)st.st_size >= (256ull << 20));
+    }
     uint64_t first_record_u = 0;
     if (use_gpu_reader) {
         first_record_u = bam_rd.stream_pos();
@@ -795,6 +800,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // decode thread feeds batches; this thread submits them.  It starts right away: the first batches are inflated and
     // decoded while the FASTA file is read and the device is set up.
     BatchQueue Q;
+    std::atomic<bool> gpu_reader_opened{false};
     std::thread dec;
     auto stop_decoder = [&]() {
         if (!dec.joinable()) return;
@@ -805,7 +811,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (H.lane_count != 0) dec = std::thread([&]() {
         if (use_gpu_reader) {
             std::string e;
-            if (!gpu_rd.open(opt.bamFile.c_str(), opt.device, bam_rd.header(), first_record_u, opt.batch_reads, 256ull << 20, e)) {
+            const bool ok = gpu_rd.open(opt.bamFile.c_str(), opt.device, bam_rd.header(), first_record_u, opt.batch_reads, 256ull << 20, e);
+            gpu_reader_opened = true; // (the context is created after this: see there)
+            if (!ok) {
                 std::lock_guard<std::mutex> lk(Q.m);
                 Q.err = e; Q.err_code = GpuBamReader::kUnsupported; Q.done = true; Q.cv.notify_all();
                 return;
@@ -864,6 +872,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     std::thread creator([&] {
         const auto c0 = clk::now();
         if (warm.joinable()) warm.join();
+        // the GPU reader sets itself up first (streams, buffers: ~20 ms alone): side by side the two were measured to hold each other
+        // up at the runtime's locks, for up to 0.4 s
+        while (use_gpu_reader && !gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
         rc = bqc_create(&bo, &ctx);
         if (rc) create_err = bqc_last_error(nullptr);
         t_create_s = secs(c0, clk::now());
@@ -952,6 +963,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     recycle(true);
     if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
+    if (timing) fprintf(stderr, "[timing] records decoded %s\n", use_gpu_reader ? "on the GPU (csrc/gpu_bam.hip)" : "on the host");
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
                 (unsigned long long)n_total, t_decode, g_pins.t_register, t_submit, t_wait, secs(t_setup, clk::now()));
