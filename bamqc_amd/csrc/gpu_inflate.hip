@@ -1,6 +1,6 @@
-// gpu_inflate.hip — raw DEFLATE (RFC 1951) of BGZF blocks on the GPU (row N2: the host's inflate is the wall of every whole-file
-// run — 0.5 core-seconds per million reads on the CPU, against 0.25 ms of kernels).  OPT-IN (BQC_GPU_INFLATE=1 /
-// bqc_gpu_inflate_device): correct and tested against zlib, not yet faster end to end than 16 host threads — see "Measured".
+// gpu_inflate.hip — raw DEFLATE (RFC 1951) of BGZF blocks and their CRC-32 on the GPU (row N2).  Used by the BAM reader on the card
+// (gpu_bam.hip: the inflated bytes stay in device memory — the program's default for whole BAM files), and, opt-in and for
+// comparison only (BQC_GPU_INFLATE=1 / bqc_gpu_inflate_device), by the host reader's BGZF layer, which copies the bytes back.
 //
 // BGZF blocks are independent, at most 64 KiB, and carry their uncompressed size: ONE LANE PER BLOCK.  The state a decoder needs is
 // kept in LDS, shared out lane by lane (2.1 KB each): 9-bit root table of the literal/length code and 7-bit root table of the
@@ -9,7 +9,8 @@
 // out [entry][lane], so that the lanes' accesses to the same entry fall on different banks.  The bit buffer is refilled one word
 // ahead (the load's latency hides behind the symbols decoded meanwhile); literals are byte stores; a match is copied 32 / 16 / 4 / 1
 // bytes at a time from the lane's own output (requests of one wave to one address are served in order); length and distance
-// bases are computed, not looked up.  What comes out is checked on the host against the block's CRC-32 like the CPU decoder's output.
+// bases are computed, not looked up.  What comes out is checked against the block's CRC-32 like the CPU decoder's output: by k_gi_crc
+// below for the reader on the card, on the host for the copy-back path.
 //
 // Measured (MI355X, a run of 12.9 K blocks = 268 MB -> 844 MB, BGZF level 1): kernel 46 / 40 / 35 / 32 ms with 64 / 32 / 16 / 8
 // lanes per workgroup, H2D 5 ms, D2H into pageable memory 35 ms; the host decoder (16 threads) needs 80 ms for the same bytes.  A
@@ -18,13 +19,14 @@
 // iteration some lane of the wave has a match.  The kernel is latency-bound: its time is the time of one block (22 ms for 3.4 K
 // blocks, 32 ms for 13 K) until the card is full (76 lanes per CU with these tables: 19 K blocks), so the reader keeps several
 // moderate runs in flight (host/bgzf.cpp: workers with a stream and page-locked bounce buffers each, beside the host's decoder).
-// End to end the program does NOT get faster with it: 10 M reads 0.59-0.69 s against 0.51-0.53 s, 40 M reads 1.62 s (two workers
-// on the card beside the host's 16 threads) against 1.52 s, 1.88 s with four — the inflated bytes go back to the host (copies,
-// the runtime's locks shared with the batch pipeline's own copies and allocations), and the record decode that follows is host
-// work either way.  What makes it pay is the next step, not a faster copy: walk and decode the records on the card too (the
-// inflated bytes never return), with the tables cut to the canonical arrays alone (356 B per lane: 460 blocks per CU in
-// flight, a whole 10 M-read file in one launch), and the matches of a block resolved after its symbols are decoded (one round
-// trip per match instead of one per symbol).
+// With the bytes copied BACK the program does not get faster: 10 M reads 0.59-0.69 s against 0.51-0.53 s, 40 M reads 1.62 s (two
+// workers on the card beside the host's 16 threads) against 1.52 s — copies, the runtime's locks shared with the batch pipeline, and
+// the record decode that follows is host work either way.  It pays once the records are walked and decoded on the card as well
+// (gpu_bam.hip: 10 M reads in 0.41 s, record loop 0.16 s, of which this kernel is 0.13 s).
+// Tried and measured slower (30-60 %): listing the matches while the symbols are decoded and resolving them in a second loop — the
+// copies' round trips are the floor either way, and inside the symbol loop the lanes without a match make progress meanwhile.
+// Next: a small LDS window of the lane's recent output (near matches without a round trip); tables cut to the canonical arrays
+// alone (356 B per lane: 460 blocks per CU in flight).
 //
 // Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
 // incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input
