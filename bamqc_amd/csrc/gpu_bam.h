@@ -3,6 +3,7 @@
 // host arrays (the host pass of the aggregation needs them), the payload (bases, qualities, CIGARs) stays in device memory
 // (HostBatch::d_seq / d_qual / d_cigar — bqc_submit_async copies from wherever the columns live).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -25,6 +26,9 @@ public:
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
     double seconds_reading() const { return t_read_; } // time spent in fread
+    // set by open() once its device buffers are allocated (also when it fails before that): a caller that creates its own device
+    // context in another thread starts doing so from here on
+    std::atomic<bool> buffers_allocated{false};
 
 private:
     struct Impl;

@@ -323,7 +323,7 @@ struct GpuBamReader::Impl {
     hipEvent_t ev = nullptr;    // blocking
     FILE* f = nullptr;
     uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
-    size_t run_bytes = 192u << 20; // (the inflate kernel's time hardly depends on the number of blocks until the card is full: ~18 K blocks)
+    size_t run_bytes = 832u << 20; // (an inflate launch costs 20-50 ms whatever the number of blocks: few, large runs; the first one is 64 MB)
     size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
     static const int kRuns = 3; // one being walked, one being inflated, one being read
     GbRun runs[kRuns];
@@ -352,6 +352,8 @@ struct GpuBamReader::Impl {
     bool timing = false;
     double t_read = 0, t_wait_run = 0;
     uint64_t n_rewalk = 0;
+    double avg_rec_bytes = 0, avg_rec_bases = 0;
+    uint64_t grow_window = 0;
 
     ~Impl()
     {
@@ -375,9 +377,9 @@ struct GpuBamReader::Impl {
     bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
     // page-locked chunks the file is read into (from the second run on)
     struct PinChunk { uint8_t* p = nullptr; hipEvent_t done = nullptr; bool used = false; };
-    static const int kChunks = 3;
+    static const int kChunks = 2;
     PinChunk chunks[kChunks];
-    size_t chunk_bytes = 32u << 20;
+    size_t chunk_bytes = 16u << 20;
     int chunk_i = 0;
     raw_vector<uint8_t> first_raw; // the first run: read while the device is still starting
     bool dev_ready = false;        // (under m) streams and buffers exist: the producer may touch the device
@@ -410,43 +412,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.producer = std::thread([&I] { I.produce(); }); // reads the first run of the file while the device is set up below
     hipError_t he = hipSetDevice(device);
     const double t_open1 = now_s();
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
-    if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
-    if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
-    if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
-    // ONE stream for all runs: a process gets a handful of hardware queues, streams beyond them share one, and a 30 ms inflate
-    // kernel in a shared queue holds up whatever else is in it
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.ps, hipStreamNonBlocking);
-    for (GbRun& R : I.runs) {
-        R.s = I.ps;
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.ready, hipEventBlockingSync | hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.copied, hipEventBlockingSync | hipEventDisableTiming);
-        if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
-    }
-    const double t_open2 = now_s();
-    for (Impl::PinChunk& C : I.chunks) {
-        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, I.chunk_bytes + (1u << 17), hipHostMallocDefault);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
-    }
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
-    const double t_open3 = now_s();
-    // read-group ids -> lane index, column-wise: off[n] len[n] index[n]
-    std::vector<uint8_t> blob;
-    I.n_lane_ids = (uint32_t)hdr.lane_names.size();
-    I.lane_count = hdr.lane_count;
-    std::vector<uint32_t> cols(3 * (size_t)I.n_lane_ids + 1);
-    {
-        uint32_t l = 0;
-        for (const auto& kv : hdr.lane_names) {
-            cols[l] = (uint32_t)blob.size(); cols[I.n_lane_ids + l] = (uint32_t)kv.first.size(); cols[2 * I.n_lane_ids + l] = kv.second;
-            blob.insert(blob.end(), kv.first.begin(), kv.first.end());
-            ++l;
-        }
-    }
-    if (!I.d_lane_blob.need(blob.size() + 1) || !I.d_lane_tab.need(cols.size())) { err = "GPU reader: out of device memory"; return false; }
-    if (!blob.empty()) (void)hipMemcpy(I.d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
     // Everything the reader will need, now: an allocation (or a release) behind a running inflate kernel waits for that kernel.
     {
         // (a run inflates to ~3.3 x its size with BGZF level 1-6 on BAM records; a run that needs more grows its buffer, once)
@@ -463,8 +429,45 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         const double t_c = now_s();
         g_pool.fill(typical, 6);
         g_pool_cap_of_live = g_pool.cap;
-        if (I.timing) fprintf(stderr, "[gpu reader] open: streams %.1f, page-locked chunks %.1f, run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_open2 - t_open1) * 1e3, (t_open3 - t_open2) * 1e3, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
+        buffers_allocated = true; // (the caller creates its context from here on: side by side with these allocations the two were measured to hold each other up)
+        if (I.timing) fprintf(stderr, "[gpu reader] open: run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
     }
+
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
+    if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
+    // ONE stream for all runs: a process gets a handful of hardware queues, streams beyond them share one, and a 30 ms inflate
+    // kernel in a shared queue holds up whatever else is in it
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.ps, hipStreamNonBlocking);
+    for (GbRun& R : I.runs) {
+        R.s = I.ps;
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.ready, hipEventBlockingSync | hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&R.copied, hipEventBlockingSync | hipEventDisableTiming);
+        if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
+    }
+    for (Impl::PinChunk& C : I.chunks) {
+        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, I.chunk_bytes + (1u << 17), hipHostMallocDefault);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
+    }
+    if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
+    // read-group ids -> lane index, column-wise: off[n] len[n] index[n]
+    std::vector<uint8_t> blob;
+    I.n_lane_ids = (uint32_t)hdr.lane_names.size();
+    I.lane_count = hdr.lane_count;
+    std::vector<uint32_t> cols(3 * (size_t)I.n_lane_ids + 1);
+    {
+        uint32_t l = 0;
+        for (const auto& kv : hdr.lane_names) {
+            cols[l] = (uint32_t)blob.size(); cols[I.n_lane_ids + l] = (uint32_t)kv.first.size(); cols[2 * I.n_lane_ids + l] = kv.second;
+            blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+            ++l;
+        }
+    }
+    if (!I.d_lane_blob.need(blob.size() + 1) || !I.d_lane_tab.need(cols.size())) { err = "GPU reader: out of device memory"; return false; }
+    if (!blob.empty()) (void)hipMemcpy(I.d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
     I.cv.notify_all();
     if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3);
@@ -548,12 +551,20 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     size_t nb = 0, utotal = 0, d_off = 0;
     hipError_t he = hipSuccess;
     if (produced == 0) {
-        const size_t want = std::min<size_t>(run_bytes, 64u << 20); // (a short first run: the first batch is there when the device is)
-        first_raw.resize(want + 64);
-        const double t0 = now_s();
-        const size_t got = fread(first_raw.data(), 1, want, f);
-        t_read += now_s() - t0;
-        if (got < want) file_eof = true;
+        // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
+        const size_t piece = 32u << 20, cap = std::min<size_t>(run_bytes, 640u << 20);
+        first_raw.resize(cap + 64);
+        size_t got = 0;
+        for (;;) {
+            const size_t want = std::min(piece, cap - got);
+            const double t0 = now_s();
+            const size_t g = fread(first_raw.data() + got, 1, want, f);
+            t_read += now_s() - t0;
+            got += g;
+            if (g < want) { file_eof = true; break; }
+            if (got >= cap) break;
+            if (got >= (64u << 20)) { std::lock_guard<std::mutex> lk(m); if (dev_ready || stop) break; }
+        }
         const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal);
         if (p == SIZE_MAX) { R.rc = -1; return; }
         if (file_eof && p != got) { R.err = "truncated BGZF file"; R.rc = -1; return; }
@@ -566,7 +577,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     } else {
         if (!wait_ready()) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
-        while (he == hipSuccess && d_off < run_bytes && !(file_eof && tail.empty())) {
+        while (he == hipSuccess && d_off < run_bytes && utotal < ((size_t)3200 << 20) && !(file_eof && tail.empty())) { // (a window's offsets are 32-bit)
             PinChunk& C = chunks[chunk_i++ % kChunks];
             if (C.used && hipEventSynchronize(C.done) != hipSuccess) { R.rc = -2; return; }
             const size_t carried = tail.size();
@@ -675,7 +686,15 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             t_adv += now_s() - ta;
             continue;
         }
-        const uint64_t avail = I.end - I.cur;
+        // the walk covers what a batch is expected to need (a window may hold many batches); a record cut off by that is where the batch ends
+        uint64_t avail = I.end - I.cur;
+        {
+            const double per_rec = I.avg_rec_bytes > 0 ? I.avg_rec_bytes : 400.0;
+            double want = (double)std::min<size_t>(max_reads, 1u << 22) * per_rec;
+            if (I.avg_rec_bases > 0) want = std::min(want, ((double)max_bases / I.avg_rec_bases + 1.0) * per_rec);
+            want = want * 1.1 + (double)(4u << 20) + (double)I.grow_window;
+            if ((double)avail > want) avail = (uint64_t)want;
+        }
         const uint8_t* base = I.win + I.cur;
         const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
         const size_t seg_cap = std::max<size_t>(nseg, (I.head + I.run_bytes / 5 * 18 + 64) / GB_SEG + 2); // (for a full run's window at once: see open)
@@ -705,6 +724,8 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             pos = S.exit;
             if (S.flags & GB_INCOMPLETE) break;
         }
+        if (n == 0 && avail < I.end - I.cur) { I.grow_window += 2 * avail + (64u << 20); continue; } // (a record longer than the walked part of the window)
+        I.grow_window = 0;
         if (n == 0) { // not one complete record in the window: the next run's bytes behind it
             if (I.stream_done) return unsupported("the file ends inside a record");
             const int rc = I.advance(err);
@@ -768,6 +789,8 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         o.d_seq = pay + o_seq; o.d_qual = pay + o_qual; o.d_cigar = (const uint32_t*)(pay + o_cig);
         I.cur += pos;
         nrec_ += n;
+        I.avg_rec_bytes = (double)pos / (double)n;
+        I.avg_rec_bases = (double)bases / (double)n;
         t_read_ = I.t_read;
         t_dec = now_s() - td;
         if (I.timing)

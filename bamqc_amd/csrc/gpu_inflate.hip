@@ -306,6 +306,276 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
 }
 
 // ---------------------------------------------------------------------------------------------------
+// the same decoder with 356 bytes of LDS per block instead of 2144: whole files in one launch
+// ---------------------------------------------------------------------------------------------------
+// k_inflate's time is the time a lane needs for its block, and LDS decides how many lanes a launch may hold (72 per CU with the
+// root tables).  Here a code is kept as what a canonical code IS — for every length the left-aligned limit `(first code + count)
+// << (15 - length)` (the next length's first code) and the rank of its first symbol, in registers — and a symbol is found by
+// comparing the next 15 bits, bit-reversed, against the limits (they are non-decreasing: its length is 1 + the number of limits
+// it reaches) and reading symbol `rank + (bits - first) >> (15 - length)` of the canonical order, which is all that stays in
+// LDS: a byte per literal/length symbol plus a bit for "256 and above", a byte per distance symbol.  More VALU work per symbol
+// (~150 instructions), which the SIMDs have to spare: the loop waits for memory most of the time.  460 blocks per CU in flight.
+#define GL_LS 0     // [288] low byte of the literal/length symbols in canonical order (during the code lengths: the precode's 19)
+#define GL_LB 288   // [36]  bit i: symbol i of that order is >= 256
+#define GL_DS 324   // [32]  distance symbols in canonical order
+#define GL_BYTES 356
+#define GL_AT(k) ((k) * NL)
+
+namespace {
+struct Canon { uint32_t lim[8], off[8]; }; // 16-bit halves: lim[l], off[l] for l = 0..15
+__device__ __forceinline__ uint32_t cn_lim(const Canon& C, int l) { return (C.lim[l >> 1] >> (16 * (l & 1))) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t cn_off(const Canon& C, int l) { return (C.off[l >> 1] >> (16 * (l & 1))) & 0xFFFFu; }
+
+// count[l] codes of length l -> limits and ranks; zlib's acceptance rules (kind 0: the code-length code must be complete)
+__device__ __forceinline__ bool canon_make(Canon& C, const uint32_t (&count)[16], bool must_be_complete)
+{
+    int left = 1;
+    uint32_t maxl = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        left = (left << 1) - (int)count[l];
+        if (left < 0) return false;
+        if (count[l]) maxl = (uint32_t)l;
+    }
+    if (left > 0 && (must_be_complete || maxl > 1)) return false;
+    uint32_t lim[16], off[16];
+    lim[0] = 0; off[0] = 0; off[1] = 0;
+    uint32_t code = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        code = (code + (l > 1 ? count[l - 1] : 0u)) << 1;
+        lim[l] = (code + count[l]) << (15 - l);
+        if (l < 15) off[l + 1] = off[l] + count[l];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { C.lim[k] = lim[2 * k] | (lim[2 * k + 1] << 16); C.off[k] = off[2 * k] | (off[2 * k + 1] << 16); }
+    return true;
+}
+
+// index of the next symbol in canonical order and its code length (0: no such code)
+__device__ __forceinline__ uint32_t canon_find(const Canon& C, uint32_t bits32, uint32_t& len)
+{
+    const uint32_t r = __brev(bits32) >> 17; // the next 15 bits, first bit on top
+    uint32_t n = 1, first = 0, offv = cn_off(C, 1);
+#pragma unroll
+    for (int l = 1; l <= 14; ++l) {
+        const uint32_t lm = cn_lim(C, l);
+        const bool ge = r >= lm;
+        n += ge;
+        first = ge ? lm : first;
+        offv = ge ? cn_off(C, l + 1) : offv;
+    }
+    len = r >= cn_lim(C, 15) ? 0u : n;
+    return offv + ((r - first) >> (15u - n));
+}
+} // namespace
+
+template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+{
+    extern __shared__ uint8_t lds8[];
+    const uint32_t bi = blockIdx.x * NL + threadIdx.x;
+    if (bi >= n_blocks) return;
+    uint8_t* L = lds8 + threadIdx.x;
+    const GiBlock blk = blocks[bi];
+    const uint8_t* const c0 = comp + blk.coff;
+    const uint8_t* const cend = c0 + blk.csize;
+    Bits B;
+    B.start(c0, cend);
+    uint8_t* const o0 = out + blk.uoff;
+    const uint32_t usize = blk.usize;
+    uint32_t o = 0;
+    uint32_t st = 0;
+    uint8_t lens[320]; // code lengths while the codes are built (private memory)
+    for (;;) {
+        B.refill();
+        if (B.byte_pos() > cend) { st = GI_ERR_TRUNC; break; }
+        const uint32_t bfinal = B.take(1), btype = B.take(2);
+        if (btype == 0u) { // stored
+            B.drop(B.bc & 7u);
+            const uint8_t* p = B.byte_pos();
+            if (p + 4 > cend) { st = GI_ERR_TRUNC; break; }
+            const uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) { st = GI_ERR_DATA; break; }
+            p += 4;
+            if (p + len > cend || o + len > usize) { st = GI_ERR_TRUNC; break; }
+            uint32_t k = 0;
+            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + o + k) = *(const gi_u32_u*)(p + k);
+            for (; k < len; ++k) o0[o + k] = p[k];
+            o += len;
+            B.start(p + len, cend);
+            if (bfinal) break;
+            continue;
+        }
+        if (btype == 3u) { st = GI_ERR_DATA; break; }
+        uint32_t hlit = 288, hdist = 32;
+        if (btype == 1u) { // fixed code (the two unused 5-bit distance codes decode to symbols 30 / 31: rejected below)
+            for (uint32_t i = 0; i < 144; ++i) lens[i] = 8;
+            for (uint32_t i = 144; i < 256; ++i) lens[i] = 9;
+            for (uint32_t i = 256; i < 280; ++i) lens[i] = 7;
+            for (uint32_t i = 280; i < 288; ++i) lens[i] = 8;
+            for (uint32_t i = 0; i < 32; ++i) lens[288 + i] = 5;
+        } else {
+            B.refill();
+            hlit = B.take(5) + 257u; hdist = B.take(5) + 1u;
+            const uint32_t hclen = B.take(4) + 4u;
+            if (hlit > 286u || hdist > 30u) { st = GI_ERR_DATA; break; }
+            uint32_t pl[19];
+#pragma unroll
+            for (int i = 0; i < 19; ++i) pl[i] = 0;
+            for (uint32_t i = 0; i < hclen; ++i) {
+                B.refill();
+                const uint32_t v = B.take(3), which = c_pre_order[i];
+#pragma unroll
+                for (int k = 0; k < 19; ++k) pl[k] = which == (uint32_t)k ? v : pl[k];
+            }
+            uint32_t cnt[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) cnt[l] = 0;
+#pragma unroll
+            for (int k = 0; k < 19; ++k)
+#pragma unroll
+                for (int l = 1; l < 8; ++l) cnt[l] += pl[k] == (uint32_t)l;
+            Canon P;
+            if (!canon_make(P, cnt, true)) { st = GI_ERR_DATA; break; }
+            { // the precode's symbols in canonical order
+                uint32_t pos[8];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) pos[l] = cn_off(P, l);
+#pragma unroll
+                for (int k = 0; k < 19; ++k)
+#pragma unroll
+                    for (int l = 1; l < 8; ++l)
+                        if (pl[k] == (uint32_t)l) { L[GL_AT(GL_LS + pos[l])] = (uint8_t)k; ++pos[l]; }
+            }
+            const uint32_t total = hlit + hdist;
+            uint32_t i = 0, prev = 0;
+            bool bad = false;
+            while (i < total) {
+                B.refill();
+                uint32_t cl;
+                const uint32_t idx = canon_find(P, (uint32_t)B.bb, cl);
+                if (!cl || idx >= 19u) { bad = true; break; }
+                B.drop(cl);
+                const uint32_t sym = L[GL_AT(GL_LS + idx)];
+                if (sym < 16u) { lens[i++] = (uint8_t)sym; prev = sym; continue; }
+                uint32_t rep, val = 0;
+                if (sym == 16u) { if (i == 0) { bad = true; break; } val = prev; rep = 3u + B.take(2); }
+                else if (sym == 17u) rep = 3u + B.take(3);
+                else rep = 11u + B.take(7);
+                if (i + rep > total) { bad = true; break; }
+                for (uint32_t k = 0; k < rep; ++k) lens[i + k] = (uint8_t)val;
+                i += rep;
+                prev = val;
+            }
+            if (bad) { st = GI_ERR_DATA; break; }
+            if (lens[256] == 0) { st = GI_ERR_DATA; break; } // no end-of-block code
+            for (uint32_t k = hdist; k-- > 0;) lens[288 + k] = lens[hlit + k]; // (from the back: the ranges may overlap)
+        }
+        // ---- the two codes: limits and ranks in registers, symbols in canonical order in LDS
+        Canon CL, CD;
+        {
+            uint32_t cnt[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) cnt[l] = 0;
+            for (uint32_t s = 0; s < hlit; ++s) {
+                const uint32_t len = lens[s];
+#pragma unroll
+                for (int l = 1; l < 16; ++l) cnt[l] += len == (uint32_t)l;
+            }
+            if (!canon_make(CL, cnt, false)) { st = GI_ERR_DATA; break; }
+            uint32_t pos[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) pos[l] = cn_off(CL, l);
+            for (uint32_t k = 0; k < 36; ++k) L[GL_AT(GL_LB + k)] = 0;
+            for (uint32_t s = 0; s < hlit; ++s) {
+                const uint32_t len = lens[s];
+                if (!len) continue;
+                uint32_t at = 0;
+#pragma unroll
+                for (int l = 1; l < 16; ++l)
+                    if (len == (uint32_t)l) { at = pos[l]; ++pos[l]; }
+                L[GL_AT(GL_LS + at)] = (uint8_t)s;
+                if (s >= 256u) L[GL_AT(GL_LB + (at >> 3))] |= (uint8_t)(1u << (at & 7u));
+            }
+        }
+        {
+            uint32_t cnt[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) cnt[l] = 0;
+            for (uint32_t s = 0; s < hdist; ++s) {
+                const uint32_t len = lens[288 + s];
+#pragma unroll
+                for (int l = 1; l < 16; ++l) cnt[l] += len == (uint32_t)l;
+            }
+            if (!canon_make(CD, cnt, false)) { st = GI_ERR_DATA; break; }
+            uint32_t pos[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) pos[l] = cn_off(CD, l);
+            for (uint32_t s = 0; s < hdist; ++s) {
+                const uint32_t len = lens[288 + s];
+                if (!len) continue;
+                uint32_t at = 0;
+#pragma unroll
+                for (int l = 1; l < 16; ++l)
+                    if (len == (uint32_t)l) { at = pos[l]; ++pos[l]; }
+                L[GL_AT(GL_DS + at)] = (uint8_t)s;
+            }
+        }
+        // ---- symbols of one block
+        for (;;) {
+            B.refill();
+            uint32_t cl;
+            const uint32_t idx = canon_find(CL, (uint32_t)B.bb, cl);
+            if (!cl || idx >= 288u) { st = GI_ERR_DATA; break; }
+            B.drop(cl);
+            const uint32_t sym = (uint32_t)L[GL_AT(GL_LS + idx)] | (((uint32_t)L[GL_AT(GL_LB + (idx >> 3))] >> (idx & 7u)) & 1u) << 8;
+            if (sym < 256u) {
+                if (o >= usize) { st = GI_ERR_SIZE; break; }
+                o0[o++] = (uint8_t)sym;
+                continue;
+            }
+            if (sym == 256u) break;
+            if (sym > 285u) { st = GI_ERR_DATA; break; }
+            B.refill();
+            const uint32_t ls = sym - 257u, le = ls < 8u || ls == 28u ? 0u : (ls - 4u) >> 2;
+            const uint32_t length = (ls < 8u ? ls + 3u : ls == 28u ? 258u : ((4u + (ls & 3u)) << le) + 3u) + B.take(le);
+            B.refill();
+            uint32_t dl;
+            const uint32_t didx = canon_find(CD, (uint32_t)B.bb, dl);
+            if (!dl || didx >= 32u) { st = GI_ERR_DATA; break; }
+            B.drop(dl);
+            const uint32_t ds = L[GL_AT(GL_DS + didx)];
+            if (ds > 29u) { st = GI_ERR_DATA; break; }
+            B.refill();
+            const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
+            const uint32_t dist = (ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u) + B.take(de);
+            if (dist > o || o + length > usize) { st = dist > o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
+            uint8_t* dst = o0 + o;
+            const uint8_t* src = dst - dist;
+            o += length;
+            if (dist >= 32u && o + 32u <= usize) {
+                for (uint32_t k = 0; k < length; k += 32u) {
+                    const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
+                    *(gi_u32x4_u*)(dst + k) = a;
+                    *(gi_u32x4_u*)(dst + k + 16) = b;
+                }
+            } else if (dist >= 16u && o + 16u <= usize) {
+                for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
+            } else if (dist >= 4u && o + 4u <= usize) {
+                for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
+            } else {
+                for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
+            }
+        }
+        if (st || bfinal) break;
+    }
+    if (!st && o != usize) st = GI_ERR_SIZE;
+    if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
+    if (st) atomicOr(status, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // CRC-32 of the inflated blocks on the card (for readers that keep the inflated bytes there: csrc/gpu_bam.hip)
 // ---------------------------------------------------------------------------------------------------
 // A wave per block: lane 0 takes the first usize - 63 L bytes, every other lane L = usize / 64 bytes; each computes the standard
@@ -376,6 +646,17 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
 {
     if (!n_blocks) return;
     static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 4; // (10 K blocks: 24 ms with 4 blocks per workgroup, 29 with 8, 34 with 16, 30 with 2)
+    // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go — 41.7 K blocks in
+    // 53 ms against 72 ms; for fewer blocks the root tables are faster (3.4 K blocks: 20 ms against 30).  BQC_GI_LEAN: 0 never, N always
+    // with N blocks per workgroup
+    static const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
+    const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 32 : 0);
+#define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status)
+    if (lean) {
+        if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 64) GI_LAUNCH_L(64); else GI_LAUNCH_L(16);
+        if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
+        return;
+    }
 #define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status)
     if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
@@ -461,7 +742,8 @@ extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_
     static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 8;
     if (timing) (void)hipEventRecord(ev[1], g->stream);
 #define GI_LAUNCH(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((uint32_t)((n_blocks + NL - 1) / NL)), dim3(NL), GI_U16 * 2 * NL, g->stream, g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, g->d_status)
-    if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 16) GI_LAUNCH(16); else GI_LAUNCH(8);
+    if (getenv("BQC_GI_LEAN") && atoi(getenv("BQC_GI_LEAN"))) bqc_gpu_inflate_launch(g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, nullptr, g->d_status, g->stream); // (tests: the lean kernel through this path too)
+    else if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 16) GI_LAUNCH(16); else GI_LAUNCH(8);
     if (timing) (void)hipEventRecord(ev[2], g->stream);
     if (hipMemcpyAsync(out, g->d_out, out_bytes, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->h_status, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;

@@ -872,8 +872,8 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     std::thread creator([&] {
         const auto c0 = clk::now();
         if (warm.joinable()) warm.join();
-        // the GPU reader sets itself up first (streams, buffers: ~20 ms alone): side by side the two were measured to hold each other
-        // up at the runtime's locks, for up to 0.4 s
+        // the GPU reader sets itself up first (buffers, streams, page-locked chunks: ~50 ms): side by side the two were measured to hold
+        // each other up at the runtime's locks — context creation 0.4-0.65 s instead of 0.1 in one run out of three
         while (use_gpu_reader && !gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
         rc = bqc_create(&bo, &ctx);
         if (rc) create_err = bqc_last_error(nullptr);
