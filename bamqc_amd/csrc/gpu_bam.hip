@@ -380,6 +380,7 @@ struct GpuBamReader::Impl {
     static const int kChunks = 2;
     PinChunk chunks[kChunks];
     size_t chunk_bytes = 16u << 20;
+    size_t kMaxRunOut = (size_t)3200 << 20; // uncompressed bytes of a run (BQC_GB_MAX_RUN_OUT_MB: tests)
     int chunk_i = 0;
     raw_vector<uint8_t> first_raw; // the first run: read while the device is still starting
     bool dev_ready = false;        // (under m) streams and buffers exist: the producer may touch the device
@@ -404,6 +405,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.device = device;
     I.timing = getenv("BQC_GB_TIMING") != nullptr;
     if (const char* e = getenv("BQC_GB_RUN_MB")) I.run_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char* e = getenv("BQC_GB_MAX_RUN_OUT_MB")) I.kMaxRunOut = (size_t)std::max(1, atoi(e)) << 20;
     I.f = fopen(path, "rb");
     if (!I.f) { err = std::string("could not open ") + path; return false; }
     setvbuf(I.f, nullptr, _IONBF, 0);
@@ -522,6 +524,7 @@ size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t hav
         const uint8_t* t = raw + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
         if (isize > kMaxBlock) { R.err = "BGZF block larger than 64 KiB"; return SIZE_MAX; }
+        if (utotal + isize > kMaxRunOut) break; // (a window's offsets are 32-bit: the rest belongs to the next run)
         if (isize) {
             if (nb + 1 > R.hb.size()) { R.hb.resize(2 * nb + 1024); R.hc.resize(2 * nb + 1024); }
             R.hb[nb] = GiBlock{d_off + p + 12 + xlen, head + utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
@@ -567,7 +570,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         }
         const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal);
         if (p == SIZE_MAX) { R.rc = -1; return; }
-        if (file_eof && p != got) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        if (file_eof && p != got && got - p < 65536 + 64 && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
         tail.assign(first_raw.data() + p, first_raw.data() + got);
         if (!wait_ready()) { R.rc = -2; return; }
         if (!R.d_comp.need(p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; }
@@ -577,13 +580,16 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     } else {
         if (!wait_ready()) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
-        while (he == hipSuccess && d_off < run_bytes && utotal < ((size_t)3200 << 20) && !(file_eof && tail.empty())) { // (a window's offsets are 32-bit)
+        while (he == hipSuccess && d_off < run_bytes && utotal + 65536 <= kMaxRunOut && !(file_eof && tail.empty())) {
             PinChunk& C = chunks[chunk_i++ % kChunks];
             if (C.used && hipEventSynchronize(C.done) != hipSuccess) { R.rc = -2; return; }
-            const size_t carried = tail.size();
+            // the chunk: what the run before left over (a partial block; a lot only when that run stopped at its size limit), then the file
+            const size_t carried = std::min(tail.size(), chunk_bytes + (1u << 16));
             if (carried) memcpy(C.p, tail.data(), carried);
+            const bool tail_only = carried < tail.size() || carried > (1u << 16);
+            std::vector<uint8_t> rest(tail.begin() + carried, tail.end());
             size_t got = 0;
-            if (!file_eof) {
+            if (!file_eof && !tail_only) {
                 const double t0 = now_s();
                 got = fread(C.p + carried, 1, chunk_bytes, f);
                 t_read += now_s() - t0;
@@ -592,14 +598,16 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
             const size_t have = carried + got;
             const size_t p = parse_blocks(R, C.p, have, d_off, nb, utotal);
             if (p == SIZE_MAX) { R.rc = -1; return; }
-            if (file_eof && p != have) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+            const bool stopped_for_size = utotal + 65536 > kMaxRunOut;
+            if (file_eof && rest.empty() && p != have && !stopped_for_size) { R.err = "truncated BGZF file"; R.rc = -1; return; }
             tail.assign(C.p + p, C.p + have);
+            tail.insert(tail.end(), rest.begin(), rest.end());
             if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
             if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, C.p, p, hipMemcpyHostToDevice, R.s);
             if (he == hipSuccess) he = hipEventRecord(C.done, R.s);
             C.used = true;
             d_off += p;
-            if (p == 0 && got == 0) break;
+            if (p == 0 && got == 0 && rest.empty()) break;
         }
     }
     R.final = file_eof && tail.empty();

@@ -52,6 +52,20 @@ def test_gpu_reader_matches_host_reader(tmp_path, shape):
         same(host, gpu)
 
 
+def test_small_runs_and_the_size_limit_of_a_run(tmp_path, monkeypatch):
+    """Runs of 8 MB of compressed file, each cut off at 24 MB of inflated bytes (a window's offsets are 32-bit: 3.2 GB in production):
+    the blocks behind the cut go to the next run, records run across every kind of boundary."""
+    path = str(tmp_path / "x.bam")
+    hostio.synth_stream(path, None, seed=41, n_reads=600_000, ref_names=["chr1", "chr2"], ref_lens=[3_000_000, 2_000_000], n_lanes=2, level=6)
+    host, _ = all_columns(path, 200_000)
+    monkeypatch.setenv("BQC_GB_RUN_MB", "8")
+    monkeypatch.setenv("BQC_GB_MAX_RUN_OUT_MB", "24")
+    for batch_reads in (50_000, 1 << 20):
+        gpu, nb = all_columns(path, batch_reads, gpu=0)
+        assert nb >= 7
+        same(host, gpu)
+
+
 def test_wild_records_every_tag_type(tmp_path):
     """Python-written BAM: records straddling BGZF blocks of random size and compression level (stored blocks too), every tag
     type around RG / NM / AS, reads without bases or qualities."""
