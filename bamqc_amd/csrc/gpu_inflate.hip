@@ -22,11 +22,12 @@
 // With the bytes copied BACK the program does not get faster: 10 M reads 0.59-0.69 s against 0.51-0.53 s, 40 M reads 1.62 s (two
 // workers on the card beside the host's 16 threads) against 1.52 s — copies, the runtime's locks shared with the batch pipeline, and
 // the record decode that follows is host work either way.  It pays once the records are walked and decoded on the card as well
-// (gpu_bam.hip: 10 M reads in 0.41 s, record loop 0.16 s, of which this kernel is 0.13 s).
+// (gpu_bam.hip: 10 M reads in 0.36 s, record loop 0.11 s, of which the inflate kernels are 0.06 s).
 // Tried and measured slower (30-60 %): listing the matches while the symbols are decoded and resolving them in a second loop — the
 // copies' round trips are the floor either way, and inside the symbol loop the lanes without a match make progress meanwhile.
-// Next: a small LDS window of the lane's recent output (near matches without a round trip); tables cut to the canonical arrays
-// alone (356 B per lane: 460 blocks per CU in flight).
+// Also slower (8 %): holding a short match's bytes in registers until the lane's second match after it (the compiler's vmcnt(0)
+// waits make the deferral void).  Next: literal bytes gathered in registers and stored 8-16 at a time (a refill of the bit buffer
+// waits with vmcnt(0), which on gfx9 also holds the last literal's store: without the copies a launch still takes 2/3 of its time).
 //
 // Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
 // incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input
