@@ -271,7 +271,8 @@ template <typename T> struct PinBuf {
 // 30 ms inflate kernel were measured to wait for it), all of one size, handed back here when a batch object dies.
 struct PayloadPool {
     std::mutex m;
-    std::vector<void*> free_list;
+    std::vector<void*> free_list;          // buffers of `cap` bytes
+    std::vector<std::pair<void*, size_t>> owned; // every buffer the pool has allocated and not released, with its size
     size_t cap = 0;
     void* take(size_t need)
     {
@@ -284,18 +285,34 @@ struct PayloadPool {
     void fill(size_t bytes, int n)
     {
         std::lock_guard<std::mutex> lk(m);
-        if (bytes > cap) { for (void* p : free_list) (void)hipFree(p); free_list.clear(); cap = bytes; }
-        while ((int)free_list.size() < n) { void* p = nullptr; if (hipMalloc(&p, cap) != hipSuccess) break; free_list.push_back(p); }
+        if (bytes > cap) { // larger batches than before: the smaller buffers go (those handed out are released when they come back)
+            for (void* p : free_list) { forget(p); (void)hipFree(p); }
+            free_list.clear();
+            cap = bytes;
+        }
+        while ((int)free_list.size() < n) {
+            void* p = nullptr;
+            if (hipMalloc(&p, cap) != hipSuccess) break;
+            free_list.push_back(p);
+            owned.emplace_back(p, cap);
+        }
     }
-    void give(void* p, size_t bytes)
+    void give(void* p) // a batch object lets go of its buffer (the pool's or its own)
     {
         std::lock_guard<std::mutex> lk(m);
-        if (bytes == cap && free_list.size() < 16) free_list.push_back(p); else (void)hipFree(p);
+        size_t bytes = 0;
+        for (auto& kv : owned) if (kv.first == p) bytes = kv.second;
+        if (bytes == cap && bytes && free_list.size() < 16) { free_list.push_back(p); return; }
+        forget(p);
+        (void)hipFree(p);
+    }
+    void forget(void* p)
+    {
+        for (size_t i = 0; i < owned.size(); ++i) if (owned[i].first == p) { owned[i] = owned.back(); owned.pop_back(); return; }
     }
 };
 PayloadPool g_pool;
-size_t g_pool_cap_of_live = 0; // (capacity of the buffers handed out: all the same while one reader is open)
-void dev_free_hook(void* p) { g_pool.give(p, g_pool_cap_of_live); }
+void dev_free_hook(void* p) { g_pool.give(p); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
 
@@ -430,7 +447,6 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         const size_t typical = std::min<size_t>(reads * 360, batch_bases / 2 * 3 + (64u << 20)) + (1u << 20);
         const double t_c = now_s();
         g_pool.fill(typical, 6);
-        g_pool_cap_of_live = g_pool.cap;
         buffers_allocated = true; // (the caller creates its context from here on: side by side with these allocations the two were measured to hold each other up)
         if (I.timing) fprintf(stderr, "[gpu reader] open: run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
     }

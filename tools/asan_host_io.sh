@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -o $T/check tools/host_io_check.cpp \
-    bamqc_amd/host/bam_io.cpp bamqc_amd/host/bgzf.cpp bamqc_amd/host/inflate_fast.cpp bamqc_amd/host/crc32_fast.cpp -lz -lpthread
+    bamqc_amd/host/bam_io.cpp bamqc_amd/host/bgzf.cpp bamqc_amd/host/inflate_fast.cpp bamqc_amd/host/crc32_fast.cpp tools/gpu_inflate_stub.cpp -lz -lpthread
 python - "$T" <<'PY'
 import sys, random, gzip
 sys.path.insert(0, ".")
