@@ -474,29 +474,40 @@ void sketch_state_import(SketchDevice* sk, const uint64_t* src, hipStream_t s)
                            (uint64_t)sk->ctr_per_level);
 }
 
+// per level: how many counters are 0, how many are 1 (all the estimators F0 / f1 need of the 16 M counters of a sketch)
+__global__ __launch_bounds__(256) void k_sketch_zero_one(const uint32_t* __restrict__ counters, uint64_t R, unsigned long long* __restrict__ out /* [32][2] */)
+{
+    const uint32_t w = blockIdx.y;
+    const uint32_t* t = counters + (uint64_t)w * R;
+    uint32_t z = 0, o = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < R; j += (uint64_t)gridDim.x * blockDim.x) { const uint32_t v = t[j]; z += v == 0u; o += v == 1u; }
+    for (int d = 32; d; d >>= 1) { z += __shfl_down(z, d, 64); o += __shfl_down(o, d, 64); }
+    if ((threadIdx.x & 63u) == 0) { if (z) atomicAdd(out + 2 * w, (unsigned long long)z); if (o) atomicAdd(out + 2 * w + 1, (unsigned long long)o); }
+}
+
 bool sketch_finalize(SketchDevice* sk, uint32_t lane, std::vector<bqc_sketch_counts>& out, hipStream_t s, std::string& err)
 {
     out.clear();
-    const size_t R = sk->ctr_per_level, n_ctr = R * 32;
-    std::vector<uint32_t> raw(n_ctr);
+    const size_t R = sk->ctr_per_level;
     std::vector<uint64_t> f2(sk->f2size);
+    unsigned long long* d_zo = nullptr;
+    if (hipMalloc((void**)&d_zo, 64 * 8) != hipSuccess) { err = "device allocation failed"; return false; }
+    struct Free { void* p; ~Free() { (void)hipFree(p); } } free_zo{d_zo};
     for (uint32_t p = 0; p < sk->n_pairs; ++p) {
         const DevSketch& D = sk->ds[(size_t)lane * sk->n_pairs + p];
         uint64_t sum_count = 0;
+        unsigned long long zo[64];
+        (void)hipMemsetAsync(d_zo, 0, sizeof zo, s);
+        hipLaunchKernelGGL(k_sketch_zero_one, dim3(64, 32), dim3(256), 0, s, D.counters, (uint64_t)R, d_zo);
         (void)hipStreamSynchronize(s);
-        if (hipMemcpy(raw.data(), D.counters, n_ctr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        if (hipMemcpy(zo, d_zo, sizeof zo, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(f2.data(), D.f2, sk->f2size * 8, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(&sum_count, D.misc, 8, hipMemcpyDeviceToHost) != hipSuccess) { err = "device copy failed"; return false; }
         bqc_sketch_counts c{};
         c.q = sk->pp[p].q; c.k = sk->pp[p].k; c.sumCount = sum_count;
         // per level: number of counters > 0, == 0, == 1 (value = min(15, raw))
         std::vector<size_t> nz(32, 0), r0(32, 0), r1(32, 0);
-        for (size_t w = 0; w < 32; ++w) {
-            const uint32_t* t = raw.data() + w * R;
-            size_t a = 0, b1 = 0;
-            for (size_t j = 0; j < R; ++j) { a += t[j] == 0; b1 += t[j] == 1; }
-            r0[w] = a; r1[w] = b1; nz[w] = R - a;
-        }
+        for (size_t w = 0; w < 32; ++w) { r0[w] = (size_t)zo[2 * w]; r1[w] = (size_t)zo[2 * w + 1]; nz[w] = R - r0[w]; }
         { // F0, StreamCounter.hpp:114-140
             double sum = 0; int n = 0; double limit = 0.2;
             while (n == 0 && limit > 1e-8) {

@@ -281,6 +281,7 @@ def e2e_leg(args, refs, cpu_kernel_value):
             assert r.returncode == 0, r.stderr[-2000:]
             m = re.search(r"record loop ([0-9.]+) s", r.stderr)
             runs.append({"args": extra, "wall_s": dt, "reads_per_s": args.reads / dt, "record_loop_s": float(m.group(1)) if m else None,
+                         "reader": "gpu (inflate, CRC, record walk and column decode on the card)" if "records decoded on the GPU" in r.stderr else "host",
                          "timing": [ln for ln in r.stderr.splitlines() if ln.startswith("[timing]")]})
         lanes = bamqc_text.parse(os.path.join(tmp, "o1.bamqc"))
         bamqc_text.check_invariants(lanes["L1"], n_records=args.reads, read_len=args.read_len)
