@@ -292,7 +292,9 @@ extern "C" int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out)
     *out = b;
     if (!b->bam.open(path, b->err)) return BQC_ERR_IO; // the header, on the host
     b->gpu.reset(new GpuBamReader());
-    if (!b->gpu->open(path, device, b->bam.header(), b->bam.stream_pos(), 1u << 20, 256u << 20, b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
+    const uint64_t first_record = b->bam.stream_pos();
+    b->bam.close(); // (the host reader's read-ahead stops here)
+    if (!b->gpu->open(path, device, b->bam.header(), first_record, 1u << 20, 256u << 20, b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
     b->refresh_lanes();
     return 0;
 }

@@ -92,3 +92,31 @@ def test_gpu_reader_hands_over_what_the_host_reader_decides(tmp_path):
     b.close()
     host, _ = all_columns(path, 100_000)
     assert len(host["flag"]) == 3000
+
+
+def test_damaged_blocks_are_an_error_for_both_readers(tmp_path):
+    """A flipped byte in the compressed data (inflate fails, or inflates to other bytes: the CRC-32 kernel) and one in a block's
+    CRC field, far enough into the file that the header is read without meeting them: an I/O error from the reader on the card
+    as from the host reader, never the end of the file."""
+    path = str(tmp_path / "x.bam")
+    hostio.synth_stream(path, None, seed=5, n_reads=700_000, ref_names=["chr1"], ref_lens=[2_000_000])
+    data = bytearray(open(path, "rb").read())
+    assert len(data) > 50_000_000
+    where = len(data) * 9 // 10
+    for kind in ("data", "crc"):
+        bad = bytearray(data)
+        p = 0
+        while True:  # the block that holds `where`
+            bsize = (bad[p + 16] | (bad[p + 17] << 8)) + 1
+            if p + bsize > where:
+                break
+            p += bsize
+        bad[p + (bsize // 2 if kind == "data" else bsize - 8)] ^= 0x10
+        f = str(tmp_path / (kind + ".bam"))
+        open(f, "wb").write(bad)
+        for gpu in (None, 0):
+            with pytest.raises(IOError) as e:
+                b = hostio.BamFile(f, gpu=gpu)
+                n = sum(len(x["flag"]) for x in b.batches(100_000))
+                raise AssertionError("read %d records to the end of a damaged file" % n)
+            assert "1000" not in str(e.value)  # an error, not a hand-over
