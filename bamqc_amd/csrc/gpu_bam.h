@@ -21,6 +21,9 @@ public:
     // hdr / first_record_u: the header as the host reader parsed it, and the offset of the first record in the uncompressed stream
     // batch_reads / batch_bases: the limits next_batch will be called with (buffers are allocated once, for full batches)
     bool open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err);
+    // The file is read and copied to the card from open() on; the first inflate kernel waits for this call: a caller that still has
+    // device set-up of its own to do (allocations, synchronous copies wait for a running kernel) makes it when that is done.
+    void allow_kernels();
     BamHeader& header() override { return hdr_; }
     void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;

@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
@@ -401,6 +402,7 @@ struct GpuBamReader::Impl {
     int chunk_i = 0;
     raw_vector<uint8_t> first_raw; // the first run: read while the device is still starting
     bool dev_ready = false;        // (under m) streams and buffers exist: the producer may touch the device
+    bool kernels_ok = false;       // (under m) GpuBamReader::allow_kernels(): the first inflate kernel may be launched
     void produce();
     void fill_run(GbRun& R);
     size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal);
@@ -410,6 +412,12 @@ struct GpuBamReader::Impl {
 };
 
 GpuBamReader::GpuBamReader() {}
+void GpuBamReader::allow_kernels()
+{
+    if (!p_) return;
+    { std::lock_guard<std::mutex> lk(p_->m); p_->kernels_ok = true; }
+    p_->cv.notify_all();
+}
 GpuBamReader::~GpuBamReader() { delete p_; }
 
 bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err)
@@ -434,11 +442,21 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
     // Everything the reader will need, now: an allocation (or a release) behind a running inflate kernel waits for that kernel.
     {
-        // (a run inflates to ~3.3 x its size with BGZF level 1-6 on BAM records; a run that needs more grows its buffer, once)
-        const size_t out_cap = I.head + I.run_bytes / 5 * 18 + 64, nb_cap = I.run_bytes / 2048, seg_cap = out_cap / GB_SEG + 2;
+        // (a run inflates to ~3.3 x its size with BGZF level 1-6 on BAM records; a run that needs more grows its buffer, once.)  Sized
+        // for what this file can need: a 20 GB set-up is 20 GB to hand back when the process ends.
+        {
+            struct stat st;
+            if (fstat(fileno(I.f), &st) == 0 && st.st_size > 0) I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)st.st_size + (1u << 20));
+        }
+        const size_t reads0 = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
+        const size_t out_cap = I.head + I.run_bytes / 5 * 18 + 64, nb_cap = I.run_bytes / 2048;
+        const size_t seg_cap = std::min<size_t>(out_cap, std::min<size_t>(reads0 * 440, batch_bases * 2) + (8u << 20)) / GB_SEG + 2; // (a walk covers a batch's worth of the window)
         bool ok = true;
         const double t_a = now_s();
-        for (GbRun& R : I.runs) ok = ok && R.d_comp.need(I.run_bytes + I.chunk_bytes + (1u << 17) + 64, true) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap, true);
+        for (int k = 0; k < 2; ++k) { // (the third run buffer is allocated when a third run comes)
+            GbRun& R = I.runs[k];
+            ok = ok && R.d_comp.need(I.run_bytes + I.chunk_bytes + (1u << 17) + 64, true) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap, true);
+        }
         const double t_b = now_s();
         ok = ok && I.d_seg.need(seg_cap) && I.h_seg.need(seg_cap) && I.d_rec.need(seg_cap * GB_MAXR, true) && I.d_base.need(seg_cap) && I.h_base.need(seg_cap);
         const size_t reads = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
@@ -595,6 +613,8 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         d_off = p;
     } else {
         if (!wait_ready()) { R.rc = -2; return; }
+        // (no-ops for the two buffers open() has allocated; the third one is allocated here, whole: the chunks are copied in as they are read)
+        if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(head + run_bytes / 5 * 18 + 64, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
         while (he == hipSuccess && d_off < run_bytes && utotal + 65536 <= kMaxRunOut && !(file_eof && tail.empty())) {
             PinChunk& C = chunks[chunk_i++ % kChunks];
@@ -630,6 +650,11 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     R.utotal = utotal;
     if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1))) { R.rc = -2; return; }
     if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.hb.data(), nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s); // (pageable, small: staged at once)
+    if (produced == 0) { // the caller says when the card may get busy: its own set-up (context, tables) behind a running 50 ms kernel was measured to take 0.2-0.65 s instead of 0.1
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || kernels_ok; });
+        if (stop) { R.rc = -2; return; }
+    }
     if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_crc.p, R.hc.data(), nb * 4, hipMemcpyHostToDevice, R.s);
     if (he != hipSuccess) { R.rc = -2; return; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -721,7 +746,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         }
         const uint8_t* base = I.win + I.cur;
         const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
-        const size_t seg_cap = std::max<size_t>(nseg, (I.head + I.run_bytes / 5 * 18 + 64) / GB_SEG + 2); // (for a full run's window at once: see open)
+        const size_t seg_cap = nseg; // (sized in open() for a batch's worth of the window: grows only for unusual records)
         if (!I.d_seg.need(seg_cap) || !I.h_seg.need(seg_cap) || !I.d_rec.need(seg_cap * GB_MAXR) || !I.d_base.need(seg_cap) || !I.h_base.need(seg_cap)) return fail_dev("out of device memory");
         hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
         if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");

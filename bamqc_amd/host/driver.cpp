@@ -295,6 +295,7 @@ extern "C" int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out)
     const uint64_t first_record = b->bam.stream_pos();
     b->bam.close(); // (the host reader's read-ahead stops here)
     if (!b->gpu->open(path, device, b->bam.header(), first_record, 1u << 20, 256u << 20, b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
+    b->gpu->allow_kernels();
     b->refresh_lanes();
     return 0;
 }
@@ -890,6 +891,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         for (size_t i = 0; i < fa.size(); ++i) if (fa[i].name == H.ref_names[r]) { fasta_index[r] = (int32_t)i; break; }
     const auto t_fasta = clk::now();
     creator.join();
+    if (use_gpu_reader) { while (!gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200)); gpu_rd.allow_kernels(); } // (the context exists: the card may get busy)
     const auto t_create = clk::now();
     if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return shard_abort(); }
     if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
