@@ -68,8 +68,13 @@ def main():
                 hist_cap=16_384 if long_reads else 4096, device=local)
     if args.sketch:
         opts.update(klist=(32,), qlist=(17,))
-    t0 = time.time()
     refs = [synth.reference(seed, i, n) for i, n in enumerate(lens)]
+    e2e = None
+    if world == 1 and rank == 0 and not args.no_e2e and not long_reads:
+        # first, while this process has not touched the GPU: the program's start-up (HIP initialisation, context creation) was
+        # measured to take 0.25-0.7 s instead of 0.1 s next to another process that holds a context on the card or is handing one back
+        e2e = e2e_leg(args, refs, None)
+    t0 = time.time()
     cols = synth.batch(seed, args.reads, lens, refs, read_len=args.read_len, first_read_index=rank * args.reads, isize=opts["isize"], long_reads=long_reads)
     t_gen = time.time() - t0
     agg = Aggregator(**opts)
@@ -161,8 +166,10 @@ def main():
         del cols
         if world == 1 and not args.no_extra and not long_reads and not args.sketch:
             out["extra"] = extra_timings(refs)
-        if world == 1 and not args.no_e2e and not long_reads:
-            out["e2e"] = e2e_leg(args, refs, out.get("cpu_baseline", {}).get("value"))
+        if e2e is not None:
+            cv = out.get("cpu_baseline", {}).get("value")
+            e2e["speedup_vs_cpu_port"] = (e2e["reads_per_s"] / cv) if cv else None
+            out["e2e"] = e2e
         print(json.dumps(out), flush=True)
     else:
         db.free()
@@ -272,8 +279,9 @@ def e2e_leg(args, refs, cpu_kernel_value):
         hostio.synth_stream(bam, fa, 1002, args.reads, names, lens, read_len=args.read_len, level=1)
         t_write = time.time() - t0
         runs = []
-        for extra in ([], [], ["--no-sketch"]):
+        for extra in ([], [], [], ["--no-sketch"]):
             out = os.path.join(tmp, "o%d.bamqc" % len(runs))
+            time.sleep(1.0)  # (the worker process of the run before hands its memory and its context back after its front end has left)
             t0 = time.perf_counter()
             r = subprocess.run([exe, "-r", fa, "-o", out, "-c", ",".join(names)] + extra + [bam], capture_output=True, text=True,
                                env=dict(os.environ, BQC_TIMING="1", BQC_T0="%.6f" % time.monotonic()))
@@ -283,6 +291,7 @@ def e2e_leg(args, refs, cpu_kernel_value):
             runs.append({"args": extra, "wall_s": dt, "reads_per_s": args.reads / dt, "record_loop_s": float(m.group(1)) if m else None,
                          "reader": "gpu (inflate, CRC, record walk and column decode on the card)" if "records decoded on the GPU" in r.stderr else "host",
                          "timing": [ln for ln in r.stderr.splitlines() if ln.startswith("[timing]")]})
+        assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "o%d.bamqc" % k), shallow=False) for k in (1, 2))
         lanes = bamqc_text.parse(os.path.join(tmp, "o1.bamqc"))
         bamqc_text.check_invariants(lanes["L1"], n_records=args.reads, read_len=args.read_len)
         # prefix of the same plan: program vs oracle, byte for byte; the oracle run is also the CPU end-to-end baseline
@@ -295,7 +304,7 @@ def e2e_leg(args, refs, cpu_kernel_value):
         t0 = time.perf_counter()
         assert oracle_bamqualcheck(pbam, pfa, want, chroms=",".join(names)) == 0
         t_cpu = time.perf_counter() - t0
-        best = max(runs[:2], key=lambda x: x["reads_per_s"])
+        best = max(runs[:3], key=lambda x: x["reads_per_s"])
         return {"what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process"
                         % (os.path.getsize(bam) / 1e6),
                 "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "host_cpus": cpu_limit(),
