@@ -8,9 +8,16 @@
 // in parallel (host/bam_io.cpp: parallel_prewalk): the window is cut into 16 KiB segments, a lane per segment GUESSES the first
 // record start in its segment (the first offset at which three records in a row look like records) and walks from there to the
 // segment's end; the host then checks, segment by segment, that every guess is exactly where the previous segment's walk
-// arrived — by induction from the known first record the chain is then the serial walk's.  A guess that is not (or a record
-// the host reader would report: corrupt, a read group that is not in the header, a second NM tag, ...) makes next_batch return
-// kUnsupported: the caller starts over with the host reader, which is the one to decide what the user is told.
+// arrived — by induction from the known first record the chain is then the serial walk's; a segment whose guess is not there
+// is walked again, alone, from the known position.  A record the host reader has a rule for beyond the plain case (corrupt, a read
+// group that is not in the header, a second NM tag, ...) makes next_batch return kUnsupported: the caller starts over with the
+// host reader, which is the one to decide what the user is told.
+//
+// The file is taken in few, large RUNS of BGZF blocks (an inflate launch costs 20-50 ms whatever the number of blocks: gpu_inflate.hip):
+// a producer thread reads (the first run while the HIP runtime is still starting), copies and launches on one stream; next_batch
+// walks and decodes the current run's window on another; what a run leaves over (an unfinished record) is copied in front of the
+// next run's bytes.  Every buffer is allocated in open(): allocations, releases and page-locking behind a running inflate kernel
+// wait for it.
 //
 // Record layout, tag types: the public SAM/BAM specification; the rules applied to a record are those of the host reader
 // (bam_io.cpp: next_batch, citing bamqualcheck.cpp:72-100 getLane, QualityCheck.hpp:201-209 NM, TripletCounting.hpp:113-127 AS).
