@@ -89,9 +89,10 @@ void parse_read_groups(BamHeader& h)
     h.lane_count = (unsigned)h.lane_names.size();
 }
 
-bool BamReader::open(const char* path, std::string& err)
+bool BamReader::open(const char* path, std::string& err, bool header_first)
 {
     if (!bg_.open(path, err)) return false;
+    if (header_first) bg_.first_run_bytes(1u << 20);
     std::string e;
     if (!fill(12, e) || memcmp(buf_.data(), "BAM\1", 4) != 0) { err = e.empty() ? "not a BAM file" : e; return false; }
     const uint32_t l_text = rd32(buf_.data() + 4);

@@ -61,7 +61,9 @@ void parse_read_groups(BamHeader& h); // getSampleIdAndLaneNames, bamqualcheck.c
 
 class BamReader : public RecordReader {
 public:
-    bool open(const char* path, std::string& err);
+    // header_first: the first run of BGZF blocks is a small one (the caller may only want the header: the program when the records
+    // are to be decoded on the GPU)
+    bool open(const char* path, std::string& err, bool header_first = false);
     // One shard of the record stream (multi-GPU): the header is read from the file's start as always; records are then taken
     // from the first record that STARTS in a BGZF block at or behind bgzf_find_block(begin_hint) — located by the same test
     // the parallel record walk uses for its guesses — up to the last record that starts before the block at

@@ -227,6 +227,7 @@ bool BgzfReader::plan_run(raw_vector<uint8_t>& raw, Run& run, std::string& err, 
     // On the GPU a lane inflates a block: a run has to hold thousands of blocks to fill the card.
     if (on_card) want = std::max<size_t>(want, gpu_run_bytes_);
     if (mark_u_.load() != UINT64_MAX) want = 4 * kMaxBlock;                          // behind the mark: only the rest of a record is wanted
+    if (first_run_bytes_) { want = std::max<size_t>(first_run_bytes_, 4 * kMaxBlock); first_run_bytes_ = 0; }
     // the tail of the previous round (a partial block) goes to the front
     const size_t have = tail_.size();
     {

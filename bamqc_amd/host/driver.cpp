@@ -290,7 +290,7 @@ extern "C" int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out)
     if (!path || !out) return BQC_ERR_ARG;
     auto* b = new bqc_bam();
     *out = b;
-    if (!b->bam.open(path, b->err)) return BQC_ERR_IO; // the header, on the host
+    if (!b->bam.open(path, b->err, true)) return BQC_ERR_IO; // the header, on the host
     b->gpu.reset(new GpuBamReader());
     const uint64_t first_record = b->bam.stream_pos();
     b->bam.close(); // (the host reader's read-ahead stops here)
@@ -751,7 +751,13 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         const uint64_t size = bqc_file_size(opt.bamFile.c_str());
         const uint64_t lo = size / shard->count * shard->index, hi = shard->index + 1 == shard->count ? UINT64_MAX : size / shard->count * (shard->index + 1);
         opened = bam_rd.open_range(opt.bamFile.c_str(), lo, hi, err);
-    } else opened = bam_rd.open(opt.bamFile.c_str(), err);
+    } else {
+        // (a file the GPU reader will probably take: the host reader is only asked for the header — a small first run)
+        const char* gd = getenv("BQC_GPU_DECODE");
+        struct stat st;
+        const bool likely_gpu = !host_reader_only && !(gd && atoi(gd) == 0) && stat(opt.bamFile.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (gd || (uint64_t)st.st_size >= (256ull << 20));
+        opened = bam_rd.open(opt.bamFile.c_str(), err, likely_gpu);
+    }
     if (!opened) {
         fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
         return shard_abort();
