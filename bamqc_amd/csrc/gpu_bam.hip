@@ -476,7 +476,9 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (I.timing) fprintf(stderr, "[gpu reader] open: run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
     }
 
+    const double t_s0 = now_s();
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
+    const double t_s1 = now_s();
     if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
     if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
@@ -490,6 +492,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipEventCreateWithFlags(&R.copied, hipEventBlockingSync | hipEventDisableTiming);
         if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
     }
+    const double t_s2 = now_s();
     for (Impl::PinChunk& C : I.chunks) {
         if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, I.chunk_bytes + (1u << 17), hipHostMallocDefault);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
@@ -513,7 +516,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
     I.cv.notify_all();
-    if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3);
+    if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms: first stream %.1f, second stream + events + status words %.1f, page-locked chunks + tables %.1f)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3, (t_s1 - t_s0) * 1e3, (t_s2 - t_s1) * 1e3, (now_s() - t_s2) * 1e3);
     return true;
 }
 

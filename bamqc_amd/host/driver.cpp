@@ -877,16 +877,19 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     bqc_ctx* ctx = nullptr;
     int rc = 0;
     std::string create_err;
-    double t_create_s = 0;
+    double t_create_s = 0, t_c_warm = 0, t_c_reader = 0, t_c_create = 0;
     std::thread creator([&] {
         const auto c0 = clk::now();
         if (warm.joinable()) warm.join();
+        const auto c1 = clk::now();
         // the GPU reader sets itself up first (buffers, streams, page-locked chunks: ~50 ms): side by side the two were measured to hold
         // each other up at the runtime's locks — context creation 0.4-0.65 s instead of 0.1 in one run out of three
         while (use_gpu_reader && !gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        const auto c2 = clk::now();
         rc = bqc_create(&bo, &ctx);
         if (rc) create_err = bqc_last_error(nullptr);
         t_create_s = secs(c0, clk::now());
+        t_c_warm = secs(c0, c1); t_c_reader = secs(c1, c2); t_c_create = secs(c2, clk::now());
     });
     // reference genome: all contigs that are BAM references, FASTA order kept for the cursor rule
     std::vector<FastaRecord> fa;
@@ -1032,10 +1035,12 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         g_pins.release_all();
     };
     if (!done_fd) teardown();
-    if (timing)
+    if (timing) {
+        fprintf(stderr, "[timing] start-up: waiting for the HIP runtime %.3f s, then for the GPU reader's set-up %.3f s, bqc_create %.3f s\n", t_c_warm, t_c_reader, t_c_create);
         fprintf(stderr, "[timing] phases: FASTA %.2f s (context created meanwhile in %.2f s), context %.2f s, references %.2f s, record loop %.2f s, finalize %.2f s, write %.2f s, destroy %.2f s%s\n",
                 secs(t_begin, t_fasta), t_create_s, secs(t_fasta, t_create), secs(t_create, t_setup), secs(t_setup, t_loop_end), secs(t_loop_end, t_final), secs(t_final, t_write),
                 secs(t_write, clk::now()), done_fd ? " (the context is released after the run has been reported complete)" : "");
+    }
     if (rc) { fprintf(stderr, "ERROR: Could not write output file %s\n", opt.outputFile.c_str()); return 1; }
     since_launch("done");
     if (fast_exit) { // the program proper leaves without the static destructors of the HIP runtime: the output file is complete and closed
