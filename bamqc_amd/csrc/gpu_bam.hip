@@ -599,7 +599,8 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     hipError_t he = hipSuccess;
     if (produced == 0) {
         // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
-        const size_t piece = 32u << 20, cap = std::min<size_t>(run_bytes, 640u << 20);
+        static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)640 << 20;
+        const size_t piece = 32u << 20, cap = std::min<size_t>(run_bytes, first_cap);
         first_raw.resize(cap + 64);
         size_t got = 0;
         for (;;) {

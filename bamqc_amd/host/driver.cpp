@@ -802,6 +802,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         }
     }
     rd.set_main_chrom(main_chrom);
+    since_launch("input opened, header read");
     const auto t_begin = std::chrono::steady_clock::now(); // (BQC_TIMING=1 also reports the phases around the record loop)
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     double t_wait = 0, t_submit = 0, t_decode = 0;
@@ -912,6 +913,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     fa.clear();
     fa.shrink_to_fit();
     const auto t_setup = clk::now();
+    since_launch("record loop starts");
 
     int status = 0;
     uint64_t n_noqual_deferred = 0;
@@ -1017,6 +1019,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (status) { bqc_destroy(ctx); return 1; }
     const bqc_counts* counts = nullptr;
     const auto t_loop_end = clk::now();
+    since_launch("record loop and its checks over");
     if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
     const auto t_final = clk::now();
     bqc_header_info hi;
