@@ -80,7 +80,7 @@ void BgzfReader::read_ahead(int worker)
         }
         { // not too far ahead of the consumer (memory: every run in flight is ~100-200 MB)
             std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return stop_ || ra_done_ || planned_ - popped_ < (ra_.size() > 1 ? kMaxAhead : 4u); });
+            cv_.wait(lk, [&] { return stop_ || ra_done_ || (planned_ - popped_ < (ra_.size() > 1 ? kMaxAhead : 4u) && !(lazy_ && planned_ >= 1)); });
             if (stop_ || ra_done_) return;
         }
         Run run;
@@ -130,6 +130,7 @@ bool BgzfReader::next_chunk(raw_vector<uint8_t>& out, std::string& err)
 {
     if (!ra_started_) { ra_started_ = true; ra_.reserve(32); ra_.emplace_back([this] { read_ahead(0); }); }
     std::unique_lock<std::mutex> lk(m_);
+    if (lazy_ && q_.empty() && !ra_done_ && planned_ >= 1) { lazy_ = false; cv_.notify_all(); } // (somebody does want more than the first run)
     cv_.wait(lk, [&] { return !q_.empty() || ra_done_; });
     if (q_.empty()) { out.clear(); return false; } // (the failing / final item was already consumed)
     Item it = std::move(q_.front());

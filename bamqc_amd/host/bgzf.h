@@ -31,7 +31,9 @@ public:
     bool next_chunk(raw_vector<uint8_t>& out, std::string& err);
     uint64_t compressed_bytes_read() const { return cbytes_; }
     void gpu_run_bytes(size_t n) { gpu_run_bytes_ = n; } // compressed bytes per run when the GPU inflates
-    void first_run_bytes(size_t n) { first_run_bytes_ = n; } // (before the first next_chunk) a small first run: for a caller that wants the file's first bytes soon
+    // (before the first next_chunk) a small first run, and nothing is read ahead behind it until somebody asks for more: for a
+    // caller that may only want the file's first bytes (the header)
+    void first_run_bytes(size_t n) { first_run_bytes_ = n; lazy_ = true; }
     unsigned threads() const { return threads_; }
 
 private:
@@ -68,6 +70,7 @@ private:
     std::atomic<bool> gpu_failed_{false};    // the card could not be used: the CPU decoder has taken over for good
     size_t gpu_run_bytes_ = 64u << 20;
     size_t first_run_bytes_ = 0;
+    bool lazy_ = false;                      // (under m_) see first_run_bytes
 };
 
 // device >= 0: readers inflate their runs on that GPU from their next run on (csrc/gpu_inflate.hip; the CRC-32 of every block is

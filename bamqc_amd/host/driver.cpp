@@ -758,6 +758,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         const bool likely_gpu = !host_reader_only && !(gd && atoi(gd) == 0) && stat(opt.bamFile.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (gd || (uint64_t)st.st_size >= (256ull << 20));
         opened = bam_rd.open(opt.bamFile.c_str(), err, likely_gpu);
     }
+    since_launch("input opened");
     if (!opened) {
         fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); // bamqualcheck.cpp:265
         return shard_abort();
