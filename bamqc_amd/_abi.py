@@ -98,7 +98,7 @@ class ShardResult(C.Structure):
 
 
 SHARD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ShardInfo), C.POINTER(ShardResult))
-SHARD_WRITE, SHARD_DONE, SHARD_FALLBACK, SHARD_FAIL = 0, 1, 2, 3
+SHARD_FAIL, SHARD_DONE, SHARD_FALLBACK, SHARD_WRITE = 0, 1, 2, 3  # (0 is what ctypes returns for a callback that raised)
 
 
 class HeaderInfo(C.Structure):

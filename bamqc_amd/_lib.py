@@ -58,6 +58,7 @@ _SIGNATURES = {
     "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bqc_bam_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "bqc_bam_open_gpu": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bqc_bam_open_gpu_range": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "bqc_bam_range_begin_block": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_end_block": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_first": (C.c_uint64, [C.c_void_p]),
@@ -83,6 +84,7 @@ _SIGNATURES = {
     "bqc_fasta_free": (None, [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_abi.u8p), _abi.u64p]),
     "bqc_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "bqc_main_shard": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, _abi.SHARD_HOOK, C.c_void_p]),
+    "bqc_main_multi": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     "bqc_calib_read4": (C.c_int, [C.c_uint64, C.c_int]),
     "bqc_inflate_raw": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "bqc_crc32": (C.c_uint32, [C.c_char_p, C.c_uint64]),

@@ -648,7 +648,20 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
     return 0;
 }
 
-extern "C" int bqc_submit(bqc_ctx* c, const bqc_batch* b) { return submit_impl(c, b, false, nullptr); }
+// (the staged path copies the columns with the host's memcpy: device-resident payload columns are bqc_submit_async's)
+static bool lives_on_device(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; } // (ordinary host memory is unknown to the runtime)
+    return a.type == hipMemoryTypeDevice;
+}
+extern "C" int bqc_submit(bqc_ctx* c, const bqc_batch* b)
+{
+    if (c && b && b->n_reads && (lives_on_device(b->seq) || lives_on_device(b->qual) || lives_on_device(b->cigar)))
+        return bqc_fail(c, BQC_ERR_ARG, "bqc_submit: payload columns in device memory need bqc_submit_async");
+    return submit_impl(c, b, false, nullptr);
+}
 extern "C" int bqc_submit_async(bqc_ctx* c, const bqc_batch* b, uint64_t* ticket) { return submit_impl(c, b, true, ticket); }
 
 extern "C" int bqc_batch_uploaded(bqc_ctx* c, uint64_t ticket, int wait)

@@ -21,6 +21,15 @@ public:
     // hdr / first_record_u: the header as the host reader parsed it, and the offset of the first record in the uncompressed stream
     // batch_reads / batch_bases: the limits next_batch will be called with (buffers are allocated once, for full batches)
     bool open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err);
+    // One shard of the record stream (multi-GPU; same meaning as BamReader::open_range, host/bam_io.h): call before open().  Only the
+    // bytes of the compressed file from `begin_block` on are read (a BGZF block boundary: bgzf_find_block), and the records taken
+    // are those that START before the block at `end_block` (UINT64_MAX: to the end of the file); the last one runs on into the
+    // successor's blocks.  begin_block 0: from the first record (first_record_u of open()); otherwise the first record is located
+    // by the walk's own guess (three records in a row that look like records) — neighbouring shards verify it afterwards:
+    // range_over() of a shard must equal range_first() of its successor.
+    void set_range(uint64_t begin_block, uint64_t end_block) { range_b0_ = begin_block; range_b1_ = end_block; ranged_ = true; }
+    uint64_t range_first() const { return range_first_; } // uncompressed offset of the shard's first record, relative to its begin block (valid after the first batch)
+    uint64_t range_over() const { return range_over_; }   // where the record after the shard's last one starts, relative to the end block (valid after the last batch)
     // The file is read and copied to the card from open() on; the first inflate kernel waits for this call: a caller that still has
     // device set-up of its own to do (allocations, synchronous copies wait for a running kernel) makes it when that is done.
     void allow_kernels();
@@ -40,4 +49,6 @@ private:
     std::vector<uint8_t> main_;
     uint64_t nrec_ = 0;
     double t_read_ = 0;
+    bool ranged_ = false;
+    uint64_t range_b0_ = 0, range_b1_ = UINT64_MAX, range_first_ = 0, range_over_ = 0;
 };

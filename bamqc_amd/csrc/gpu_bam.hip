@@ -83,26 +83,30 @@ __device__ bool gb_plausible(const uint8_t* base, uint64_t avail, uint64_t p, in
 
 // lane per segment: first record start (segment 0: the window's start, which is one), then the chain up to the segment's end
 // (seg0, exact: the segments from seg0 on, the first of them from the known record start `exact` — the whole window is
-// (0, 0); a segment whose guess turned out wrong is walked again alone from where the chain arrives)
-__global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base, uint64_t avail, uint32_t seg0, uint32_t nseg, uint64_t exact, int32_t n_ref,
+// (0, 0); a segment whose guess turned out wrong is walked again alone from where the chain arrives; exact == UINT64_MAX:
+// a shard that starts in the middle of the file does not know its first record: segment seg0 guesses like the others).
+// `limit`: a shard's end — no record that starts at or behind it is listed (S.exit is then where that record starts).
+__global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base, uint64_t avail, uint32_t seg0, uint32_t nseg, uint64_t exact, uint64_t limit, int32_t n_ref,
                                                  GbSeg* __restrict__ segs, GbRec* __restrict__ recs)
 {
     const uint32_t s = seg0 + blockIdx.x * 64 + threadIdx.x;
     if (s >= seg0 + nseg) return;
     const uint64_t a = (uint64_t)s * GB_SEG, b = min(avail, a + GB_SEG);
     GbSeg S{};
-    uint64_t p = s == seg0 ? exact : a;
-    if (s != seg0) {
-        for (; p < b; ++p) {
+    const bool known = s == seg0 && exact != UINT64_MAX;
+    uint64_t p = known ? exact : a;
+    if (!known) {
+        const uint64_t stop = min(b, limit);
+        for (; p < stop; ++p) {
             uint64_t q1, q2, q3;
             if (gb_plausible(base, avail, p, n_ref, q1) && gb_plausible(base, avail, q1, n_ref, q2) && gb_plausible(base, avail, q2, n_ref, q3)) break;
         }
-        if (p >= b) { S.first = S.exit = 0xFFFFFFFFu; S.flags = GB_NO_START; segs[s] = S; return; }
+        if (p >= stop) { S.first = S.exit = 0xFFFFFFFFu; S.flags = GB_NO_START; segs[s] = S; return; }
     }
     S.first = (uint32_t)p;
     GbRec* out = recs + (size_t)s * GB_MAXR;
     uint32_t so = 0, qo = 0, co = 0, n = 0;
-    while (p < b) {
+    while (p < b && p < limit) {
         if (p + 36 > avail) { S.flags |= GB_INCOMPLETE; break; }
         const uint32_t bs = ld32(base + p);
         if (bs < 32u) { S.flags |= GB_CORRUPT; break; }
@@ -335,6 +339,7 @@ struct GbRun {
     DevBuf<uint8_t> d_out;
     uint32_t* d_status = nullptr;
     size_t utotal = 0;
+    uint64_t abs0 = 0;   // where this run's first inflated byte lies in the reader's uncompressed stream (which starts at its begin block)
     int state = 0;       // 0 free, 1 being filled, 2 ready (under Impl::m)
     bool final = false;  // nothing follows (this one may be empty)
     int rc = 1;          // 1 ok, -1 malformed (err), -2 device
@@ -348,6 +353,18 @@ struct GpuBamReader::Impl {
     hipEvent_t ev = nullptr;    // blocking
     FILE* f = nullptr;
     uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
+    // a shard of the file (GpuBamReader::set_range): the producer reads from begin_off on and notes where the block at mark_off
+    // lies in the uncompressed stream; behind it only small runs follow (the consumer wants the rest of one record)
+    uint64_t begin_off = 0, mark_off = UINT64_MAX;
+    uint64_t read_off = 0;      // (producer) file offset of the next byte to read
+    uint64_t parsed_off = 0;    // (producer) file offset of the next block header to parse
+    uint64_t u_produced = 0;    // (producer) uncompressed bytes of the runs before the current one
+    std::atomic<uint64_t> mark_abs{UINT64_MAX}; // the mark in the uncompressed stream, once the producer has got there
+    static constexpr uint64_t kBeyond = 2u << 20; // compressed bytes a run takes behind the mark
+    bool need_locate = false, range_done = false; // (consumer)
+    uint64_t win_abs0 = 0;      // (consumer) position of win[head] in the uncompressed stream
+    uint64_t abs_of(size_t x) const { return win_abs0 + x - head; } // (x < head: what the run before left over)
+    uint64_t stop_off() const { return mark_off == UINT64_MAX ? UINT64_MAX : (parsed_off < mark_off ? mark_off : parsed_off) + kBeyond; }
     size_t run_bytes = 832u << 20; // (an inflate launch costs 20-50 ms whatever the number of blocks: few, large runs; the first one is 64 MB)
     size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
     static const int kRuns = 3; // one being walked, one being inflated, one being read
@@ -412,7 +429,7 @@ struct GpuBamReader::Impl {
     bool kernels_ok = false;       // (under m) GpuBamReader::allow_kernels(): the first inflate kernel may be launched
     void produce();
     void fill_run(GbRun& R);
-    size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal);
+    size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, bool& stopped);
     bool wait_ready();
     // the next run becomes the window (what is left of the current one goes in front of it); 1: done, 0: no more runs, -1 / -2: see GbRun::rc
     int advance(std::string& err);
@@ -430,7 +447,7 @@ GpuBamReader::~GpuBamReader() { delete p_; }
 bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint64_t first_record_u, size_t batch_reads, size_t batch_bases, std::string& err)
 {
     const double t_open0 = now_s();
-    hdr_ = hdr;
+    if (&hdr != &hdr_) hdr_ = hdr; // (a caller that has filled header() itself passes it: nothing is written while others read it)
     delete p_;
     p_ = new Impl();
     Impl& I = *p_;
@@ -441,6 +458,13 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.f = fopen(path, "rb");
     if (!I.f) { err = std::string("could not open ") + path; return false; }
     setvbuf(I.f, nullptr, _IONBF, 0);
+    if (ranged_) {
+        I.begin_off = range_b0_; I.mark_off = range_b1_;
+        if (I.begin_off && fseeko(I.f, (off_t)I.begin_off, SEEK_SET) != 0) { err = std::string("could not seek in ") + path; return false; }
+        I.need_locate = I.begin_off != 0;
+        if (I.begin_off) first_record_u = 0; // (the header lies in the first shard)
+    }
+    I.read_off = I.parsed_off = I.begin_off;
     I.skip_u = first_record_u;
     I.n_ref = (int32_t)hdr.ref_names.size();
     I.producer = std::thread([&I] { I.produce(); }); // reads the first run of the file while the device is set up below
@@ -453,7 +477,10 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         // for what this file can need: a 20 GB set-up is 20 GB to hand back when the process ends.
         {
             struct stat st;
-            if (fstat(fileno(I.f), &st) == 0 && st.st_size > 0) I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)st.st_size + (1u << 20));
+            if (fstat(fileno(I.f), &st) == 0 && st.st_size > 0) {
+                const uint64_t upto = std::min<uint64_t>((uint64_t)st.st_size, I.mark_off == UINT64_MAX ? UINT64_MAX : I.mark_off + Impl::kBeyond + (1u << 17));
+                I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)(upto > I.begin_off ? upto - I.begin_off : 0) + (1u << 20));
+            }
         }
         const size_t reads0 = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
         const size_t out_cap = I.head + I.run_bytes / 5 * 18 + 64, nb_cap = I.run_bytes / 2048;
@@ -546,11 +573,19 @@ void GpuBamReader::Impl::produce()
 // reads the next run of whole BGZF blocks and starts its inflation (block headers: host/bgzf.cpp plan_run — same checks)
 // whole BGZF blocks of raw[0, have): appended to the run's block table (their deflate data will lie at d_off + ... in the run's
 // compressed buffer); returns the bytes they span, SIZE_MAX on a malformed stream (host/bgzf.cpp plan_run — same checks)
-size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal)
+size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, bool& stopped)
 {
     const size_t kMaxBlock = 65536;
     size_t p = 0;
     while (p + 18 <= have) {
+        if (mark_off != UINT64_MAX) { // a shard: where its end block lies in the uncompressed stream; the run ends a little behind it
+            const uint64_t at = parsed_off + p;
+            if (mark_abs.load() == UINT64_MAX) {
+                if (at == mark_off) mark_abs = R.abs0 + utotal;
+                else if (at > mark_off) { R.err = "the split point of the file is not a BGZF block boundary"; return SIZE_MAX; }
+            }
+            if (at >= stop_at) { stopped = true; break; }
+        }
         const uint8_t* h = raw + p;
         if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { R.err = "not a BGZF stream (bad gzip member header)"; return SIZE_MAX; }
         const size_t xlen = h[10] | (h[11] << 8);
@@ -592,30 +627,41 @@ bool GpuBamReader::Impl::wait_ready()
 
 // Reads the next run of whole BGZF blocks and starts its inflation.  The first run is read before the device is up (into pageable
 // memory, copied staged); the others go through page-locked chunks, the read of one overlapping the copy of the one before.
+// A shard's run stops kBeyond bytes behind its end block, and nothing is read that no run will want.
 void GpuBamReader::Impl::fill_run(GbRun& R)
 {
     R.rc = 1; R.final = false; R.utotal = 0; R.err.clear();
+    R.abs0 = u_produced;
     size_t nb = 0, utotal = 0, d_off = 0;
     hipError_t he = hipSuccess;
+    const uint64_t stop_at = stop_off();
+    bool stopped = false;
+    // bytes of the file this run may still read: up to the last block that can start before `stop`
+    auto may_read = [&](size_t want) -> size_t {
+        if (stop_at == UINT64_MAX) return want;
+        const uint64_t upto = stop_at + (1u << 17);
+        return upto > read_off ? (size_t)std::min<uint64_t>(want, upto - read_off) : 0;
+    };
     if (produced == 0) {
         // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
         static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)640 << 20;
-        const size_t piece = 32u << 20, cap = std::min<size_t>(run_bytes, first_cap);
+        const size_t piece = 32u << 20, cap = may_read(std::min<size_t>(run_bytes, first_cap));
         first_raw.resize(cap + 64);
         size_t got = 0;
         for (;;) {
             const size_t want = std::min(piece, cap - got);
             const double t0 = now_s();
-            const size_t g = fread(first_raw.data() + got, 1, want, f);
+            const size_t g = want ? fread(first_raw.data() + got, 1, want, f) : 0;
             t_read += now_s() - t0;
-            got += g;
+            got += g; read_off += g;
             if (g < want) { file_eof = true; break; }
             if (got >= cap) break;
             if (got >= (64u << 20)) { std::lock_guard<std::mutex> lk(m); if (dev_ready || stop) break; }
         }
-        const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal);
+        const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal, stop_at, stopped);
         if (p == SIZE_MAX) { R.rc = -1; return; }
-        if (file_eof && p != got && got - p < 65536 + 64 && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        if (file_eof && !stopped && p != got && got - p < 65536 + 64 && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        parsed_off += p;
         tail.assign(first_raw.data() + p, first_raw.data() + got);
         if (!wait_ready()) { R.rc = -2; return; }
         if (!R.d_comp.need(p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; }
@@ -627,38 +673,42 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         // (no-ops for the two buffers open() has allocated; the third one is allocated here, whole: the chunks are copied in as they are read)
         if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(head + run_bytes / 5 * 18 + 64, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
-        while (he == hipSuccess && d_off < run_bytes && utotal + 65536 <= kMaxRunOut && !(file_eof && tail.empty())) {
+        while (he == hipSuccess && !stopped && d_off < run_bytes && utotal + 65536 <= kMaxRunOut && !(file_eof && tail.empty())) {
             PinChunk& C = chunks[chunk_i++ % kChunks];
             if (C.used && hipEventSynchronize(C.done) != hipSuccess) { R.rc = -2; return; }
             // the chunk: what the run before left over (a partial block; a lot only when that run stopped at its size limit), then the file
             const size_t carried = std::min(tail.size(), chunk_bytes + (1u << 16));
             if (carried) memcpy(C.p, tail.data(), carried);
             const bool tail_only = carried < tail.size() || carried > (1u << 16);
-            std::vector<uint8_t> rest(tail.begin() + carried, tail.end());
+            tail.erase(tail.begin(), tail.begin() + carried); // (what did not fit stays, in order, for the next chunk)
+            const bool more_tail = !tail.empty();
             size_t got = 0;
             if (!file_eof && !tail_only) {
+                const size_t want = may_read(chunk_bytes);
                 const double t0 = now_s();
-                got = fread(C.p + carried, 1, chunk_bytes, f);
+                got = want ? fread(C.p + carried, 1, want, f) : 0;
                 t_read += now_s() - t0;
-                if (got < chunk_bytes) file_eof = true;
+                read_off += got;
+                if (got < want) file_eof = true;
             }
             const size_t have = carried + got;
-            const size_t p = parse_blocks(R, C.p, have, d_off, nb, utotal);
+            const size_t p = parse_blocks(R, C.p, have, d_off, nb, utotal, stop_at, stopped);
             if (p == SIZE_MAX) { R.rc = -1; return; }
             const bool stopped_for_size = utotal + 65536 > kMaxRunOut;
-            if (file_eof && rest.empty() && p != have && !stopped_for_size) { R.err = "truncated BGZF file"; R.rc = -1; return; }
-            tail.assign(C.p + p, C.p + have);
-            tail.insert(tail.end(), rest.begin(), rest.end());
+            if (file_eof && tail.empty() && p != have && !stopped_for_size && !stopped) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+            parsed_off += p;
+            tail.insert(tail.begin(), C.p + p, C.p + have);
             if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
             if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, C.p, p, hipMemcpyHostToDevice, R.s);
             if (he == hipSuccess) he = hipEventRecord(C.done, R.s);
             C.used = true;
             d_off += p;
-            if (p == 0 && got == 0 && rest.empty()) break;
+            if (p == 0 && got == 0 && !more_tail) break; // (no progress is possible: nothing parsed, nothing read, nothing left over to add)
         }
     }
     R.final = file_eof && tail.empty();
     R.utotal = utotal;
+    u_produced += utotal;
     if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1))) { R.rc = -2; return; }
     if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.hb.data(), nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s); // (pageable, small: staged at once)
     if (produced == 0) { // the caller says when the card may get busy: its own set-up (context, tables) behind a running 50 ms kernel was measured to take 0.2-0.65 s instead of 0.1
@@ -705,6 +755,7 @@ int GpuBamReader::Impl::advance(std::string& err)
     GbRun* old = cur_run;
     cur_run = N;
     win = N->d_out.p;
+    win_abs0 = N->abs0;
     cur = head - left;
     end = head + N->utotal;
     if (N->final) stream_done = true; // (no run follows this one)
@@ -734,18 +785,36 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
     }
     const double t0 = now_s();
     double t_adv = 0, t_walk = 0, t_dec = 0;
+    if (I.range_done) return 0;
+    auto end_of_range = [&](uint64_t next_record_abs) { // the shard is over: where the successor's first record starts, relative to the end block
+        const uint64_t mk = I.mark_abs.load();
+        range_over_ = mk != UINT64_MAX && next_record_abs >= mk ? next_record_abs - mk : 0;
+        I.range_done = true;
+    };
     for (;;) {
         const double ta = now_s();
         if (I.cur == I.end || I.skip_u) { // nothing (left) in the window
             const bool was_done = I.stream_done;
             const int rc = I.advance(err);
-            if (rc == 0) return (I.skip_u && was_done) ? unsupported("the file ends inside its header") : 0;
+            if (rc == 0) {
+                if (I.skip_u && was_done) return unsupported("the file ends inside its header");
+                if (I.need_locate) { range_first_ = 0; I.need_locate = false; } // (a shard without a byte: nothing starts here)
+                end_of_range(I.abs_of(I.cur));
+                return 0;
+            }
             if (rc == -1) { err_code = BQC_ERR_IO; return -1; }
             if (rc == -2) return fail_dev("a failed copy or out of memory");
             if (rc == -3) return unsupported(err.c_str());
             t_adv += now_s() - ta;
             continue;
         }
+        // a shard ends where its end block begins in the uncompressed stream (known once the producer has got there)
+        uint64_t limit = UINT64_MAX;
+        {
+            const uint64_t mk = I.mark_abs.load(), here = I.abs_of(I.cur);
+            if (mk != UINT64_MAX) limit = mk > here ? mk - here : 0;
+        }
+        if (limit == 0 && !I.need_locate) { end_of_range(I.abs_of(I.cur)); return 0; }
         // the walk covers what a batch is expected to need (a window may hold many batches); a record cut off by that is where the batch ends
         uint64_t avail = I.end - I.cur;
         {
@@ -756,23 +825,48 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             if ((double)avail > want) avail = (uint64_t)want;
         }
         const uint8_t* base = I.win + I.cur;
-        const uint32_t nseg = (uint32_t)((avail + GB_SEG - 1) / GB_SEG);
+        // (segments that begin behind the shard's end hold nothing for it)
+        const uint32_t nseg = (uint32_t)((std::min<uint64_t>(avail, limit == UINT64_MAX ? avail : limit + 1) + GB_SEG - 1) / GB_SEG);
         const size_t seg_cap = nseg; // (sized in open() for a batch's worth of the window: grows only for unusual records)
         if (!I.d_seg.need(seg_cap) || !I.h_seg.need(seg_cap) || !I.d_rec.need(seg_cap * GB_MAXR) || !I.d_base.need(seg_cap) || !I.h_base.need(seg_cap)) return fail_dev("out of device memory");
-        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, (uint64_t)0, I.n_ref, I.d_seg.p, I.d_rec.p);
+        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, I.need_locate ? UINT64_MAX : (uint64_t)0, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
         if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
         // the chain, segment by segment; whole segments are taken while the batch has room
         uint64_t pos = 0, n = 0, bases = 0, so = 0, qo = 0, co = 0;
         uint32_t last_taken = 0;
+        bool over = false; // the chain has reached the shard's end
+        if (I.need_locate) { // a shard in the middle of the file: its first record is the first guess of the walk (verified by the predecessor shard afterwards)
+            uint32_t s0 = 0;
+            while (s0 < nseg && (I.h_seg.p[s0].flags & GB_NO_START)) ++s0;
+            if (s0 == nseg) {
+                if (avail < I.end - I.cur && (limit == UINT64_MAX || avail < limit)) { I.grow_window += 2 * avail + (64u << 20); continue; }
+                if (limit != UINT64_MAX && limit <= avail) { // no record starts in this shard: the predecessor's last one covers it
+                    return unsupported("no record starts in this part of the file");
+                }
+                if (I.stream_done) return unsupported("no record starts in this part of the file");
+                return unsupported("the first record of this part of the file was not found");
+            }
+            pos = I.h_seg.p[s0].first;
+            static const bool skew = getenv("BQC_TEST_SHARD_SKEW") != nullptr; // tests: a wrong guess (the second record found), to exercise the fallback
+            if (skew) {
+                uint32_t bs = 0;
+                if (hipMemcpy(&bs, base + pos, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail_dev("copy failed");
+                if (pos + 4 + (uint64_t)bs < avail && pos + 4 + (uint64_t)bs < limit) pos += 4 + (uint64_t)bs;
+            }
+            range_first_ = I.abs_of(I.cur + pos);
+            I.need_locate = false;
+            if (pos) { I.cur += pos; continue; } // (the window now starts at the record: walked again from there, as every other batch)
+        }
         for (uint32_t s = 0; s < nseg; ++s) {
             GbBase& B = I.h_base.p[s];
             B = GbBase{so, qo, co, (uint32_t)n, 0};
             const uint64_t seg_end = std::min<uint64_t>(avail, (uint64_t)(s + 1) * GB_SEG);
+            if (pos >= limit) { over = true; break; }
             if (pos >= seg_end) continue; // the previous record runs through this segment
             GbSeg& S = I.h_seg.p[s];
             if ((S.flags & GB_NO_START) || S.first != pos) { // the guess is not where the chain arrives (or there was none): this segment again, from there
                 ++I.n_rewalk;
-                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, I.n_ref, I.d_seg.p, I.d_rec.p);
+                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
                 if (hipMemcpyAsync(&S, I.d_seg.p + s, sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
                 if (S.first != pos) return unsupported("the record walk could not be verified");
             }
@@ -784,6 +878,8 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             pos = S.exit;
             if (S.flags & GB_INCOMPLETE) break;
         }
+        if (pos >= limit) over = true;
+        if (n == 0 && over) { I.cur += pos; end_of_range(I.abs_of(I.cur)); return 0; }
         if (n == 0 && avail < I.end - I.cur) { I.grow_window += 2 * avail + (64u << 20); continue; } // (a record longer than the walked part of the window)
         I.grow_window = 0;
         if (n == 0) { // not one complete record in the window: the next run's bytes behind it
@@ -848,6 +944,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         if (*I.h_status) return unsupported("a record the host reader handles (read group / tags)");
         o.d_seq = pay + o_seq; o.d_qual = pay + o_qual; o.d_cigar = (const uint32_t*)(pay + o_cig);
         I.cur += pos;
+        if (over) end_of_range(I.abs_of(I.cur));
         nrec_ += n;
         I.avg_rec_bytes = (double)pos / (double)n;
         I.avg_rec_bases = (double)bases / (double)n;

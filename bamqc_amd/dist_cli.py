@@ -20,7 +20,12 @@ def main(argv=None):
     from . import distributed as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force = os.environ.get("BQC_FORCE_SHARD_PATH") == "1"  # (one process through the sharded path: backend set-up + reduce on one card)
+    if force and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -33,8 +38,8 @@ def main(argv=None):
                 seed = [int(time.time()) or 1]
                 dist.broadcast_object_list(seed, src=0)
                 argv[k + 1] = str(seed[0])
-    rc = D.run_sharded(["bamqualcheck"] + argv, backend=backend if world > 1 else "none", device=local if backend == "nccl" else 0)
-    if world > 1:
+    rc = D.run_sharded(["bamqualcheck"] + argv, backend=backend if (world > 1 or force) else "none", device=local if backend == "nccl" else 0)
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
     return rc

@@ -13,31 +13,18 @@ check, FASTA order), one point-to-point hand-over of the coverage state per neig
 """
 import ctypes as C
 import os
-import time
+import sys
 
 import numpy as np
 
 from . import _abi, _lib
 
 
-def plan_shards(ref_lens, world_size):
-    """Longest-processing-time assignment of contigs to ranks (the chromosome-sharded mode of earlier versions; kept as a
-    planning helper). Returns owner[rid] (np.int32).  Deterministic: ties break on the lower contig id / lower rank."""
-    order = sorted(range(len(ref_lens)), key=lambda i: (-int(ref_lens[i]), i))
-    load = [0] * world_size
-    owner = np.zeros(len(ref_lens), np.int32)
-    for i in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
-        owner[i] = r
-        load[r] += int(ref_lens[i])
-    return owner
-
-
 def reduce_state(vec, dst=0):
     """Sum the flat state vector over ranks onto `dst`. `vec` is a torch int64 tensor (cuda for
     nccl, cpu for gloo) holding uint64 words; two's-complement addition wraps identically."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():  # (also with one process: the collective then runs on its own — a smoke test of the backend)
         dist.reduce(vec, dst=dst, op=dist.ReduceOp.SUM)
     return vec
 
@@ -102,12 +89,12 @@ def run_sharded(argv, backend=None, device=None):
         device = int(os.environ.get("LOCAL_RANK", "0"))
     argv = list(argv) + ["--device", str(device)]
     cargs = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
-    if world == 1:
+    if world == 1 and not (dist.is_initialized() and os.environ.get("BQC_FORCE_SHARD_PATH") == "1"):
         return int(lib.bqc_main(len(argv), cargs))
     tdev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
     keep = {}
 
-    def hook(_user, info_p, out_p):
+    def hook_body(info_p, out_p):
         info = info_p.contents
         ctx = info.ctx
         mine = dict(status=int(info.status), has_ctx=bool(ctx), b0=int(info.begin_block), b1=int(info.end_block), first=int(info.first),
@@ -160,21 +147,34 @@ def run_sharded(argv, backend=None, device=None):
             return _abi.SHARD_FAIL
         # ---- ONE reduce of the flat state vector onto process 0
         words = int(lib.bqc_state_words(ctx))
+
+        def all_ok(rc):  # every process learns whether every process's step worked, before the next collective or the output
+            bad = torch.tensor([1 if rc else 0], dtype=torch.int32, device=tdev)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            return not int(bad.item())
+
         if backend == "nccl":
-            vec = torch.empty(words, dtype=torch.int64, device=tdev)
+            vec = torch.zeros(words, dtype=torch.int64, device=tdev)
             rc = lib.bqc_state_export(ctx, C.c_void_p(vec.data_ptr()))
+            if not all_ok(rc):
+                if rc:
+                    print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+                return _abi.SHARD_FAIL
             reduce_state(vec)
-            if rank == 0 and not rc:
-                rc = lib.bqc_state_import(ctx, C.c_void_p(vec.data_ptr()))
+            rc = lib.bqc_state_import(ctx, C.c_void_p(vec.data_ptr())) if rank == 0 else 0
         else:  # gloo: host tensors
             host = np.zeros(words, np.uint64)
             rc = lib.bqc_state_export_host(ctx, host.ctypes.data_as(_abi.u64p))
+            if not all_ok(rc):
+                if rc:
+                    print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+                return _abi.SHARD_FAIL
             vec = torch.from_numpy(host.view(np.int64))
             reduce_state(vec)
-            if rank == 0 and not rc:
-                rc = lib.bqc_state_import_host(ctx, host.ctypes.data_as(_abi.u64p))
-        if rc:
-            print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
+            rc = lib.bqc_state_import_host(ctx, host.ctypes.data_as(_abi.u64p)) if rank == 0 else 0
+        if not all_ok(rc):
+            if rc:
+                print((lib.bqc_last_error(ctx) or b"").decode(), flush=True)
             return _abi.SHARD_FAIL
         if rank != 0:
             return _abi.SHARD_DONE
@@ -187,6 +187,17 @@ def run_sharded(argv, backend=None, device=None):
         out.lane_names = names
         out.lane_index = idx.ctypes.data_as(_abi.u32p)
         return _abi.SHARD_WRITE
+
+    def hook(_user, info_p, out_p):
+        # (a ctypes callback that raises returns 0 to its caller after printing the traceback: 0 is SHARD_FAIL, and the other
+        # processes are told so that none of them is left waiting or writes a sum that lacks this process's part)
+        try:
+            return hook_body(info_p, out_p)
+        except BaseException:  # noqa: BLE001 - whatever it was, this process's result is void
+            import traceback
+            traceback.print_exc()
+            sys.stdout.flush()
+            return _abi.SHARD_FAIL
 
     cb = _abi.SHARD_HOOK(hook)
     return int(lib.bqc_main_shard(len(argv), cargs, rank, world, cb, None))

@@ -300,9 +300,9 @@ bool BgzfReader::inflate_run(const raw_vector<uint8_t>& raw, const Run& run, raw
     if (gpu && *gpu && gpu_dev >= 0 && blocks.size() >= 64) {
         if (bounce.capacity() < run.utotal + 64) { bounce.clear(); bounce.reserve(run.utotal + run.utotal / 4 + (1u << 20)); advise_huge(bounce); }
         bounce.resize(run.utotal);
-        if (bqc_raw_vector_pin_hook) { // page-locked: the copies run at the link's speed and the waiting thread sleeps
-            bqc_raw_vector_pin_hook(raw.data(), raw.capacity());
-            bqc_raw_vector_pin_hook(bounce.data(), bounce.capacity());
+        if (auto pin = bqc_raw_vector_pin_hook.load(std::memory_order_acquire)) { // page-locked: the copies run at the link's speed and the waiting thread sleeps
+            pin(raw.data(), raw.capacity());
+            pin(bounce.data(), bounce.capacity());
         }
         std::vector<GiBlock> gb;
         gb.reserve(blocks.size());

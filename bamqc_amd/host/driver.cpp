@@ -5,6 +5,7 @@
 // include/bamqc_host.h around the BAM reader.
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -255,6 +256,7 @@ struct bqc_bam {
     bool is_sam = false;
     FILE* sam_file = nullptr;
     std::unique_ptr<GpuBamReader> gpu; // bqc_bam_open_gpu: records decoded on the card
+    uint64_t g_b0 = 0, g_b1 = UINT64_MAX; // bqc_bam_open_gpu_range: the shard's block boundaries
     RecordReader& rd() { return gpu ? static_cast<RecordReader&>(*gpu) : is_sam ? static_cast<RecordReader&>(sam) : static_cast<RecordReader&>(bam); }
     const BamHeader& hdr() const { return const_cast<bqc_bam*>(this)->rd().header(); }
     ~bqc_bam() { if (sam_file && sam_file != stdin) fclose(sam_file); }
@@ -308,10 +310,35 @@ extern "C" int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_
     b->refresh_lanes();
     return 0;
 }
-extern "C" uint64_t bqc_bam_range_begin_block(const bqc_bam* b) { return b->bam.range_begin_block(); }
-extern "C" uint64_t bqc_bam_range_end_block(const bqc_bam* b) { return b->bam.range_end_block(); }
-extern "C" uint64_t bqc_bam_range_first(const bqc_bam* b) { return b->bam.range_first(); }
-extern "C" uint64_t bqc_bam_range_over(const bqc_bam* b) { return b->bam.range_over(); }
+// the block boundaries of a shard, as BamReader::open_range finds them; false: an empty shard (or an error: err set)
+static bool shard_blocks(const char* path, uint64_t begin_hint, uint64_t end_hint, uint64_t& b0, uint64_t& b1, std::string& err)
+{
+    const uint64_t size = bgzf_file_size(path);
+    b1 = end_hint >= size ? UINT64_MAX : bgzf_find_block(path, end_hint, err);
+    if (b1 >= size) b1 = UINT64_MAX;
+    b0 = begin_hint == 0 ? 0 : bgzf_find_block(path, begin_hint, err);
+    return err.empty() && b0 < std::min(b1, size);
+}
+extern "C" int bqc_bam_open_gpu_range(const char* path, int device, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out)
+{
+    if (!path || !out) return BQC_ERR_ARG;
+    auto* b = new bqc_bam();
+    *out = b;
+    if (!shard_blocks(path, begin_hint, end_hint, b->g_b0, b->g_b1, b->err)) { if (b->err.empty()) b->err = "empty shard"; return BQC_ERR_ARG; }
+    if (!b->bam.open(path, b->err, true)) return BQC_ERR_IO; // the header, on the host
+    b->gpu.reset(new GpuBamReader());
+    const uint64_t first_record = b->bam.stream_pos();
+    b->bam.close();
+    b->gpu->set_range(b->g_b0, b->g_b1);
+    if (!b->gpu->open(path, device, b->bam.header(), first_record, 1u << 20, 256u << 20, b->err)) { b->gpu.reset(); return BQC_ERR_DEVICE; }
+    b->gpu->allow_kernels();
+    b->refresh_lanes();
+    return 0;
+}
+extern "C" uint64_t bqc_bam_range_begin_block(const bqc_bam* b) { return b->gpu ? b->g_b0 : b->bam.range_begin_block(); }
+extern "C" uint64_t bqc_bam_range_end_block(const bqc_bam* b) { return b->gpu ? b->g_b1 : b->bam.range_end_block(); }
+extern "C" uint64_t bqc_bam_range_first(const bqc_bam* b) { return b->gpu ? b->gpu->range_first() : b->bam.range_first(); }
+extern "C" uint64_t bqc_bam_range_over(const bqc_bam* b) { return b->gpu ? b->gpu->range_over() : b->bam.range_over(); }
 extern "C" uint64_t bqc_file_size(const char* path) { return path ? bgzf_file_size(path) : 0; }
 extern "C" void bqc_gpu_inflate_device(int device) { bgzf_gpu_inflate_device(device); }
 extern "C" uint64_t bqc_gpu_inflated_blocks(void) { return bgzf_gpu_inflated_blocks(); }
@@ -746,11 +773,22 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     auto shard_abort = [&]() { if (shard) { bqc_shard_info si{}; si.status = 1; bqc_shard_result sr{}; (void)shard->hook(shard->user, &si, &sr); } return 1; };
     if (shard && from_stdin) { fprintf(stderr, "ERROR: a stream on stdin cannot be split between processes\n"); return shard_abort(); }
     bool opened;
+    // a shard of the file: its block boundaries are found here (BamReader::open_range finds the same ones: bgzf_find_block is a
+    // function of the hint), so that either reader can take the range
+    uint64_t shard_b0 = 0, shard_b1 = UINT64_MAX;
+    bool shard_gpu = false;
     if (from_stdin) opened = sam_rd.open(stdin, err);
     else if (shard) { // this process's part of the compressed file
         const uint64_t size = bqc_file_size(opt.bamFile.c_str());
         const uint64_t lo = size / shard->count * shard->index, hi = shard->index + 1 == shard->count ? UINT64_MAX : size / shard->count * (shard->index + 1);
-        opened = bam_rd.open_range(opt.bamFile.c_str(), lo, hi, err);
+        const char* gd = getenv("BQC_GPU_DECODE");
+        struct stat st;
+        if (!host_reader_only && !(gd && atoi(gd) == 0) && stat(opt.bamFile.c_str(), &st) == 0 && S_ISREG(st.st_mode)) {
+            std::string e2;
+            // (an empty part, or a small one, is the host reader's: the GPU reader's set-up costs ~50 ms)
+            shard_gpu = shard_blocks(opt.bamFile.c_str(), lo, hi, shard_b0, shard_b1, e2) && (gd || std::min(shard_b1, size) - shard_b0 >= (256ull << 20));
+        }
+        opened = shard_gpu ? bam_rd.open(opt.bamFile.c_str(), err, true) /* the header; the records come from the card */ : bam_rd.open_range(opt.bamFile.c_str(), lo, hi, err);
     } else {
         // (a file the GPU reader will probably take: the host reader is only asked for the header — a small first run)
         const char* gd = getenv("BQC_GPU_DECODE");
@@ -769,8 +807,16 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // host reader (host_reader_only).  BQC_GPU_DECODE=0: the host reader from the start.
     GpuBamReader gpu_rd;
     const char* gd_env = getenv("BQC_GPU_DECODE"); // 1: whenever possible, 0: never; unset: files of 256 MB and more (its set-up costs ~50 ms)
-    bool use_gpu_reader = !from_stdin && !shard && !host_reader_only && bam_rd.header().lane_count != 0 && !(gd_env && atoi(gd_env) == 0);
-    if (use_gpu_reader) { // a regular file: the reader opens it a second time
+    bool use_gpu_reader = !from_stdin && (!shard || shard_gpu) && !host_reader_only && bam_rd.header().lane_count != 0 && !(gd_env && atoi(gd_env) == 0);
+    if (shard && shard_gpu && !use_gpu_reader) { // (no @RG line: the host reader, over its range, decides what that means)
+        bam_rd.~BamReader();
+        new (&bam_rd) BamReader();
+        const uint64_t size = bqc_file_size(opt.bamFile.c_str());
+        const uint64_t lo = size / shard->count * shard->index, hi = shard->index + 1 == shard->count ? UINT64_MAX : size / shard->count * (shard->index + 1);
+        if (!bam_rd.open_range(opt.bamFile.c_str(), lo, hi, err)) { fprintf(stderr, "ERROR: Could not open %s for reading.\n", opt.bamFile.c_str()); return shard_abort(); }
+        shard_gpu = false;
+    }
+    if (use_gpu_reader && !shard) { // a regular file: the reader opens it a second time
         struct stat st;
         use_gpu_reader = stat(opt.bamFile.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (gd_env || (uint64_t)st.st_size >= (256ull << 20));
     }
@@ -778,6 +824,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (use_gpu_reader) {
         first_record_u = bam_rd.stream_pos();
         bam_rd.close(); // (its read-ahead has inflated the first run of blocks for the header; no more)
+        if (shard) gpu_rd.set_range(shard_b0, shard_b1);
         bqc_raw_vector_free_hook = pin_free_hook;
         bqc_raw_vector_pin_hook = pin_hook;
     }
@@ -822,7 +869,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (H.lane_count != 0) dec = std::thread([&]() {
         if (use_gpu_reader) {
             std::string e;
-            const bool ok = gpu_rd.open(opt.bamFile.c_str(), opt.device, bam_rd.header(), first_record_u, opt.batch_reads, 256ull << 20, e);
+            const bool ok = gpu_rd.open(opt.bamFile.c_str(), opt.device, gpu_rd.header(), first_record_u, opt.batch_reads, 256ull << 20, e);
             gpu_reader_opened = true; // (the context is created after this: see there)
             if (!ok) {
                 std::lock_guard<std::mutex> lk(Q.m);
@@ -963,7 +1010,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         const auto s0 = clk::now();
         t_wait += secs(w0, s0);
         n_total += v.n_reads;
-        if (pinned) {
+        if (pinned || hb->d_seq) { // (BQC_NO_PINNED=1 is about host columns: a payload that lives on the card can only be taken from there)
             if (!hb->d_seq) pin_batch(*hb); // (a batch decoded on the card: its payload is there already, its small fixed columns are copied staged)
             uint64_t ticket = 0;
             if ((rc = bqc_submit_async(ctx, &v, &ticket))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
@@ -1003,7 +1050,8 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (shard) { // what needs the other processes: split check, coverage hand-over, sum of the state vectors, lane names
         bqc_shard_info si{};
         si.ctx = ctx; si.status = status;
-        si.begin_block = bam_rd.range_begin_block(); si.end_block = bam_rd.range_end_block(); si.first = bam_rd.range_first(); si.over = bam_rd.range_over();
+        if (use_gpu_reader) { si.begin_block = shard_b0; si.end_block = shard_b1; si.first = gpu_rd.range_first(); si.over = gpu_rd.range_over(); }
+        else { si.begin_block = bam_rd.range_begin_block(); si.end_block = bam_rd.range_end_block(); si.first = bam_rd.range_first(); si.over = bam_rd.range_over(); }
         si.sample_id = rd.header().sample_id.c_str();
         si.n_lane_names = (uint32_t)names.size(); si.lane_names = names.data(); si.lane_index = idx.data();
         bqc_shard_result sr{};
@@ -1052,6 +1100,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         if (done_fd) { // nothing is printed from here on: the run is reported complete, then this process cleans up on its own
             const int fd = atoi(done_fd);
             const unsigned char st = 0;
+            (void)prctl(PR_SET_PDEATHSIG, 0); // (the front end leaves now; this process still hands its memory back)
             if (write(fd, &st, 1) == 1) {
                 close(fd);
                 const int nul = open("/dev/null", O_WRONLY);

@@ -1,22 +1,24 @@
 // raw_vector.h — std::vector whose resize() leaves new elements uninitialised (every element is overwritten by its producer).
 #pragma once
+#include <atomic>
 #include <memory>
 #include <utility>
 #include <vector>
 
 // Called with every block a raw_vector gives back, before it is freed: the program page-locks the columns it decodes into
 // (driver.cpp) and must release the lock of a block that a growing vector is about to free.
-inline void (*bqc_raw_vector_free_hook)(void*) = nullptr;
+// (atomic: set by the program's main thread while reader and worker threads give blocks back)
+inline std::atomic<void (*)(void*)> bqc_raw_vector_free_hook{nullptr};
 // The other direction: a producer that fills a buffer by copies from the device (the BGZF reader when the GPU inflates) asks for
 // the block to be page-locked; whoever sets this hook sets the one above too.
-inline void (*bqc_raw_vector_pin_hook)(const void*, size_t) = nullptr;
+inline std::atomic<void (*)(const void*, size_t)> bqc_raw_vector_pin_hook{nullptr};
 
 template <typename T>
 struct no_init_alloc : std::allocator<T> {
     template <typename U> struct rebind { using other = no_init_alloc<U>; };
     void deallocate(T* p, std::size_t n)
     {
-        if (bqc_raw_vector_free_hook) bqc_raw_vector_free_hook((void*)p);
+        if (auto hook = bqc_raw_vector_free_hook.load(std::memory_order_acquire)) hook((void*)p);
         std::allocator<T>::deallocate(p, n);
     }
     template <typename U> void construct(U* p) noexcept { ::new ((void*)p) U; }

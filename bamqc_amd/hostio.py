@@ -35,7 +35,9 @@ class BamFile:
         gpu: a device index — the file is inflated and decoded on that GPU (batches are fetched back)."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
-        if gpu is not None:
+        if gpu is not None and (begin_hint is not None or end_hint is not None):
+            rc = self.lib.bqc_bam_open_gpu_range(path.encode(), gpu, begin_hint or 0, 2 ** 64 - 1 if end_hint is None else end_hint, C.byref(self.h))
+        elif gpu is not None:
             rc = self.lib.bqc_bam_open_gpu(path.encode(), gpu, C.byref(self.h))
         elif begin_hint is None and end_hint is None:
             rc = self.lib.bqc_bam_open(path.encode(), C.byref(self.h))

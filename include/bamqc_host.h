@@ -62,6 +62,8 @@ int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint,
  * the caller).  bqc_bam_next returns -1000 when the file needs the host reader (a read group missing from the header, a record
  * the host reader would report, ...): open it with bqc_bam_open then. */
 int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out);
+/* A shard (as bqc_bam_open_range) read, inflated and decoded on GPU `device`: only the shard's bytes of the file are touched. */
+int bqc_bam_open_gpu_range(const char* path, int device, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out);
 uint64_t bqc_bam_range_begin_block(const bqc_bam* b);
 uint64_t bqc_bam_range_end_block(const bqc_bam* b);   /* UINT64_MAX: end of the file */
 uint64_t bqc_bam_range_first(const bqc_bam* b);       /* valid after the first bqc_bam_next */
@@ -131,9 +133,17 @@ typedef struct bqc_shard_result {     /* filled by the hook for BQC_SHARD_WRITE:
     const char* const* lane_names;
     const uint32_t* lane_index;
 } bqc_shard_result;
-enum { BQC_SHARD_WRITE = 0, BQC_SHARD_DONE = 1, BQC_SHARD_FALLBACK = 2, BQC_SHARD_FAIL = 3 };
+enum { BQC_SHARD_FAIL = 0, BQC_SHARD_DONE = 1, BQC_SHARD_FALLBACK = 2, BQC_SHARD_WRITE = 3 }; /* (0 — what a hook that died returns — never means "write") */
 typedef int (*bqc_shard_hook)(void* user, const bqc_shard_info* info, bqc_shard_result* out);
 int bqc_main_shard(int argc, const char** argv, uint32_t shard_index, uint32_t shard_count, bqc_shard_hook hook, void* user);
+
+/* The program over n_gpus GPUs of one node as one binary (`bamqualcheck --gpus N`; reference: the single main() of
+ * bamqualcheck.cpp:239-457): forks one worker per GPU — call it before anything in the process has touched a GPU — each of
+ * which runs bqc_main_shard over its byte range of the BAM file; the shard hook is implemented in C++ over socket pairs for the
+ * few words of agreement and the 8 KB coverage hand-over, and over librccl (loaded at run time) for the ONE reduce of the state
+ * vectors: ncclReduce(uint64, sum) on device pointers.  BQC_REDUCE=pipe sums on the host instead (and so do workers that share
+ * one card, BQC_GPUS_SHARE_DEVICE=1).  argv: the program's arguments (without --gpus).  Returns the exit status. */
+int bqc_main_multi(int argc, const char** argv, int n_gpus);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,44 @@ def read_bam(path):
     return text, refs, recs
 
 
+def columns(path, main_chrom=None):
+    """The file as the column dict the product's readers hand out (include/bamqc.h: bqc_batch) — decoded here from the records
+    of read_bam, sharing nothing with the product: flag with the decoder's annotations (0x1000 mate on a main chromosome,
+    0x8000 no qualities), lane through the header's @RG order, first integer NM, first AS.  Returns (cols, refs, lanes, sample)."""
+    text, refs, recs = read_bam(path)
+    lanes, sample = {}, ""
+    for line in text.split("\n"):
+        if line.startswith("@RG"):
+            for f in line.split("\t")[1:]:
+                if f.startswith("ID:"):
+                    lanes[f[3:]] = len(lanes)
+                if f.startswith("SM:"):
+                    sample = f[3:]
+    main = [1] * len(refs) if main_chrom is None else list(main_chrom)
+    ints = "cCsSiI"
+    want = dict(flag=[], mapq=[], lane=[], rid=[], pos=[], tlen=[], nm=[], as_=[], l_seq=[], n_cigar=[])
+    for r in recs:
+        f = r["flag"] & 0x0FFF
+        if 0 <= r["rnext"] < len(refs) and main[r["rnext"]]:
+            f |= 0x1000
+        if r["l_seq"] > 0 and r["qual"][0] == 0xFF:
+            f |= 0x8000
+        nm = [v for key, vals in r["tags"].items() if key == "NM" for ty, v in vals if ty in ints]
+        as_ = [v for key, vals in r["tags"].items() if key == "AS" for ty, v in vals]
+        want["flag"].append(f); want["mapq"].append(r["mapq"]); want["lane"].append(lanes[r["tags"]["RG"][0][1]])
+        want["rid"].append(r["rid"]); want["pos"].append(r["pos"]); want["tlen"].append(r["tlen"])
+        want["nm"].append((nm[0] & 0xFFFFFFFF) if nm else 0xFFFFFFFF)
+        want["as_"].append((int(as_[0]) & 0xFFFFFFFF) if as_ else 0x80000000)
+        want["l_seq"].append(r["l_seq"]); want["n_cigar"].append(len(r["cigar"]))
+    dt = dict(flag=np.uint16, mapq=np.uint8, lane=np.uint8, rid=np.int32, pos=np.int32, tlen=np.int32, l_seq=np.uint32, n_cigar=np.uint16)
+    cols = {k: np.array(v, np.int64).astype(dt[k]) for k, v in want.items() if k in dt}
+    cols["nm"] = np.array(want["nm"], np.uint32).view(np.int32)
+    cols["as_"] = np.array(want["as_"], np.uint32).view(np.int32)
+    cat = lambda key, d: np.concatenate([r[key] for r in recs]).astype(d) if recs else np.zeros(0, d)
+    cols["seq"], cols["qual"], cols["cigar"] = cat("seq", np.uint8), cat("qual", np.uint8), cat("cigar", np.uint32)
+    return cols, refs, lanes, sample
+
+
 def bam_to_sam_text(path):
     """The BAM file as SAM text (header + one line per record; integer tags as type i)."""
     text, refs, recs = read_bam(path)

@@ -14,16 +14,6 @@ from bamqc_amd import distributed as D
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_plan_shards_covers_every_contig_once_and_balances():
-    from bamqc_amd.synth import GRCH38
-    for world in (1, 2, 4, 8):
-        owner = D.plan_shards(GRCH38, world)
-        assert owner.shape == (24,) and set(owner.tolist()) == set(range(world))
-        loads = np.bincount(owner, weights=np.array(GRCH38, float), minlength=world)
-        assert loads.max() / loads.mean() < 1.08  # LPT over 24 contigs is within a few % of perfect
-    assert D.plan_shards([5, 5, 5], 2).tolist() == [0, 1, 0]  # deterministic tie-breaks
-
-
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

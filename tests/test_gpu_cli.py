@@ -39,6 +39,9 @@ def test_config1_10k_reads_bytes_identical(tmp_path):
     assert oracle_bamqualcheck(bam, fa, want, chroms="chr1") == 0
     assert filecmp.cmp(got, want, shallow=False)
     assert filecmp.cmp(got, os.path.join(ROOT, "tests", "golden", "config1.bamqc"), shallow=False)  # committed fixture
+    ind = str(tmp_path / "independent.bamqc")  # the oracle fed by tests/pybam.py: no product code on the checker's side
+    assert oracle_bamqualcheck(bam, fa, ind, chroms="chr1", independent=True) == 0
+    assert filecmp.cmp(got, ind, shallow=False)
     txt = open(got).read()
     assert txt.startswith("sample_id SYN\nlane L1\ntotal_read_pairs ") and "triplet_counts_T_2nd_RC" in txt
 
@@ -115,3 +118,22 @@ def test_long_reads_end_to_end_batches_cut_by_bases(tmp_path):
     assert r.returncode == 0, r.stderr
     assert oracle_bamqualcheck(bam, fa, want, chroms="chr1,chr2", klist=(), qlist=(), batch_reads=5000) == 0
     assert filecmp.cmp(got, want, shallow=False)
+
+
+def test_paired_config1_output_feeds_the_downstream_consumer(tmp_path):
+    """SURVEY §8f N3 on the PRODUCT's output: the program's `.bamqc` for the properly paired config-1 reads passes the line rules
+    of the reference's bamqc_summary.py:96-131 (restated in tests/test_summary_consumer.py), holds every key summarize() reads,
+    and is byte for byte the oracle's file — the one tests/golden/config1_summary.json was computed from by the reference's own
+    consumer."""
+    from tests.test_summary_consumer import NEEDED, paired_config1_bamqc, read_rules
+    want, n = paired_config1_bamqc(tmp_path)
+    got = str(tmp_path / "product.bamqc")
+    r = run_cli("-r", str(tmp_path / "c1.fa"), "-o", got, "-c", "chr1", str(tmp_path / "paired.bam"))
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, want, shallow=False)
+    lanes = read_rules(got)
+    assert len(lanes) == 1
+    lane = lanes[0]
+    assert lane["total_read_pairs"] == n and lane["read_length"] == 150
+    assert not [k for k in NEEDED if k not in lane]
+    assert len(lane["8mer_count"]) == 65536 and len(lane["genome_coverage_histogram"]) == 101

@@ -120,3 +120,64 @@ def test_damaged_blocks_are_an_error_for_both_readers(tmp_path):
                 n = sum(len(x["flag"]) for x in b.batches(100_000))
                 raise AssertionError("read %d records to the end of a damaged file" % n)
             assert "1000" not in str(e.value)  # an error, not a hand-over
+
+
+def _shard_hints(path, n):
+    import os
+    size = os.path.getsize(path)
+    return [(size // n * i, None if i + 1 == n else size // n * (i + 1)) for i in range(n)]
+
+
+@pytest.mark.parametrize("shape,n", [("short_pe", 2), ("short_pe", 5), ("long_reads", 3), ("lanes", 7)])
+def test_gpu_range_reader_matches_host_range_reader(tmp_path, monkeypatch, shape, n):
+    """A shard of the file (records that START between two block boundaries) through the reader on the card: the same columns and
+    the same chain words (first / over) as the host reader's shard; the shards together are the whole file; only the shard's
+    bytes are read.  Runs of 8 MB so that the end block lies in a later run than the start and records cross run boundaries."""
+    path = str(tmp_path / "x.bam")
+    kw = dict(seed=33, n_reads=600_000, ref_names=["chr1", "chr2", "chrM"], ref_lens=[4_000_000, 2_500_000, 16_000])
+    if shape == "lanes":
+        kw.update(n_lanes=3, n_reads=400_000)
+    if shape == "long_reads":
+        kw.update(long_reads=True, n_reads=12_000, read_len=9000)
+    hostio.synth_stream(path, None, **kw)
+    whole, _ = all_columns(path, 250_000)
+    monkeypatch.setenv("BQC_GB_RUN_MB", "8")
+    parts = []
+    prev_over = None
+    for lo, hi in _shard_hints(path, n):
+        hb = hostio.BamFile(path, begin_hint=lo, end_hint=hi)
+        hcols = [dict((k, np.array(v, copy=True)) for k, v in b.items() if isinstance(v, np.ndarray)) for b in hb.batches(100_000)]
+        hinfo = hb.range_info
+        hb.close()
+        gb = hostio.BamFile(path, begin_hint=lo, end_hint=hi, gpu=0)
+        gcols = [dict((k, np.array(v, copy=True)) for k, v in b.items() if isinstance(v, np.ndarray)) for b in gb.batches(77_000)]
+        ginfo = gb.range_info
+        gb.close()
+        assert ginfo == hinfo, (lo, hi)
+        assert hcols and gcols
+        h = {k: np.concatenate([c[k] for c in hcols]) for k in hcols[0]}
+        g = {k: np.concatenate([c[k] for c in gcols]) for k in gcols[0]}
+        same(h, g)
+        if prev_over is not None:
+            assert ginfo[2] == prev_over  # the chain: this shard begins where its predecessor's last record ended
+        prev_over = ginfo[3]
+        parts.append(g)
+    same(whole, {k: np.concatenate([p[k] for p in parts]) for k in parts[0]})
+
+
+def test_gpu_reader_against_an_independent_decoder(tmp_path):
+    """The reader on the card against tests/pybam.py (gzip + struct, shares nothing with the product): the wild file with
+    every tag type, and a synthetic file — every column, not through the host reader."""
+    from tests import pybam
+    from tests.test_host_io import _wild_bam
+    wild = str(tmp_path / "wild.bam")
+    _wild_bam(wild, 29, 3000, extra_nm=False)
+    synth = str(tmp_path / "s.bam")
+    hostio.synth_stream(synth, None, seed=3, n_reads=40_000, ref_names=["chr1", "chr2"], ref_lens=[900_000, 400_000], n_lanes=2)
+    for path, main in ((wild, [1, 1, 1]), (synth, [1, 0])):
+        want, refs, _, _ = pybam.columns(path, main)
+        b = hostio.BamFile(path, gpu=0)
+        b.set_main_chrom(np.array(main[:len(refs)], np.uint8))
+        got = [dict((k, np.array(v, copy=True)) for k, v in x.items() if isinstance(v, np.ndarray)) for x in b.batches(1777)]
+        b.close()
+        same(want, {k: np.concatenate([c[k] for c in got]) for k in got[0]})

@@ -31,7 +31,12 @@ def same(a, b):
     raise AssertionError("outputs differ in %d lines: %s" % (len(diff), diff[:12]))
 
 
-def run_ranks(world, args, env_extra=None, timeout=600):
+def run_ranks(world, args, env_extra=None, timeout=600, launcher="torch"):
+    if launcher == "cxx":  # the one-binary form: bamqualcheck --gpus N forks its workers itself (bamqc_amd/host/multi_gpu.cpp)
+        env = dict(os.environ, BQC_GPUS_SHARE_DEVICE="1")  # (the test box has one card: every worker uses device 0, sums go through pipes)
+        env.update(env_extra or {})
+        r = subprocess.run([EXE, "--gpus", str(world)] + list(args), env=env, capture_output=True, text=True, timeout=timeout)
+        return [r.returncode] * world, [r.stdout + r.stderr] * world
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for rank in range(world):
@@ -55,13 +60,24 @@ def inputs(tmp_path_factory):
     return bam, fa, single, d
 
 
+@pytest.mark.parametrize("launcher", ["torch", "cxx"])
+@pytest.mark.parametrize("decode", ["0", "1"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_byte_range_shards_equal_single_process(inputs, world):
+def test_byte_range_shards_equal_single_process(inputs, world, decode, launcher):
+    """decode 1: every rank inflates and decodes ITS byte range on the card (csrc/gpu_bam.hip: set_range); 0: the host reader."""
     bam, fa, single, d = inputs
-    out = str(d / ("sharded%d.bamqc" % world))
-    rcs, outs = run_ranks(world, ["-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam])
+    out = str(d / ("sharded%d_%s_%s.bamqc" % (world, decode, launcher)))
+    rcs, outs = run_ranks(world, ["-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam], env_extra={"BQC_GPU_DECODE": decode, "BQC_TIMING": "1"}, launcher=launcher)
     assert rcs == [0] * world, outs
     assert same(single, out)
+    if decode == "1":
+        assert all("records decoded on the GPU" in o for o in outs), outs
+    if world == 2 and launcher == "torch":  # against the ORACLE's file too, not only the single-process GPU run
+        from tests.cli_oracle import oracle_bamqualcheck
+        want = str(d / "oracle.bamqc")
+        if not os.path.exists(want):
+            assert oracle_bamqualcheck(bam, fa, want, chroms="chr1,chr2", isize=800) == 0
+        assert same(want, out)
 
 
 def test_sparse_coverage_and_small_batches(tmp_path):
@@ -77,18 +93,20 @@ def test_sparse_coverage_and_small_batches(tmp_path):
     assert same(single, out)
 
 
-def test_unverifiable_split_falls_back_to_one_process(inputs):
-    """BQC_TEST_SHARD_SKEW makes every middle shard guess its first record wrong: the ranks notice (the predecessor's last
-    record does not end where the successor began), rank 0 processes the file alone, the output is still right."""
+@pytest.mark.parametrize("launcher,decode", [("torch", "0"), ("torch", "1"), ("cxx", "1")])
+def test_unverifiable_split_falls_back_to_one_process(inputs, launcher, decode):
+    """BQC_TEST_SHARD_SKEW makes every middle shard guess its first record wrong (either reader): the ranks notice (the
+    predecessor's last record does not end where the successor began), rank 0 processes the file alone, the output is still right."""
     bam, fa, single, d = inputs
-    out = str(d / "fallback.bamqc")
-    rcs, outs = run_ranks(2, ["-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam], env_extra={"BQC_TEST_SHARD_SKEW": "1"})
+    out = str(d / ("fallback_%s_%s.bamqc" % (launcher, decode)))
+    rcs, outs = run_ranks(2, ["-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam], env_extra={"BQC_TEST_SHARD_SKEW": "1", "BQC_GPU_DECODE": decode}, launcher=launcher)
     assert rcs == [0, 0], outs
     assert "could not be verified" in outs[0]
     assert same(single, out)
 
 
-def test_an_error_on_one_rank_ends_all_ranks(inputs):
+@pytest.mark.parametrize("launcher", ["torch", "cxx"])
+def test_an_error_on_one_rank_ends_all_ranks(inputs, launcher):
     """The FASTA file lacks a contig that only the LAST rank's reads need: that rank reports it, every rank exits 1 (no rank is
     left waiting in a collective)."""
     bam, fa, single, d = inputs
@@ -100,6 +118,24 @@ def test_an_error_on_one_rank_ends_all_ranks(inputs):
                 keep = line.startswith(">chr1")
             if keep:
                 g.write(line)
-    rcs, outs = run_ranks(2, ["-r", fa1, "-o", str(d / "err.bamqc"), "-c", "chr1,chr2", "-i", "800", bam])
+    rcs, outs = run_ranks(2, ["-r", fa1, "-o", str(d / "err.bamqc"), "-c", "chr1,chr2", "-i", "800", bam], launcher=launcher)
     assert rcs == [1, 1], outs
     assert any("Could not read fasta record" in o for o in outs)
+
+
+@pytest.mark.parametrize("launcher", ["cxx", "torch"])
+def test_rccl_set_up_and_reduce_run_on_one_card(inputs, launcher):
+    """One process through the sharded path with the REAL backend (the other tests of this module sum through gloo / pipes, the
+    box has one card): communicator set-up and the reduce of the state vector on a device pointer — ncclCommInitRank + ncclReduce
+    from C++ (`bamqualcheck --gpus 1`, BQC_GPUS_FORCE=1), init_process_group("nccl") + dist.reduce from the torch launcher."""
+    bam, fa, single, d = inputs
+    out = str(d / ("rccl1_%s.bamqc" % launcher))
+    args = ["-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam]
+    if launcher == "cxx":
+        r = subprocess.run([EXE, "--gpus", "1"] + args, env=dict(os.environ, BQC_GPUS_FORCE="1", BQC_GPU_DECODE="1"), capture_output=True, text=True, timeout=600)
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, BQC_FORCE_SHARD_PATH="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-m", "bamqc_amd.dist_cli"] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert same(single, out)

@@ -58,7 +58,9 @@ def paired_config1_bamqc(tmp_path):
     keep = np.sort(np.concatenate([first[:n], second[:n]]))
     o = Oracle(n_lanes=f.lane_count, n_refs=1, isize=1000, main_chrom=main, fasta_index=np.array([0], np.int32), klist=(32,), qlist=(17,))
     o.reference(0, refs[0][1])
-    assert o.process(take(cols, keep)) == 0
+    kept = take(cols, keep)
+    hostio.write_bam(str(tmp_path / "paired.bam"), kept, ["chr1"], [1_000_000])  # (the same reads as a file: the program's input in tests/test_gpu_cli.py)
+    assert o.process(kept) == 0
     o.finalize()
     lanes = f.lanes()
     out = str(tmp_path / "paired.bamqc")
