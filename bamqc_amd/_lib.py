@@ -58,6 +58,7 @@ _SIGNATURES = {
     "bqc_bam_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "bqc_bam_open_range": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "bqc_bam_open_gpu": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "bqc_bam_batches_handed_over": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_open_gpu_range": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "bqc_bam_range_begin_block": (C.c_uint64, [C.c_void_p]),
     "bqc_bam_range_end_block": (C.c_uint64, [C.c_void_p]),

@@ -12,9 +12,11 @@
 
 class GpuBamReader : public RecordReader {
 public:
-    // err_code of next_batch when this input needs the host reader instead (a read group that is not in the header, a record the
-    // host reader would report, a record walk that cannot be verified, ...): nothing has been reported to the user, the caller
-    // starts over with BamReader, which decides what is an error and what is not.
+    // err_code of next_batch when this input needs the host reader instead (a record walk that cannot be verified, a corrupt
+    // record, a file that ends inside a record): nothing has been reported to the user, the caller starts over with BamReader, which
+    // decides what is an error and what is not.  A BATCH with a record the card does not decode (a read group that is not in the
+    // header, a second NM tag, no RG tag, ...) is not such a case: that batch is decoded by the host reader's rules
+    // (bam_decode_records) from the bytes on the card, and the run continues.
     static const int kUnsupported = -1000;
     GpuBamReader();
     ~GpuBamReader() override;
@@ -37,6 +39,7 @@ public:
     void set_main_chrom(const std::vector<uint8_t>& mc) override { main_ = mc; }
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
+    uint64_t batches_handed_over() const { return n_handed_over_; } // batches decoded by the host reader's rules (see next_batch)
     double seconds_reading() const { return t_read_; } // time spent in fread
     // set by open() once its device buffers are allocated (also when it fails before that): a caller that creates its own device
     // context in another thread starts doing so from here on
@@ -47,7 +50,7 @@ private:
     Impl* p_ = nullptr;
     BamHeader hdr_;
     std::vector<uint8_t> main_;
-    uint64_t nrec_ = 0;
+    uint64_t nrec_ = 0, n_handed_over_ = 0;
     double t_read_ = 0;
     bool ranged_ = false;
     uint64_t range_b0_ = 0, range_b1_ = UINT64_MAX, range_first_ = 0, range_over_ = 0;

@@ -394,6 +394,8 @@ struct GpuBamReader::Impl {
     bool timing = false;
     double t_read = 0, t_wait_run = 0;
     uint64_t n_rewalk = 0;
+    raw_vector<uint8_t> handover_raw;      // a batch the host decoder takes: its bytes
+    std::vector<BamRec> handover_recs;
     double avg_rec_bytes = 0, avg_rec_bases = 0;
     uint64_t grow_window = 0;
 
@@ -417,6 +419,24 @@ struct GpuBamReader::Impl {
         if (f) fclose(f);
     }
     bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
+    // read-group ids -> lane index, column-wise: off[n] len[n] index[n] (again when a batch handed over to the host decoder has met
+    // ids that are not in the header: they are lane 0 from then on, bamqualcheck.cpp:86)
+    bool upload_lanes(const BamHeader& hdr)
+    {
+        std::vector<uint8_t> blob;
+        n_lane_ids = (uint32_t)hdr.lane_names.size();
+        lane_count = hdr.lane_count;
+        std::vector<uint32_t> cols(3 * (size_t)n_lane_ids + 1);
+        uint32_t l = 0;
+        for (const auto& kv : hdr.lane_names) {
+            cols[l] = (uint32_t)blob.size(); cols[n_lane_ids + l] = (uint32_t)kv.first.size(); cols[2 * n_lane_ids + l] = kv.second;
+            blob.insert(blob.end(), kv.first.begin(), kv.first.end());
+            ++l;
+        }
+        if (!d_lane_blob.need(blob.size() + 1) || !d_lane_tab.need(cols.size())) return false;
+        if (!blob.empty() && hipMemcpy(d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+        return hipMemcpy(d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     // page-locked chunks the file is read into (from the second run on)
     struct PinChunk { uint8_t* p = nullptr; hipEvent_t done = nullptr; bool used = false; };
     static const int kChunks = 2;
@@ -525,22 +545,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
     }
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
-    // read-group ids -> lane index, column-wise: off[n] len[n] index[n]
-    std::vector<uint8_t> blob;
-    I.n_lane_ids = (uint32_t)hdr.lane_names.size();
-    I.lane_count = hdr.lane_count;
-    std::vector<uint32_t> cols(3 * (size_t)I.n_lane_ids + 1);
-    {
-        uint32_t l = 0;
-        for (const auto& kv : hdr.lane_names) {
-            cols[l] = (uint32_t)blob.size(); cols[I.n_lane_ids + l] = (uint32_t)kv.first.size(); cols[2 * I.n_lane_ids + l] = kv.second;
-            blob.insert(blob.end(), kv.first.begin(), kv.first.end());
-            ++l;
-        }
-    }
-    if (!I.d_lane_blob.need(blob.size() + 1) || !I.d_lane_tab.need(cols.size())) { err = "GPU reader: out of device memory"; return false; }
-    if (!blob.empty()) (void)hipMemcpy(I.d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice);
-    (void)hipMemcpy(I.d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice);
+    if (!I.upload_lanes(hdr)) { err = "GPU reader: out of device memory"; return false; }
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
     I.cv.notify_all();
     if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms: first stream %.1f, second stream + events + status words %.1f, page-locked chunks + tables %.1f)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3, (t_s1 - t_s0) * 1e3, (t_s2 - t_s1) * 1e3, (now_s() - t_s2) * 1e3);
@@ -941,7 +946,39 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         if (he == hipSuccess) he = hipMemcpyAsync(o.l_seq.data(), C.l_seq, N * 4, hipMemcpyDeviceToHost, I.s);
         if (he == hipSuccess) he = hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s);
         if (he != hipSuccess || !I.sync()) return fail_dev("decode failed");
-        if (*I.h_status) return unsupported("a record the host reader handles (read group / tags)");
+        if (*I.h_status) {
+            // A record the card does not decode (a read group that is not in the header, a second NM tag, no RG tag, ...): THIS
+            // batch is decoded by the host reader's rules — its bytes come back from the window, its records are listed by a serial
+            // walk, bam_decode_records (host/bam_io.cpp) fills the batch's host columns and decides what is an error — and the run goes
+            // on from the card with the next batch.
+            if (hipMemsetAsync(I.d_status, 0, 4, I.s) != hipSuccess) return fail_dev("memset failed");
+            try { I.handover_raw.resize((size_t)pos); } catch (const std::bad_alloc&) { return unsupported("no host memory for a batch handed over"); }
+            if (hipMemcpy(I.handover_raw.data(), base, (size_t)pos, hipMemcpyDeviceToHost) != hipSuccess) return fail_dev("copy failed");
+            std::vector<BamRec>& recs = I.handover_recs;
+            recs.clear();
+            recs.reserve(N);
+            size_t hso = 0, hqo = 0, hco = 0;
+            for (uint64_t q = 0; q + 36 <= pos && recs.size() < N;) {
+                const uint8_t* r = I.handover_raw.data() + q;
+                const uint32_t bs = r[0] | (r[1] << 8) | (r[2] << 16) | ((uint32_t)r[3] << 24);
+                const uint32_t n_cig = r[16] | (r[17] << 8), l_seq = r[20] | (r[21] << 8) | (r[22] << 16) | ((uint32_t)r[23] << 24);
+                recs.push_back(BamRec{(size_t)q, bs, l_seq, n_cig, hso, hqo, hco, nrec_ + recs.size()});
+                hso += (l_seq + 1u) / 2u; hqo += l_seq; hco += n_cig;
+                q += 4ull + bs;
+            }
+            if (recs.size() != N || hso != so || hqo != qo || hco != co) return unsupported("the record walk could not be verified");
+            o.d_seq = o.d_qual = nullptr; o.d_cigar = nullptr; // (a host batch; its device buffer stays for the next one)
+            const bool fine = bam_decode_records(I.handover_raw.data(), recs, hdr_, main_, bqc_host_threads(), o, err, err_code);
+            ++n_handed_over_;
+            if (hdr_.lane_names.size() != I.n_lane_ids && !I.upload_lanes(hdr_)) return fail_dev("out of device memory");
+            I.cur += pos;
+            if (over) end_of_range(I.abs_of(I.cur));
+            nrec_ += n;
+            I.avg_rec_bytes = (double)pos / (double)n;
+            I.avg_rec_bases = (double)bases / (double)n;
+            if (I.timing) fprintf(stderr, "[gpu reader] batch of %zu records handed over to the host decoder (%.1f ms)\n", N, (now_s() - t0) * 1e3);
+            return fine ? 1 : -1;
+        }
         o.d_seq = pay + o_seq; o.d_qual = pay + o_qual; o.d_cigar = (const uint32_t*)(pay + o_cig);
         I.cur += pos;
         if (over) end_of_range(I.abs_of(I.cur));

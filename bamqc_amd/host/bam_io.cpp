@@ -233,7 +233,7 @@ void BamReader::walk_segment(const uint8_t* base, size_t avail, size_t a, size_t
         if (var > bs || p + 4 + (size_t)bs > avail) break;
         bool keep = true;
         if (filter_) keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
-        if (keep) out.recs.push_back(Rec{p, bs, l_seq, n_cig, 0, 0, 0, out.n_all});
+        if (keep) out.recs.push_back(BamRec{p, bs, l_seq, n_cig, 0, 0, 0, out.n_all});
         ++out.n_all;
         p += 4 + (size_t)bs;
     }
@@ -263,7 +263,7 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
     parallel_ranges(T, T, 1, [&](unsigned, size_t lo, size_t hi) {
         for (size_t t = lo; t < hi; ++t) walk_segment(base, avail, t * step, t + 1 == T ? avail : (t + 1) * step, t == 0, segs_[t]);
     });
-    std::vector<Rec>& recs = recs_;
+    std::vector<BamRec>& recs = recs_;
     size_t pos = 0;
     uint64_t n_all = 0;
     for (unsigned t = 0; t < T; ++t) {
@@ -273,7 +273,7 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
             if (pos < b) walk_segment(base, avail, pos, b, true, S);
             else { S.recs.clear(); S.n_all = 0; S.first = S.end = pos; }
         }
-        for (const Rec& r : S.recs) { recs.push_back(r); recs.back().nrec = nrec_ + n_all + r.nrec; }
+        for (const BamRec& r : S.recs) { recs.push_back(r); recs.back().nrec = nrec_ + n_all + r.nrec; }
         n_all += S.n_all;
         pos = S.end;
         if (pos < b) break; // an incomplete or invalid record: the serial walk continues (and reports) from here
@@ -281,7 +281,7 @@ void BamReader::parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel
     // the batch's limits and the payload offsets, in record order
     size_t n_take = 0;
     for (; n_take < recs.size() && n_take < max_reads && bases < max_bases; ++n_take) {
-        Rec& r = recs[n_take];
+        BamRec& r = recs[n_take];
         if (ranged_ && beyond_range(r.off)) break; // starts behind the shard's end: the serial walk below notes where
         r.so = so; r.qo = qo; r.co = co;
         so += (r.l_seq + 1) / 2; qo += r.l_seq; co += r.n_cig;
@@ -307,7 +307,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     err_code = 0;
     static const bool timing = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '3';
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<Rec>& recs = recs_;
+    std::vector<BamRec>& recs = recs_;
     recs.clear();
     if (range_done_) return 0;
     if (need_locate_) {
@@ -351,7 +351,7 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         bool keep = true;
         if (filter_) keep = rid < 0 ? keep_unplaced_ : ((size_t)rid < keep_.size() && keep_[rid]);
         if (keep) {
-            recs.push_back(Rec{rel, bs, l_seq, n_cig, so, qo, co, nrec_});
+            recs.push_back(BamRec{rel, bs, l_seq, n_cig, so, qo, co, nrec_});
             so += (l_seq + 1) / 2; qo += l_seq; co += n_cig;
             bases += l_seq;
         }
@@ -364,6 +364,32 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
     }
     const auto t1 = std::chrono::steady_clock::now();
     const size_t n = recs.size();
+    std::string derr;
+    int dcode = 0;
+    const bool decoded = bam_decode_records(buf_.data() + cur_, recs, hdr_, main_, bg_.threads(), o, derr, dcode);
+    cur_ += rel; // the decoded records may now be dropped from the buffer
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] batch of %zu records: walk %.3f s (of which waiting for inflated data %.3f s, appending it %.3f s), parallel decode %.3f s\n", n,
+                std::chrono::duration<double>(t1 - t0).count(), t_wait_, t_copy_, std::chrono::duration<double>(t2 - t1).count());
+        t_wait_ = t_copy_ = 0;
+    }
+    // the first error in record order wins; an I/O error of the walk comes after every indexed record
+    if (!decoded) { err = derr; err_code = dcode; return -1; }
+    if (io_error) { err_code = BQC_ERR_IO; return -1; }
+    return n ? 1 : 0;
+}
+
+// The records `recs` of the byte range at `base` into the batch's columns, by all host threads: tag scan (RG -> lane through the
+// header's table, every integer NM, first AS) and copies of the payload to where the walk has placed it.  Unknown RG ids
+// (std::map::operator[] inserts them with lane 0, bamqualcheck.cpp:86) and the per-record error rules are resolved in record
+// order afterwards.  false: a record the reference's rules end the run at (the first one in record order; err / err_code).
+bool bam_decode_records(const uint8_t* base, const std::vector<BamRec>& recs, BamHeader& hdr, const std::vector<uint8_t>& main_chrom, unsigned threads, HostBatch& o,
+                        std::string& err, int& err_code)
+{
+    const size_t n = recs.size();
+    size_t so = 0, qo = 0, co = 0;
+    if (n) { const BamRec& L = recs.back(); so = L.so + (L.l_seq + 1) / 2; qo = L.qo + L.l_seq; co = L.co + L.n_cig; }
     o.flag.resize(n); o.mapq.resize(n); o.lane.resize(n); o.rid.resize(n); o.pos.resize(n); o.tlen.resize(n);
     o.nm.resize(n); o.as.resize(n); o.l_seq.resize(n); o.n_cigar.resize(n);
     { // (batches are recycled: the capacities settle after the first ones)
@@ -372,18 +398,17 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
         if (o.seq.capacity() != c1) advise_huge(o.seq);
         if (o.qual.capacity() != c2) advise_huge(o.qual);
     }
-    const unsigned nt_max = bg_.threads();
+    const unsigned nt_max = std::max(1u, threads);
     std::vector<RecErr> errs(nt_max);
     std::vector<std::vector<std::pair<uint32_t, int32_t>>> extra(nt_max);          // further NM tags: (read, value)
     std::vector<std::vector<std::pair<uint32_t, std::string>>> unknown_rg(nt_max); // reads whose RG id is not in the header
-    const uint8_t* base = buf_.data() + cur_;
-    const auto& lane_names = hdr_.lane_names;
+    const auto& lane_names = hdr.lane_names;
     parallel_ranges(n, nt_max, 4096, [&](unsigned t, size_t lo, size_t hi) {
         std::string last_id;
         int last_lane = -1;
         bool have_last = false;
         for (size_t i = lo; i < hi; ++i) {
-            const Rec& R = recs[i];
+            const BamRec& R = recs[i];
             const uint8_t* r = base + R.off + 4;
             const int32_t rid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
             const uint32_t l_name = r[8], mapq = r[9];
@@ -463,11 +488,11 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
                 else if (rg_bad) { E.index = i; E.msg = "Read does not have Z"; E.code = BQC_ERR_ARG; }
                 else if (!rg_seen) { // DEFINED: the reference falls off the end of getLane() (undefined behaviour)
                     E.index = i; E.msg = "ERROR: read without RG tag (record " + std::to_string(R.nrec) + ")"; E.code = BQC_ERR_ARG;
-                } else if ((unsigned)lane >= hdr_.lane_count) { E.index = i; E.msg = "ERROR: read group index out of range (no @RG lines in the header?)"; E.code = BQC_ERR_ARG; }
+                } else if ((unsigned)lane >= hdr.lane_count) { E.index = i; E.msg = "ERROR: read group index out of range (no @RG lines in the header?)"; E.code = BQC_ERR_ARG; }
                 else if (nm_seen && nm == BQC_NM_ABSENT) { E.index = i; E.msg = "NM tag value 0xFFFFFFFF is not representable"; E.code = BQC_ERR_RANGE; }
             }
             uint32_t f = flag & 0x0FFFu;
-            if (rnext >= 0 && (size_t)rnext < main_.size() && main_[rnext]) f |= BQC_FLAG_MATE_MAIN;
+            if (rnext >= 0 && (size_t)rnext < main_chrom.size() && main_chrom[rnext]) f |= BQC_FLAG_MATE_MAIN;
             if (l_seq > 0 && ql[0] == 0xFF) f |= BQC_FLAG_NO_QUAL;
             o.flag[i] = (uint16_t)f; o.mapq[i] = (uint8_t)mapq; o.lane[i] = (uint8_t)(lane < 0 ? 0 : lane); o.rid[i] = rid;
             o.pos[i] = pos; o.tlen[i] = tlen; o.nm[i] = nm; o.as[i] = as; o.l_seq[i] = l_seq; o.n_cigar[i] = (uint16_t)n_cig;
@@ -476,28 +501,19 @@ int BamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, std:
             memcpy(o.qual.data() + R.qo, ql, l_seq);
         }
     });
-    cur_ += rel; // the decoded records may now be dropped from the buffer
-    if (timing) {
-        const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[timing] batch of %zu records: walk %.3f s (of which waiting for inflated data %.3f s, appending it %.3f s), parallel decode %.3f s\n", n,
-                std::chrono::duration<double>(t1 - t0).count(), t_wait_, t_copy_, std::chrono::duration<double>(t2 - t1).count());
-        t_wait_ = t_copy_ = 0;
-    }
     // unknown read groups, in record order: the first use inserts the id with lane 0
     for (auto& u : unknown_rg)
         for (auto& kv : u)
-            if (hdr_.lane_names.find(kv.second) == hdr_.lane_names.end()) hdr_.lane_names[kv.second] = 0;
+            if (hdr.lane_names.find(kv.second) == hdr.lane_names.end()) hdr.lane_names[kv.second] = 0;
     for (auto& x : extra)
         for (auto& kv : x) { o.nm_extra_read.push_back(kv.first); o.nm_extra_val.push_back(kv.second); }
-    // the first error in record order wins; an I/O error of the walk comes after every indexed record
+    // the first error in record order wins
     const RecErr* first = nullptr;
     for (auto& E : errs)
         if (E.index != SIZE_MAX && (!first || E.index < first->index)) first = &E;
-    if (first) { err = first->msg; err_code = first->code; return -1; }
-    if (io_error) { err_code = BQC_ERR_IO; return -1; }
-    return n ? 1 : 0;
+    if (first) { err = first->msg; err_code = first->code; return false; }
+    return true;
 }
-
 // ---------------------------------------------------------------------------------------------------
 // SAM text
 // ---------------------------------------------------------------------------------------------------

@@ -59,6 +59,14 @@ public:
 
 void parse_read_groups(BamHeader& h); // getSampleIdAndLaneNames, bamqualcheck.cpp:44-66
 
+// a record found by a walk over the block_size chain; off: relative to the walked range; so / qo / co: where its packed bases,
+// qualities and CIGAR words go in the batch's payload columns
+struct BamRec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; };
+// The decoder behind BamReader::next_batch, for any byte range whose records are known (also used by the reader on the card for
+// a batch it hands over: csrc/gpu_bam.hip): see bam_io.cpp.
+bool bam_decode_records(const uint8_t* base, const std::vector<BamRec>& recs, BamHeader& hdr, const std::vector<uint8_t>& main_chrom, unsigned threads, HostBatch& o,
+                        std::string& err, int& err_code);
+
 class BamReader : public RecordReader {
 public:
     // header_first: the first run of BGZF blocks is a small one (the caller may only want the header: the program when the records
@@ -94,9 +102,8 @@ private:
     BgzfReader bg_;
     BamHeader hdr_;
     raw_vector<uint8_t> buf_, chunk_;
-    struct Rec { size_t off; uint32_t bs, l_seq, n_cig; size_t so, qo, co; uint64_t nrec; }; // a record found by the walk; off: relative to cur_
-    std::vector<Rec> recs_; // (kept from batch to batch: 64 MB per million records)
-    struct WalkSeg { size_t first = 0, end = 0; uint64_t n_all = 0; std::vector<Rec> recs; };
+    std::vector<BamRec> recs_; // (kept from batch to batch: 64 MB per million records)
+    struct WalkSeg { size_t first = 0, end = 0; uint64_t n_all = 0; std::vector<BamRec> recs; };
     std::vector<WalkSeg> segs_;
     void walk_segment(const uint8_t* base, size_t avail, size_t a, size_t b, bool exact_start, WalkSeg& out) const;
     void parallel_prewalk(size_t max_reads, size_t max_bases, size_t& rel, size_t& bases, size_t& so, size_t& qo, size_t& co);

@@ -339,6 +339,7 @@ extern "C" uint64_t bqc_bam_range_begin_block(const bqc_bam* b) { return b->gpu 
 extern "C" uint64_t bqc_bam_range_end_block(const bqc_bam* b) { return b->gpu ? b->g_b1 : b->bam.range_end_block(); }
 extern "C" uint64_t bqc_bam_range_first(const bqc_bam* b) { return b->gpu ? b->gpu->range_first() : b->bam.range_first(); }
 extern "C" uint64_t bqc_bam_range_over(const bqc_bam* b) { return b->gpu ? b->gpu->range_over() : b->bam.range_over(); }
+extern "C" uint64_t bqc_bam_batches_handed_over(const bqc_bam* b) { return b && b->gpu ? b->gpu->batches_handed_over() : 0; }
 extern "C" uint64_t bqc_file_size(const char* path) { return path ? bgzf_file_size(path) : 0; }
 extern "C" void bqc_gpu_inflate_device(int device) { bgzf_gpu_inflate_device(device); }
 extern "C" uint64_t bqc_gpu_inflated_blocks(void) { return bgzf_gpu_inflated_blocks(); }
@@ -1027,6 +1028,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
     if (timing) fprintf(stderr, "[timing] records decoded %s\n", use_gpu_reader ? "on the GPU (csrc/gpu_bam.hip)" : "on the host");
+    if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",
                 (unsigned long long)n_total, t_decode, g_pins.t_register, t_submit, t_wait, secs(t_setup, clk::now()));

@@ -61,6 +61,11 @@ class BamFile:
         return (int(f.bqc_bam_range_begin_block(self.h)), int(f.bqc_bam_range_end_block(self.h)), int(f.bqc_bam_range_first(self.h)),
                 int(f.bqc_bam_range_over(self.h)))
 
+    @property
+    def batches_handed_over(self):
+        """GPU reader: batches that held a record the card does not decode and went through the host decoder."""
+        return int(self.lib.bqc_bam_batches_handed_over(self.h))
+
     def lanes(self):
         """[(name, index)] in output order (lexicographic by @RG ID)."""
         n = self.lib.bqc_bam_n_lane_names(self.h)

@@ -143,7 +143,9 @@ def main():
             pass
         out = {
             "metric": "BAM records/sec (and GB/s vs HBM roofline), 150 bp PE, 1/2/4/8 MI355X",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "reads/s",
+            "value_kind": "device-resident kernel step (inputs in HBM when the clock starts: the contract's `value`); BAM-file throughput of the program is e2e.reads_per_s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32/u64 integer", "data": "synthetic",
             "config": {"workload": ("config 5: %d reads x %d bases per GPU, 20-60 CIGAR operations, 1 x 250 Mb contig, -i 30000" if long_reads else
@@ -279,7 +281,7 @@ def e2e_leg(args, refs, cpu_kernel_value):
         hostio.synth_stream(bam, fa, 1002, args.reads, names, lens, read_len=args.read_len, level=1)
         t_write = time.time() - t0
         runs = []
-        for extra in ([], [], [], ["--no-sketch"]):
+        for extra in ([], [], [], [], [], ["--no-sketch"]):
             out = os.path.join(tmp, "o%d.bamqc" % len(runs))
             time.sleep(1.0)  # (the worker process of the run before hands its memory and its context back after its front end has left)
             t0 = time.perf_counter()
@@ -304,10 +306,25 @@ def e2e_leg(args, refs, cpu_kernel_value):
         t0 = time.perf_counter()
         assert oracle_bamqualcheck(pbam, pfa, want, chroms=",".join(names)) == 0
         t_cpu = time.perf_counter() - t0
-        best = max(runs[:3], key=lambda x: x["reads_per_s"])
-        return {"what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process"
-                        % (os.path.getsize(bam) / 1e6),
-                "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "host_cpus": cpu_limit(),
+        timed = sorted(runs[:5], key=lambda x: x["wall_s"])
+        best = timed[len(timed) // 2]  # the MEDIAN of five runs (each started a second after the one before has left)
+        # Ten files back to back, as a QC pipeline runs them: every front end starts the moment the one before has left, i.e. while
+        # that run's worker process is still handing its page-locked buffers and its GPU context back — the price of the early exit
+        # of tools/bamqualcheck.cpp is inside this wall time.
+        n_b2b = 10
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        for k in range(n_b2b):
+            r = subprocess.run([exe, "-r", fa, "-o", os.path.join(tmp, "b%d.bamqc" % k), "-c", ",".join(names), bam], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+        t_b2b = time.perf_counter() - t0
+        assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "b%d.bamqc" % k), shallow=False) for k in range(n_b2b))
+        return {"what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process "
+                        "(median of 5 runs; the front end leaves when the output is complete, its worker's teardown of 0.2-0.5 s is outside a single "
+                        "run's wall time and inside back_to_back's)" % (os.path.getsize(bam) / 1e6),
+                "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "wall_s_min": timed[0]["wall_s"], "wall_s_max": timed[-1]["wall_s"],
+                "back_to_back": {"files": n_b2b, "wall_s": t_b2b, "s_per_file": t_b2b / n_b2b, "reads_per_s": n_b2b * args.reads / t_b2b},
+                "host_cpus": cpu_limit(),
                 "runs": runs, "write_input_s": t_write,
                 "matches_oracle": filecmp.cmp(got, want, shallow=False), "oracle_prefix_reads": npre,
                 "cpu_port_e2e_reads_per_s": npre / t_cpu,

@@ -59,9 +59,12 @@ int bqc_bam_open(const char* path, bqc_bam** out);  /* on failure *out still hol
  * bqc_bam_range_over of a shard must equal bqc_bam_range_first of its successor (else: process the file unsharded). */
 int bqc_bam_open_range(const char* path, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out);
 /* The same reader with the file inflated and its records decoded on GPU `device` (the batches of bqc_bam_next are fetched back for
- * the caller).  bqc_bam_next returns -1000 when the file needs the host reader (a read group missing from the header, a record
- * the host reader would report, ...): open it with bqc_bam_open then. */
+ * the caller).  A batch that holds a record the card does not decode (a read group missing from the header, a second NM tag, no
+ * RG tag, ...) is decoded by the host reader's rules from the bytes on the card (bqc_bam_batches_handed_over counts them);
+ * bqc_bam_next returns -1000 when the FILE needs the host reader (a record walk that cannot be verified, a corrupt record, a
+ * file that ends inside a record): open it with bqc_bam_open then. */
 int bqc_bam_open_gpu(const char* path, int device, bqc_bam** out);
+uint64_t bqc_bam_batches_handed_over(const bqc_bam* b);
 /* A shard (as bqc_bam_open_range) read, inflated and decoded on GPU `device`: only the shard's bytes of the file are touched. */
 int bqc_bam_open_gpu_range(const char* path, int device, uint64_t begin_hint, uint64_t end_hint, bqc_bam** out);
 uint64_t bqc_bam_range_begin_block(const bqc_bam* b);

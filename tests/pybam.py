@@ -53,6 +53,12 @@ def read_bam(path):
                 e = r.index(b"\0", q)
                 val = r[q:e].decode()
                 q = e + 1
+            elif ty == "B":
+                st = chr(r[q])
+                cnt = struct.unpack_from("<i", r, q + 1)[0]
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[st]
+                val = (st, list(struct.unpack_from("<%d%s" % (cnt, fmt), r, q + 5)))
+                q += 5 + cnt * struct.calcsize(fmt)
             else:
                 raise ValueError("tag type " + ty)
             tags.setdefault(key, []).append((ty, val))

@@ -78,20 +78,53 @@ def test_wild_records_every_tag_type(tmp_path):
         same(host, gpu)
 
 
-def test_gpu_reader_hands_over_what_the_host_reader_decides(tmp_path):
-    """A record with a second NM tag (an extra value in the host reader's batch) is not decoded on the card: the reader says so
-    (code 1000) before anything is reported, and the host reader takes the file."""
+def test_gpu_reader_hands_over_a_batch_not_the_file(tmp_path):
+    """Records with a second NM tag (an extra value in the host reader's batch) are not decoded on the card: the BATCH that holds
+    one goes through the host decoder (same columns, extra values included), the others stay on the card."""
     from tests.test_host_io import _wild_bam
     path = str(tmp_path / "wild.bam")
     _, extra = _wild_bam(path, 21, 3000)
     assert extra
-    b = hostio.BamFile(path, gpu=0)
-    with pytest.raises(IOError) as e:
-        list(b.batches(100_000))
-    assert "1000" in str(e.value)
-    b.close()
     host, _ = all_columns(path, 100_000)
-    assert len(host["flag"]) == 3000
+    assert len(host["flag"]) == 3000 and len(host["nm_extra_read"]) == len(extra)
+    b = hostio.BamFile(path, gpu=0)
+    got = [dict((k, np.array(v, copy=True)) for k, v in x.items() if isinstance(v, np.ndarray)) for x in b.batches(100_000)]
+    assert b.batches_handed_over == 1 and len(got) == 1
+    b.close()
+    same(host, got[0])
+    # one odd record at the END of a clean file: one batch of several is handed over
+    clean = str(tmp_path / "clean.bam")
+    hostio.synth_stream(clean, None, seed=11, n_reads=700_000, ref_names=["chr1", "chr2"], ref_lens=[4_000_000, 2_000_000])
+    from tests import pybam
+    import struct
+    raw = open(clean, "rb").read()
+    assert raw[-28:] == pybam._bgzf_block(b"")
+    name = b"odd\0"
+    body = struct.pack("<iiBBHHHiiii", 1, 1_999_000, len(name), 30, 4680, 1, 0, 4, -1, -1, 0) + name + struct.pack("<I", (4 << 4) | 0) + bytes([0x12, 0x48]) + bytes([30] * 4) + b"RGZnot_in_header\0"
+    odd = str(tmp_path / "odd.bam")
+    open(odd, "wb").write(raw[:-28] + pybam._bgzf_block(struct.pack("<i", len(body)) + body) + pybam._bgzf_block(b""))
+    host, _ = all_columns(odd, 250_000)
+    b = hostio.BamFile(odd, gpu=0)
+    got = [dict((k, np.array(v, copy=True)) for k, v in x.items() if isinstance(v, np.ndarray)) for x in b.batches(250_000)]
+    assert b.batches_handed_over == 1 and len(got) >= 3
+    assert ("not_in_header", 0) in b.lanes()
+    b.close()
+    same(host, {k: np.concatenate([c[k] for c in got]) for k in got[0]})
+    # through the program: the odd file costs about what the clean one does (one batch by the host's rules, not the file twice)
+    import os, subprocess, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = str(tmp_path / "r.fa")
+    from bamqc_amd import synth
+    hostio.write_fasta(fa, ["chr1", "chr2"], [synth.reference(11, 0, 4_000_000), synth.reference(11, 1, 2_000_000)])
+    wall = {}
+    for name, path in (("clean", clean), ("odd", odd), ("clean", clean), ("odd", odd)):
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(root, "bin", "bamqualcheck"), "-r", fa, "-o", str(tmp_path / (name + ".bamqc")), "-c", "chr1,chr2", path],
+                           env=dict(os.environ, BQC_GPU_DECODE="1", BQC_TIMING="1", BQC_NO_FORK="1"), capture_output=True, text=True)
+        wall[name] = min(wall.get(name, 1e9), time.perf_counter() - t0)
+        assert r.returncode == 0, r.stderr
+        assert "records decoded on the GPU" in r.stderr and ("1 batches held records" in r.stderr) == (name == "odd"), r.stderr
+    assert wall["odd"] < 1.25 * wall["clean"] + 0.05, wall
 
 
 def test_damaged_blocks_are_an_error_for_both_readers(tmp_path):
