@@ -26,7 +26,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -351,7 +353,7 @@ struct GpuBamReader::Impl {
     hipStream_t s = nullptr;    // the consumer's: walk, decode, copies
     hipStream_t ps = nullptr;   // the producer's: copies and inflate kernels of every run
     hipEvent_t ev = nullptr;    // blocking
-    FILE* f = nullptr;
+    int fd = -1;                // the file (pread from several threads)
     uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
     // a shard of the file (GpuBamReader::set_range): the producer reads from begin_off on and notes where the block at mark_off
     // lies in the uncompressed stream; behind it only small runs follow (the consumer wants the rest of one record)
@@ -403,10 +405,13 @@ struct GpuBamReader::Impl {
     {
         { std::lock_guard<std::mutex> lk(m); stop = true; }
         cv.notify_all();
+        { std::lock_guard<std::mutex> lk(rm); rstop = true; }
+        rcv.notify_all();
         if (producer.joinable()) producer.join();
+        for (std::thread& t : readers) if (t.joinable()) t.join();
         (void)hipSetDevice(device);
         if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
-        for (PinChunk& C : chunks) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) (void)hipHostFree(C.p); }
+        for (Slot& C : slots) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) (void)hipHostFree(C.p); }
         for (GbRun& R : runs) {
             if (R.ready) (void)hipEventDestroy(R.ready);
             if (R.copied) (void)hipEventDestroy(R.copied);
@@ -416,7 +421,7 @@ struct GpuBamReader::Impl {
         if (ev) (void)hipEventDestroy(ev);
         if (d_status) (void)hipFree(d_status);
         if (h_status) (void)hipHostFree(h_status);
-        if (f) fclose(f);
+        if (fd >= 0) close(fd);
     }
     bool sync() { return hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess; }
     // read-group ids -> lane index, column-wise: off[n] len[n] index[n] (again when a batch handed over to the host decoder has met
@@ -437,13 +442,31 @@ struct GpuBamReader::Impl {
         if (!blob.empty() && hipMemcpy(d_lane_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
         return hipMemcpy(d_lane_tab.p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     }
-    // page-locked chunks the file is read into (from the second run on)
-    struct PinChunk { uint8_t* p = nullptr; hipEvent_t done = nullptr; bool used = false; };
-    static const int kChunks = 2;
-    PinChunk chunks[kChunks];
+    // The file behind the first run comes through a RING of page-locked chunks filled by several reader threads (one thread's
+    // copy out of the page cache manages 8-9 GB/s, which a card that inflates 20+ GB/s of compressed input waits for): chunk i
+    // is the file's bytes [ring_base + i * chunk_bytes, + chunk_bytes); the producer parses them in order, copies the whole
+    // blocks to the card and gives the chunk back.  A block cut by a chunk's end is completed in the HEADROOM in front of the next
+    // chunk's bytes, so that a block is always contiguous.
+    struct Slot { uint8_t* p = nullptr; size_t len = 0; uint64_t index = UINT64_MAX; bool filled = false, used = false; hipEvent_t done = nullptr; };
+    static const int kSlots = 6, kReaders = 3;
+    static constexpr size_t kHeadroom = 1u << 17;
+    Slot slots[kSlots];
     size_t chunk_bytes = 16u << 20;
+    std::vector<std::thread> readers;
+    std::mutex rm;
+    std::condition_variable rcv;
+    uint64_t ring_base = 0;          // file offset of chunk 0 (set when the first run has been parsed)
+    bool ring_open = false;          // (under rm) ring_base is valid: the readers may start
+    uint64_t next_claim = 0;         // (under rm) next chunk a reader takes
+    uint64_t released = 0;           // (under rm) chunks below this one have been given back
+    uint64_t read_limit = UINT64_MAX; // (under rm) chunks that begin at or behind this file offset are not read (a shard: nothing far behind its end)
+    bool rstop = false;              // (under rm)
+    uint64_t ring_i = 0;             // (producer) the chunk being parsed ...
+    size_t ring_at = kHeadroom;      // ... and the first unparsed byte in its slot buffer (below kHeadroom: a block's head, carried over)
+    void reader_loop();
+    Slot* wait_chunk(uint64_t i);
+    bool release_chunk(uint64_t i, hipStream_t st);
     size_t kMaxRunOut = (size_t)3200 << 20; // uncompressed bytes of a run (BQC_GB_MAX_RUN_OUT_MB: tests)
-    int chunk_i = 0;
     raw_vector<uint8_t> first_raw; // the first run: read while the device is still starting
     bool dev_ready = false;        // (under m) streams and buffers exist: the producer may touch the device
     bool kernels_ok = false;       // (under m) GpuBamReader::allow_kernels(): the first inflate kernel may be launched
@@ -475,12 +498,10 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.timing = getenv("BQC_GB_TIMING") != nullptr;
     if (const char* e = getenv("BQC_GB_RUN_MB")) I.run_bytes = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("BQC_GB_MAX_RUN_OUT_MB")) I.kMaxRunOut = (size_t)std::max(1, atoi(e)) << 20;
-    I.f = fopen(path, "rb");
-    if (!I.f) { err = std::string("could not open ") + path; return false; }
-    setvbuf(I.f, nullptr, _IONBF, 0);
+    I.fd = ::open(path, O_RDONLY);
+    if (I.fd < 0) { err = std::string("could not open ") + path; return false; }
     if (ranged_) {
         I.begin_off = range_b0_; I.mark_off = range_b1_;
-        if (I.begin_off && fseeko(I.f, (off_t)I.begin_off, SEEK_SET) != 0) { err = std::string("could not seek in ") + path; return false; }
         I.need_locate = I.begin_off != 0;
         if (I.begin_off) first_record_u = 0; // (the header lies in the first shard)
     }
@@ -497,7 +518,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         // for what this file can need: a 20 GB set-up is 20 GB to hand back when the process ends.
         {
             struct stat st;
-            if (fstat(fileno(I.f), &st) == 0 && st.st_size > 0) {
+            if (fstat(I.fd, &st) == 0 && st.st_size > 0) {
                 const uint64_t upto = std::min<uint64_t>((uint64_t)st.st_size, I.mark_off == UINT64_MAX ? UINT64_MAX : I.mark_off + Impl::kBeyond + (1u << 17));
                 I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)(upto > I.begin_off ? upto - I.begin_off : 0) + (1u << 20));
             }
@@ -540,10 +561,11 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
     }
     const double t_s2 = now_s();
-    for (Impl::PinChunk& C : I.chunks) {
-        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, I.chunk_bytes + (1u << 17), hipHostMallocDefault);
+    for (Impl::Slot& C : I.slots) {
+        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostMallocDefault);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
     }
+    for (int t = 0; t < Impl::kReaders; ++t) I.readers.emplace_back([&I] { I.reader_loop(); }); // (they wait for the first run to be parsed)
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
     if (!I.upload_lanes(hdr)) { err = "GPU reader: out of device memory"; return false; }
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
@@ -630,9 +652,67 @@ bool GpuBamReader::Impl::wait_ready()
     return hipSetDevice(device) == hipSuccess;
 }
 
+// A reader of the chunk ring: takes the next chunk index, waits until its slot has been given back (and the card has copied what
+// it held), reads the chunk's bytes of the file.
+void GpuBamReader::Impl::reader_loop()
+{
+    bool dev_set = false;
+    for (;;) {
+        uint64_t i;
+        {
+            std::unique_lock<std::mutex> lk(rm);
+            rcv.wait(lk, [&] { return rstop || (ring_open && next_claim < released + (uint64_t)kSlots && ring_base + next_claim * chunk_bytes < read_limit); });
+            if (rstop) return;
+            i = next_claim++;
+        }
+        Slot& S = slots[i % kSlots];
+        if (S.used) { // (the copy of the chunk this slot held before)
+            if (!dev_set) { (void)hipSetDevice(device); dev_set = true; }
+            (void)hipEventSynchronize(S.done);
+        }
+        const uint64_t at = ring_base + i * chunk_bytes;
+        size_t got = 0;
+        const double t0 = now_s();
+        while (got < chunk_bytes) {
+            const ssize_t k = pread(fd, S.p + kHeadroom + got, chunk_bytes - got, (off_t)(at + got));
+            if (k < 0) { if (errno == EINTR) continue; break; } // (a read error shows as a short chunk: "truncated BGZF file")
+            if (k == 0) break;
+            got += (size_t)k;
+        }
+        {
+            std::lock_guard<std::mutex> lk(rm);
+            t_read += now_s() - t0;
+            S.len = got; S.index = i; S.filled = true;
+        }
+        rcv.notify_all();
+    }
+}
+
+GpuBamReader::Impl::Slot* GpuBamReader::Impl::wait_chunk(uint64_t i)
+{
+    Slot& S = slots[i % kSlots];
+    std::unique_lock<std::mutex> lk(rm);
+    rcv.wait(lk, [&] { return rstop || (S.filled && S.index == i); });
+    return rstop ? nullptr : &S;
+}
+
+// the producer is done with chunk i: its slot may be read into again once the copies queued on `st` so far have run
+bool GpuBamReader::Impl::release_chunk(uint64_t i, hipStream_t st)
+{
+    Slot& S = slots[i % kSlots];
+    if (hipEventRecord(S.done, st) != hipSuccess) return false;
+    {
+        std::lock_guard<std::mutex> lk(rm);
+        S.used = true; S.filled = false;
+        released = i + 1;
+    }
+    rcv.notify_all();
+    return true;
+}
+
 // Reads the next run of whole BGZF blocks and starts its inflation.  The first run is read before the device is up (into pageable
-// memory, copied staged); the others go through page-locked chunks, the read of one overlapping the copy of the one before.
-// A shard's run stops kBeyond bytes behind its end block, and nothing is read that no run will want.
+// memory, by the reader threads' worth of plain threads, copied staged); the others come through the chunk ring.  A shard's run
+// stops kBeyond bytes behind its end block, and no chunk is read that begins behind what a run can want.
 void GpuBamReader::Impl::fill_run(GbRun& R)
 {
     R.rc = 1; R.final = false; R.utotal = 0; R.err.clear();
@@ -641,33 +721,58 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     hipError_t he = hipSuccess;
     const uint64_t stop_at = stop_off();
     bool stopped = false;
-    // bytes of the file this run may still read: up to the last block that can start before `stop`
-    auto may_read = [&](size_t want) -> size_t {
-        if (stop_at == UINT64_MAX) return want;
-        const uint64_t upto = stop_at + (1u << 17);
-        return upto > read_off ? (size_t)std::min<uint64_t>(want, upto - read_off) : 0;
-    };
     if (produced == 0) {
         // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
         static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)640 << 20;
-        const size_t piece = 32u << 20, cap = may_read(std::min<size_t>(run_bytes, first_cap));
+        const size_t piece = 32u << 20;
+        size_t cap = std::min<size_t>(run_bytes, first_cap);
+        if (stop_at != UINT64_MAX) cap = (size_t)std::min<uint64_t>(cap, stop_at + (1u << 17) - begin_off);
         first_raw.resize(cap + 64);
-        size_t got = 0;
-        for (;;) {
-            const size_t want = std::min(piece, cap - got);
-            const double t0 = now_s();
-            const size_t g = want ? fread(first_raw.data() + got, 1, want, f) : 0;
-            t_read += now_s() - t0;
-            got += g; read_off += g;
-            if (g < want) { file_eof = true; break; }
-            if (got >= cap) break;
-            if (got >= (64u << 20)) { std::lock_guard<std::mutex> lk(m); if (dev_ready || stop) break; }
+        const size_t n_pieces = (cap + piece - 1) / piece;
+        std::atomic<size_t> next_piece{0};
+        std::vector<size_t> got_of(n_pieces, 0);
+        const double t0 = now_s();
+        auto read_pieces = [&]() {
+            for (;;) {
+                const size_t k = next_piece.load();
+                if (k >= n_pieces) return;
+                if (k * piece >= (64u << 20)) { std::lock_guard<std::mutex> lk(m); if (dev_ready || stop) return; }
+                size_t mine = k;
+                if (!next_piece.compare_exchange_strong(mine, k + 1)) continue;
+                const size_t want = std::min(piece, cap - k * piece);
+                size_t g = 0;
+                while (g < want) {
+                    const ssize_t r = pread(fd, first_raw.data() + k * piece + g, want - g, (off_t)(begin_off + k * piece + g));
+                    if (r < 0) { if (errno == EINTR) continue; break; }
+                    if (r == 0) break;
+                    g += (size_t)r;
+                }
+                got_of[k] = g;
+                if (g < want) { next_piece = n_pieces; return; } // the file ends here
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < kReaders; ++t) th.emplace_back(read_pieces);
+            read_pieces();
+            for (std::thread& t : th) t.join();
         }
+        size_t got = 0;
+        for (size_t k = 0; k < n_pieces; ++k) { got += got_of[k]; if (got_of[k] < std::min(piece, cap - k * piece)) break; }
+        t_read += now_s() - t0;
+        if (got < cap) file_eof = true;
         const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal, stop_at, stopped);
         if (p == SIZE_MAX) { R.rc = -1; return; }
-        if (file_eof && !stopped && p != got && got - p < 65536 + 64 && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        if (file_eof && !stopped && p != got && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
         parsed_off += p;
-        tail.assign(first_raw.data() + p, first_raw.data() + got);
+        file_eof = file_eof && p == got; // (what the first run has left over is read again, through the ring)
+        { // the ring starts at the first byte no run has taken
+            std::lock_guard<std::mutex> lk(rm);
+            ring_base = parsed_off;
+            ring_open = true;
+            read_limit = stop_at == UINT64_MAX ? UINT64_MAX : stop_off() + (1u << 17);
+        }
+        rcv.notify_all();
         if (!wait_ready()) { R.rc = -2; return; }
         if (!R.d_comp.need(p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
@@ -678,40 +783,37 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         // (no-ops for the two buffers open() has allocated; the third one is allocated here, whole: the chunks are copied in as they are read)
         if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(head + run_bytes / 5 * 18 + 64, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
-        while (he == hipSuccess && !stopped && d_off < run_bytes && utotal + 65536 <= kMaxRunOut && !(file_eof && tail.empty())) {
-            PinChunk& C = chunks[chunk_i++ % kChunks];
-            if (C.used && hipEventSynchronize(C.done) != hipSuccess) { R.rc = -2; return; }
-            // the chunk: what the run before left over (a partial block; a lot only when that run stopped at its size limit), then the file
-            const size_t carried = std::min(tail.size(), chunk_bytes + (1u << 16));
-            if (carried) memcpy(C.p, tail.data(), carried);
-            const bool tail_only = carried < tail.size() || carried > (1u << 16);
-            tail.erase(tail.begin(), tail.begin() + carried); // (what did not fit stays, in order, for the next chunk)
-            const bool more_tail = !tail.empty();
-            size_t got = 0;
-            if (!file_eof && !tail_only) {
-                const size_t want = may_read(chunk_bytes);
-                const double t0 = now_s();
-                got = want ? fread(C.p + carried, 1, want, f) : 0;
-                t_read += now_s() - t0;
-                read_off += got;
-                if (got < want) file_eof = true;
-            }
-            const size_t have = carried + got;
-            const size_t p = parse_blocks(R, C.p, have, d_off, nb, utotal, stop_at, stopped);
+        if (stop_at != UINT64_MAX) { // the readers may go as far as this run can want
+            { std::lock_guard<std::mutex> lk(rm); read_limit = std::max(read_limit, stop_at + (1u << 17)); }
+            rcv.notify_all();
+        }
+        while (he == hipSuccess && !stopped && !file_eof && d_off < run_bytes && utotal + 65536 <= kMaxRunOut) {
+            Slot* S = wait_chunk(ring_i);
+            if (!S) { R.rc = -2; return; }
+            const size_t have = kHeadroom + S->len - ring_at;
+            const size_t p = parse_blocks(R, S->p + ring_at, have, d_off, nb, utotal, stop_at, stopped);
             if (p == SIZE_MAX) { R.rc = -1; return; }
-            const bool stopped_for_size = utotal + 65536 > kMaxRunOut;
-            if (file_eof && tail.empty() && p != have && !stopped_for_size && !stopped) { R.err = "truncated BGZF file"; R.rc = -1; return; }
-            parsed_off += p;
-            tail.insert(tail.begin(), C.p + p, C.p + have);
             if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
-            if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, C.p, p, hipMemcpyHostToDevice, R.s);
-            if (he == hipSuccess) he = hipEventRecord(C.done, R.s);
-            C.used = true;
-            d_off += p;
-            if (p == 0 && got == 0 && !more_tail) break; // (no progress is possible: nothing parsed, nothing read, nothing left over to add)
+            if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, S->p + ring_at, p, hipMemcpyHostToDevice, R.s);
+            if (he != hipSuccess) break;
+            d_off += p; parsed_off += p; ring_at += p;
+            if (stopped || utotal + 65536 > kMaxRunOut) break; // (the rest of this chunk is the next run's)
+            const size_t rem = kHeadroom + S->len - ring_at; // a block cut by the chunk's end (or nothing)
+            if (S->len < chunk_bytes) { // the file ends in this chunk
+                if (rem) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+                file_eof = true;
+                break;
+            }
+            if (rem > kHeadroom) { R.err = "corrupt BGZF block (larger than 64 KiB)"; R.rc = -1; return; }
+            Slot* N = wait_chunk(ring_i + 1);
+            if (!N) { R.rc = -2; return; }
+            if (rem) memcpy(N->p + kHeadroom - rem, S->p + ring_at, rem);
+            if (!release_chunk(ring_i, R.s)) { R.rc = -2; return; }
+            ++ring_i;
+            ring_at = kHeadroom - rem;
         }
     }
-    R.final = file_eof && tail.empty();
+    R.final = file_eof;
     R.utotal = utotal;
     u_produced += utotal;
     if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1))) { R.rc = -2; return; }

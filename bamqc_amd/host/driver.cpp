@@ -50,122 +50,138 @@ static inline uint8_t dna5_of_char(char c)
     }
 }
 
-// Loads every record; the id is cut at the first space or tab (TripletCounting.hpp:99-102).
-// `want` (optional) limits which sequences are kept in memory; all records keep their FASTA position.
-// An uncompressed FASTA file is mapped and parsed by all host threads (a human genome is 3 GB of text: 2.2 s on one thread):
-// header lines are found first ('>' outside a header line, in parallel; a few thousand at most), then the sequence between two
-// headers is counted (bytes other than '\n' / '\r') and encoded chunk by chunk straight into the record's array.  Same rules as
-// the sequential loader below.  1: loaded, 0: not this kind of file (compressed, a pipe, empty), -1: error.
+// An uncompressed FASTA file, mapped: where its records are (header lines found by all host threads: '>' outside a header line; a
+// few thousand at most), and any record's sequence as Dna5 codes on demand — counted (bytes other than '\n' / '\r') and encoded
+// chunk by chunk straight into the record's array by all host threads (a human genome is 3 GB of text: 2.2 s on one thread).
+// The id is cut at the first space or tab (TripletCounting.hpp:99-102).  Same rules as the sequential loader below.
+struct MappedFasta {
+    struct Rec { std::string name; size_t lo, hi; }; // [lo, hi): the record's sequence lines in the file
+    std::vector<Rec> recs;
+    const char* m = nullptr;
+    size_t size = 0;
+    ~MappedFasta() { if (m) munmap((void*)m, size); }
+    MappedFasta() = default;
+    MappedFasta(const MappedFasta&) = delete;
+    MappedFasta& operator=(const MappedFasta&) = delete;
+    // 1: indexed, 0: not this kind of file (compressed, a pipe, empty)
+    int open(const char* path)
+    {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return 0;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) { close(fd); return 0; }
+        size = (size_t)st.st_size;
+        void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (mp == MAP_FAILED) { size = 0; return 0; }
+        m = (const char*)mp;
+        if ((uint8_t)m[0] == 0x1f && (uint8_t)m[1] == 0x8b) return 0; // gzip: the sequential loader inflates it
+        (void)madvise(mp, size, MADV_WILLNEED);
+        const unsigned nt = bqc_host_threads();
+        // 1. every '>' of the file
+        const size_t n_chunks = std::max<size_t>(1, std::min<size_t>((size + (1u << 20) - 1) >> 20, (size_t)nt * 4));
+        std::vector<std::vector<size_t>> gts(n_chunks);
+        parallel_ranges(n_chunks, nt, 1, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t c = lo; c < hi; ++c) {
+                const char* p = m + size * c / n_chunks;
+                const char* const e = m + size * (c + 1) / n_chunks;
+                while (p < e) {
+                    const char* g = (const char*)memchr(p, '>', (size_t)(e - p));
+                    if (!g) break;
+                    gts[c].push_back((size_t)(g - m));
+                    p = g + 1;
+                }
+            }
+        });
+        // 2. those outside a header line start one; the line ends at the next '\n' (or with the file)
+        struct Hdr { size_t gt, nl; };
+        std::vector<Hdr> hdrs;
+        size_t limit = 0;
+        for (const auto& v : gts)
+            for (size_t g : v) {
+                if (g < limit) continue;
+                const char* nl = (const char*)memchr(m + g, '\n', size - g);
+                const size_t e = nl ? (size_t)(nl - m) : size;
+                hdrs.push_back(Hdr{g, e});
+                limit = e + 1;
+            }
+        recs.reserve(hdrs.size());
+        for (size_t i = 0; i < hdrs.size(); ++i) {
+            std::string hdr(m + hdrs[i].gt + 1, hdrs[i].nl - hdrs[i].gt - 1);
+            const size_t cut = hdr.find_first_of(" \t");
+            std::string name = hdr.substr(0, cut);
+            if (!name.empty() && name.back() == '\r') name.pop_back();
+            recs.push_back(Rec{name, std::min(size, hdrs[i].nl + 1), i + 1 < hdrs.size() ? hdrs[i + 1].gt : size});
+        }
+        return 1;
+    }
+    // the sequences of the records `which` (indices into recs), encoded together by all host threads; false: out of memory
+    bool encode(const std::vector<size_t>& which, std::vector<raw_vector<uint8_t>*> const& out) const
+    {
+        const unsigned nt = bqc_host_threads();
+        struct Task { size_t k, lo, hi, count, at; };
+        std::vector<Task> tasks;
+        const size_t kTask = 4u << 20;
+        for (size_t k = 0; k < which.size(); ++k)
+            for (size_t a = recs[which[k]].lo; a < recs[which[k]].hi; a += kTask) tasks.push_back(Task{k, a, std::min(recs[which[k]].hi, a + kTask), 0, 0});
+        parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; ++t) {
+                size_t n = 0;
+                for (const char* q = m + tasks[t].lo; q < m + tasks[t].hi; ++q) n += (*q != '\n') & (*q != '\r');
+                tasks[t].count = n;
+            }
+        });
+        std::vector<size_t> total(which.size(), 0);
+        for (auto& t : tasks) { t.at = total[t.k]; total[t.k] += t.count; }
+        try {
+            for (size_t k = 0; k < which.size(); ++k) { out[k]->clear(); if (total[k]) { out[k]->resize(total[k]); advise_huge(*out[k]); } }
+        } catch (const std::bad_alloc&) { return false; }
+        uint8_t lut[256];
+        for (int i = 0; i < 256; ++i) lut[i] = dna5_of_char((char)i);
+        parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; ++t) {
+                uint8_t* w = out[tasks[t].k]->data() + tasks[t].at;
+                const char* q = m + tasks[t].lo;
+                const char* const hi_q = m + tasks[t].hi;
+                while (q < hi_q) { // line by line: a run without '\n' is translated as a whole; a '\r' inside it (rare) takes the byte-wise path
+                    const char* nl = (const char*)memchr(q, '\n', (size_t)(hi_q - q));
+                    const char* const e = nl ? nl : hi_q;
+                    const size_t n = (size_t)(e - q);
+                    if (n && memchr(q, '\r', n)) {
+                        for (size_t i = 0; i < n; ++i) if (q[i] != '\r') *w++ = lut[(uint8_t)q[i]];
+                    } else {
+                        for (size_t i = 0; i < n; ++i) w[i] = lut[(uint8_t)q[i]];
+                        w += n;
+                    }
+                    q = e + 1;
+                }
+            }
+        });
+        return true;
+    }
+};
+
+// Loads every record (`want`, optional, limits which sequences are kept in memory; all records keep their FASTA position) of a
+// mapped file.  1: loaded, 0: not this kind of file (compressed, a pipe, empty), -1: error.
 static int load_fasta_mapped(const char* path, const std::vector<std::string>* want, std::vector<FastaRecord>& out)
 {
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return 0;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) { close(fd); return 0; }
-    const size_t size = (size_t)st.st_size;
-    void* mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (mp == MAP_FAILED) return 0;
-    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{mp, size};
-    const char* const m = (const char*)mp;
-    if ((uint8_t)m[0] == 0x1f && (uint8_t)m[1] == 0x8b) return 0; // gzip: the sequential loader inflates it
-    (void)madvise(mp, size, MADV_WILLNEED);
-    const unsigned nt = bqc_host_threads();
-    const bool ft = getenv("BQC_FASTA_TIMING") != nullptr;
-    auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!ft) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[fasta] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
-        tp = now;
-    };
-    // 1. every '>' of the file
-    const size_t n_chunks = std::max<size_t>(1, std::min<size_t>((size + (1u << 20) - 1) >> 20, (size_t)nt * 4));
-    std::vector<std::vector<size_t>> gts(n_chunks);
-    parallel_ranges(n_chunks, nt, 1, [&](unsigned, size_t lo, size_t hi) {
-        for (size_t c = lo; c < hi; ++c) {
-            const char* p = m + size * c / n_chunks;
-            const char* const e = m + size * (c + 1) / n_chunks;
-            while (p < e) {
-                const char* g = (const char*)memchr(p, '>', (size_t)(e - p));
-                if (!g) break;
-                gts[c].push_back((size_t)(g - m));
-                p = g + 1;
-            }
-        }
-    });
-    lap("find '>'");
-    // 2. those outside a header line start one; the line ends at the next '\n' (or with the file)
-    struct Hdr { size_t gt, nl; };
-    std::vector<Hdr> hdrs;
-    size_t limit = 0;
-    for (const auto& v : gts)
-        for (size_t g : v) {
-            if (g < limit) continue;
-            const char* nl = (const char*)memchr(m + g, '\n', size - g);
-            const size_t e = nl ? (size_t)(nl - m) : size;
-            hdrs.push_back(Hdr{g, e});
-            limit = e + 1;
-        }
-    // 3. records; the sequence of the kept ones is cut into tasks
-    struct Task { size_t rec, lo, hi, count, at; };
-    std::vector<Task> tasks;
+    MappedFasta mf;
+    if (mf.open(path) != 1) return 0;
     out.clear();
-    out.reserve(hdrs.size());
-    const size_t kTask = 4u << 20;
-    for (size_t i = 0; i < hdrs.size(); ++i) {
-        std::string hdr(m + hdrs[i].gt + 1, hdrs[i].nl - hdrs[i].gt - 1);
-        const size_t cut = hdr.find_first_of(" \t");
-        std::string name = hdr.substr(0, cut);
-        if (!name.empty() && name.back() == '\r') name.pop_back();
+    out.reserve(mf.recs.size());
+    std::vector<size_t> which;
+    for (size_t i = 0; i < mf.recs.size(); ++i) {
         bool keep = true;
         if (want) {
             keep = false;
-            for (const auto& w : *want) if (w == name) { keep = true; break; }
+            for (const auto& w : *want) if (w == mf.recs[i].name) { keep = true; break; }
         }
-        out.push_back(FastaRecord{name, {}});
-        const size_t lo = std::min(size, hdrs[i].nl + 1), hi = i + 1 < hdrs.size() ? hdrs[i + 1].gt : size;
-        if (keep)
-            for (size_t a = lo; a < hi; a += kTask) tasks.push_back(Task{i, a, std::min(hi, a + kTask), 0, 0});
+        out.push_back(FastaRecord{mf.recs[i].name, {}});
+        if (keep) which.push_back(i);
     }
-    // 4. count, place, encode
-    parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
-        for (size_t t = lo; t < hi; ++t) {
-            size_t n = 0;
-            for (const char* q = m + tasks[t].lo; q < m + tasks[t].hi; ++q) n += (*q != '\n') & (*q != '\r');
-            tasks[t].count = n;
-        }
-    });
-    lap("count");
-    std::vector<size_t> total(out.size(), 0);
-    for (auto& t : tasks) { t.at = total[t.rec]; total[t.rec] += t.count; }
-    try {
-        for (size_t i = 0; i < out.size(); ++i) if (total[i]) { out[i].codes.resize(total[i]); advise_huge(out[i].codes); }
-    } catch (const std::bad_alloc&) { return -1; }
-    lap("allocate");
-    uint8_t lut[256];
-    for (int i = 0; i < 256; ++i) lut[i] = dna5_of_char((char)i);
-    parallel_ranges(tasks.size(), nt, 1, [&](unsigned, size_t lo, size_t hi) {
-        for (size_t t = lo; t < hi; ++t) {
-            uint8_t* w = out[tasks[t].rec].codes.data() + tasks[t].at;
-            const char* q = m + tasks[t].lo;
-            const char* const hi_q = m + tasks[t].hi;
-            while (q < hi_q) { // line by line: a run without '\n' is translated as a whole; a '\r' inside it (rare) takes the byte-wise path
-                const char* nl = (const char*)memchr(q, '\n', (size_t)(hi_q - q));
-                const char* const e = nl ? nl : hi_q;
-                const size_t n = (size_t)(e - q);
-                if (n && memchr(q, '\r', n)) {
-                    for (size_t i = 0; i < n; ++i) if (q[i] != '\r') *w++ = lut[(uint8_t)q[i]];
-                } else {
-                    for (size_t i = 0; i < n; ++i) w[i] = lut[(uint8_t)q[i]];
-                    w += n;
-                }
-                q = e + 1;
-            }
-        }
-    });
-    lap("encode");
-    return 1;
+    std::vector<raw_vector<uint8_t>*> dst;
+    for (size_t i : which) dst.push_back(&out[i].codes);
+    return mf.encode(which, dst) ? 1 : -1;
 }
 
 static bool load_fasta(const char* path, const std::vector<std::string>* want, std::vector<FastaRecord>& out, std::string& err)
@@ -942,9 +958,15 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         t_c_warm = secs(c0, c1); t_c_reader = secs(c1, c2); t_c_create = secs(c2, clk::now());
     });
     // reference genome: all contigs that are BAM references, FASTA order kept for the cursor rule
+    // One of several processes over a file needs the contigs ITS records lie on, not the genome: the FASTA file is only indexed
+    // here (where its records are), and a contig is encoded and uploaded when the first batch with a read on it arrives
+    // (ensure_refs below) — eight workers parsing 3 GB of text each on shared host cores would cost more than their record loops.
     std::vector<FastaRecord> fa;
     std::string ferr;
-    if (!load_fasta(opt.referenceFile.c_str(), &H.ref_names, fa, ferr)) fprintf(stderr, "%s\n", ferr.c_str()); // return value ignored (:291)
+    MappedFasta lazy_fa;
+    const bool lazy_refs = shard && !(getenv("BQC_EAGER_REFS") && getenv("BQC_EAGER_REFS")[0] == '1') && lazy_fa.open(opt.referenceFile.c_str()) == 1;
+    if (lazy_refs) { for (const auto& r : lazy_fa.recs) fa.push_back(FastaRecord{r.name, {}}); }
+    else if (!load_fasta(opt.referenceFile.c_str(), &H.ref_names, fa, ferr)) fprintf(stderr, "%s\n", ferr.c_str()); // return value ignored (:291)
     std::vector<int32_t> fasta_index(std::max(1u, n_refs), -1);
     for (uint32_t r = 0; r < n_refs; ++r)
         for (size_t i = 0; i < fa.size(); ++i) if (fa[i].name == H.ref_names[r]) { fasta_index[r] = (int32_t)i; break; }
@@ -954,13 +976,41 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     const auto t_create = clk::now();
     if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return shard_abort(); }
     if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
-    for (uint32_t r = 0; r < n_refs; ++r)
+    std::vector<uint8_t> ref_loaded(std::max(1u, n_refs), 0);
+    for (uint32_t r = 0; r < n_refs && !lazy_refs; ++r)
         if (fasta_index[r] >= 0) {
             const auto& c = fa[fasta_index[r]].codes;
             if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
+            ref_loaded[r] = 1;
         }
     fa.clear();
     fa.shrink_to_fit();
+    double t_lazy_refs = 0;
+    uint32_t n_lazy_refs = 0;
+    auto ensure_refs = [&](const HostBatch& hb) -> int { // (lazy_refs) the contigs this batch's reads lie on are on the card before it is submitted
+        std::vector<size_t> which;
+        std::vector<uint32_t> rids;
+        int32_t last = -1;
+        for (int32_t rid : hb.rid) {
+            if (rid == last || rid < 0 || (uint32_t)rid >= n_refs) continue;
+            last = rid;
+            if (ref_loaded[rid] || fasta_index[rid] < 0) continue;
+            ref_loaded[rid] = 1;
+            which.push_back((size_t)fasta_index[rid]);
+            rids.push_back((uint32_t)rid);
+        }
+        if (which.empty()) return 0;
+        const auto l0 = clk::now();
+        std::vector<raw_vector<uint8_t>> codes(which.size());
+        std::vector<raw_vector<uint8_t>*> dst;
+        for (auto& c : codes) dst.push_back(&c);
+        if (!lazy_fa.encode(which, dst)) { fprintf(stderr, "ERROR: out of memory while loading %s\n", opt.referenceFile.c_str()); return 1; }
+        for (size_t k = 0; k < rids.size(); ++k)
+            if (bqc_set_reference(ctx, (int32_t)rids[k], codes[k].data(), codes[k].size())) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); return 1; }
+        t_lazy_refs += secs(l0, clk::now());
+        n_lazy_refs += (uint32_t)rids.size();
+        return 0;
+    };
     const auto t_setup = clk::now();
     since_launch("record loop starts");
 
@@ -1007,6 +1057,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
                 fwrite(out.data(), 1, out.size(), stderr);
             }
         }
+        if (lazy_refs && ensure_refs(*hb)) { status = 1; continue; }
         const bqc_batch v = hb->view();
         const auto s0 = clk::now();
         t_wait += secs(w0, s0);
@@ -1028,6 +1079,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
     if (timing) fprintf(stderr, "[timing] records decoded %s\n", use_gpu_reader ? "on the GPU (csrc/gpu_bam.hip)" : "on the host");
+    if (timing && lazy_refs) fprintf(stderr, "[timing] %u of %u contigs loaded, when their first reads arrived: %.3f s\n", n_lazy_refs, n_refs, t_lazy_refs);
     if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",

@@ -100,7 +100,7 @@ def test_gpu_reader_hands_over_a_batch_not_the_file(tmp_path):
     raw = open(clean, "rb").read()
     assert raw[-28:] == pybam._bgzf_block(b"")
     name = b"odd\0"
-    body = struct.pack("<iiBBHHHiiii", 1, 1_999_000, len(name), 30, 4680, 1, 0, 4, -1, -1, 0) + name + struct.pack("<I", (4 << 4) | 0) + bytes([0x12, 0x48]) + bytes([30] * 4) + b"RGZnot_in_header\0"
+    body = struct.pack("<iiBBHHHiiii", 1, 1_999_000, len(name), 30, 4680, 1, 0x41, 4, -1, -1, 0) + name + struct.pack("<I", (4 << 4) | 0) + bytes([0x12, 0x48]) + bytes([30] * 4) + b"RGZnot_in_header\0"
     odd = str(tmp_path / "odd.bam")
     open(odd, "wb").write(raw[:-28] + pybam._bgzf_block(struct.pack("<i", len(body)) + body) + pybam._bgzf_block(b""))
     host, _ = all_columns(odd, 250_000)
