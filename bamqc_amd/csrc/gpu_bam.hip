@@ -369,6 +369,7 @@ struct GpuBamReader::Impl {
     uint64_t stop_off() const { return mark_off == UINT64_MAX ? UINT64_MAX : (parsed_off < mark_off ? mark_off : parsed_off) + kBeyond; }
     size_t run_bytes = 832u << 20; // (an inflate launch costs 20-50 ms whatever the number of blocks: few, large runs; the first one is 64 MB)
     size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
+    size_t out_cap = 0;         // bytes of a run's output buffer (head included): set in open() before the producer starts
     static const int kRuns = 3; // one being walked, one being inflated, one being read
     GbRun runs[kRuns];
     // producer thread: file -> runs
@@ -472,7 +473,7 @@ struct GpuBamReader::Impl {
     bool kernels_ok = false;       // (under m) GpuBamReader::allow_kernels(): the first inflate kernel may be launched
     void produce();
     void fill_run(GbRun& R);
-    size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, bool& stopped);
+    size_t parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, size_t out_limit, bool& stopped);
     bool wait_ready();
     // the next run becomes the window (what is left of the current one goes in front of it); 1: done, 0: no more runs, -1 / -2: see GbRun::rc
     int advance(std::string& err);
@@ -508,6 +509,14 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.read_off = I.parsed_off = I.begin_off;
     I.skip_u = first_record_u;
     I.n_ref = (int32_t)hdr.ref_names.size();
+    { // (the sizes the producer works with are final before it starts)
+        struct stat st;
+        if (fstat(I.fd, &st) == 0 && st.st_size > 0) {
+            const uint64_t upto = std::min<uint64_t>((uint64_t)st.st_size, I.mark_off == UINT64_MAX ? UINT64_MAX : I.mark_off + Impl::kBeyond + (1u << 17));
+            I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)(upto > I.begin_off ? upto - I.begin_off : 0) + (1u << 20));
+        }
+        I.out_cap = I.head + I.run_bytes / 5 * 18 + 64;
+    }
     I.producer = std::thread([&I] { I.produce(); }); // reads the first run of the file while the device is set up below
     hipError_t he = hipSetDevice(device);
     const double t_open1 = now_s();
@@ -516,15 +525,8 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     {
         // (a run inflates to ~3.3 x its size with BGZF level 1-6 on BAM records; a run that needs more grows its buffer, once.)  Sized
         // for what this file can need: a 20 GB set-up is 20 GB to hand back when the process ends.
-        {
-            struct stat st;
-            if (fstat(I.fd, &st) == 0 && st.st_size > 0) {
-                const uint64_t upto = std::min<uint64_t>((uint64_t)st.st_size, I.mark_off == UINT64_MAX ? UINT64_MAX : I.mark_off + Impl::kBeyond + (1u << 17));
-                I.run_bytes = std::min<size_t>(I.run_bytes, (size_t)(upto > I.begin_off ? upto - I.begin_off : 0) + (1u << 20));
-            }
-        }
         const size_t reads0 = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
-        const size_t out_cap = I.head + I.run_bytes / 5 * 18 + 64, nb_cap = I.run_bytes / 2048;
+        const size_t out_cap = I.out_cap, nb_cap = I.run_bytes / 2048;
         const size_t seg_cap = std::min<size_t>(out_cap, std::min<size_t>(reads0 * 440, batch_bases * 2) + (8u << 20)) / GB_SEG + 2; // (a walk covers a batch's worth of the window)
         bool ok = true;
         const double t_a = now_s();
@@ -600,7 +602,7 @@ void GpuBamReader::Impl::produce()
 // reads the next run of whole BGZF blocks and starts its inflation (block headers: host/bgzf.cpp plan_run — same checks)
 // whole BGZF blocks of raw[0, have): appended to the run's block table (their deflate data will lie at d_off + ... in the run's
 // compressed buffer); returns the bytes they span, SIZE_MAX on a malformed stream (host/bgzf.cpp plan_run — same checks)
-size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, bool& stopped)
+size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t have, size_t d_off, size_t& nb, size_t& utotal, uint64_t stop_at, size_t out_limit, bool& stopped)
 {
     const size_t kMaxBlock = 65536;
     size_t p = 0;
@@ -630,7 +632,7 @@ size_t GpuBamReader::Impl::parse_blocks(GbRun& R, const uint8_t* raw, size_t hav
         const uint8_t* t = raw + p + bsize - 8;
         const size_t isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((size_t)t[7] << 24);
         if (isize > kMaxBlock) { R.err = "BGZF block larger than 64 KiB"; return SIZE_MAX; }
-        if (utotal + isize > kMaxRunOut) break; // (a window's offsets are 32-bit: the rest belongs to the next run)
+        if (utotal + isize > out_limit) break; // (a window's offsets are 32-bit, and the run's output buffer is what it is: the rest belongs to the next run)
         if (isize) {
             if (nb + 1 > R.hb.size()) { R.hb.resize(2 * nb + 1024); R.hc.resize(2 * nb + 1024); }
             R.hb[nb] = GiBlock{d_off + p + 12 + xlen, head + utotal, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)isize};
@@ -721,6 +723,9 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     hipError_t he = hipSuccess;
     const uint64_t stop_at = stop_off();
     bool stopped = false;
+    // A run ends where its output buffer does (sized in open() for 3.6 x the compressed bytes: a file that inflates further gets
+    // more, smaller runs — never a buffer released and allocated again behind a running kernel).
+    const size_t out_limit = std::min(kMaxRunOut, out_cap - head - 64);
     if (produced == 0) {
         // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
         static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)640 << 20;
@@ -761,9 +766,9 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         for (size_t k = 0; k < n_pieces; ++k) { got += got_of[k]; if (got_of[k] < std::min(piece, cap - k * piece)) break; }
         t_read += now_s() - t0;
         if (got < cap) file_eof = true;
-        const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal, stop_at, stopped);
+        const size_t p = parse_blocks(R, first_raw.data(), got, 0, nb, utotal, stop_at, out_limit, stopped);
         if (p == SIZE_MAX) { R.rc = -1; return; }
-        if (file_eof && !stopped && p != got && utotal + 65536 <= kMaxRunOut) { R.err = "truncated BGZF file"; R.rc = -1; return; }
+        if (file_eof && !stopped && p != got && utotal + 65536 <= out_limit) { R.err = "truncated BGZF file"; R.rc = -1; return; }
         parsed_off += p;
         file_eof = file_eof && p == got; // (what the first run has left over is read again, through the ring)
         { // the ring starts at the first byte no run has taken
@@ -781,23 +786,23 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     } else {
         if (!wait_ready()) { R.rc = -2; return; }
         // (no-ops for the two buffers open() has allocated; the third one is allocated here, whole: the chunks are copied in as they are read)
-        if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(head + run_bytes / 5 * 18 + 64, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
+        if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(out_cap, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
         if (stop_at != UINT64_MAX) { // the readers may go as far as this run can want
             { std::lock_guard<std::mutex> lk(rm); read_limit = std::max(read_limit, stop_at + (1u << 17)); }
             rcv.notify_all();
         }
-        while (he == hipSuccess && !stopped && !file_eof && d_off < run_bytes && utotal + 65536 <= kMaxRunOut) {
+        while (he == hipSuccess && !stopped && !file_eof && d_off < run_bytes && utotal + 65536 <= out_limit) {
             Slot* S = wait_chunk(ring_i);
             if (!S) { R.rc = -2; return; }
             const size_t have = kHeadroom + S->len - ring_at;
-            const size_t p = parse_blocks(R, S->p + ring_at, have, d_off, nb, utotal, stop_at, stopped);
+            const size_t p = parse_blocks(R, S->p + ring_at, have, d_off, nb, utotal, stop_at, out_limit, stopped);
             if (p == SIZE_MAX) { R.rc = -1; return; }
             if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
             if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, S->p + ring_at, p, hipMemcpyHostToDevice, R.s);
             if (he != hipSuccess) break;
             d_off += p; parsed_off += p; ring_at += p;
-            if (stopped || utotal + 65536 > kMaxRunOut) break; // (the rest of this chunk is the next run's)
+            if (stopped || utotal + 65536 > out_limit) break; // (the rest of this chunk is the next run's)
             const size_t rem = kHeadroom + S->len - ring_at; // a block cut by the chunk's end (or nothing)
             if (S->len < chunk_bytes) { // the file ends in this chunk
                 if (rem) { R.err = "truncated BGZF file"; R.rc = -1; return; }

@@ -1079,6 +1079,12 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
     if (timing) fprintf(stderr, "[timing] records decoded %s\n", use_gpu_reader ? "on the GPU (csrc/gpu_bam.hip)" : "on the host");
+    if (timing) { // (every buffer of the run exists at this point: what is in use now is the run's peak)
+        size_t free_b = 0, total_b = 0, pinned = 0;
+        { std::lock_guard<std::mutex> lk(g_pins.m); for (auto& kv : g_pins.blocks) pinned += kv.second; }
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            fprintf(stderr, "[timing] device memory in use at the end of the record loop: %.2f GB of %.0f GB; page-locked decode buffers %.2f GB\n", (total_b - free_b) / 1e9, total_b / 1e9, pinned / 1e9);
+    }
     if (timing && lazy_refs) fprintf(stderr, "[timing] %u of %u contigs loaded, when their first reads arrived: %.3f s\n", n_lazy_refs, n_refs, t_lazy_refs);
     if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)

@@ -26,7 +26,13 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(unsigned long l
 #define BFE(i) "v_bfe_u32 %" #i ", %" #i ", 1, 31\n"
 #define XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
 #define MUL(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
-#define ADD64(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define ADDE64(i) "v_add_u32_e64 %" #i ", %" #i ", %8\n"
+#define ADDLIT(i) "v_add_u32 %" #i ", 0x12345678, %" #i "\n"
+#define AND2(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define LSHL2(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x96\n"
+#define ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define CHAIN(i) "v_add_u32 %0, %0, %8\n"
         if (OP == 0) { EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) }
         if (OP == 1) { EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) }
         if (OP == 2) { EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) }
@@ -35,6 +41,11 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(unsigned long l
         if (OP == 5) { EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) EIGHT(BFE) }
         if (OP == 6) { EIGHT(XOR) EIGHT(ADD) EIGHT(PERM) EIGHT(ALIGN) EIGHT(ANDOR) EIGHT(LSHLADD) EIGHT(BFE) EIGHT(XOR) } // the mix of k_short's SWAR code
         if (OP == 7) { EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) EIGHT(MUL) }
+        if (OP == 8) { EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) EIGHT(ADDE64) }
+        if (OP == 9) { EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) }
+        if (OP == 10) { EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) }
+        if (OP == 11) { EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) }
+        if (OP == 12) { EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) } // one dependent chain: latency
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
@@ -93,6 +104,11 @@ int main(int argc, char** argv)
     run<5>("bfe_u32", n_cu, d_out, js, first);
     run<6>("swar_mix", n_cu, d_out, js, first);
     run<7>("mul_lo_u32", n_cu, d_out, js, first);
+    run<8>("add_e64", n_cu, d_out, js, first);
+    run<9>("add_literal", n_cu, d_out, js, first);
+    run<10>("and_lshl_vop2", n_cu, d_out, js, first);
+    run<11>("bitop3_add3", n_cu, d_out, js, first);
+    run<12>("add_chain", n_cu, d_out, js, first);
     fprintf(js, "\n]}\n");
     fclose(js);
     return 0;

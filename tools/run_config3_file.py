@@ -1,0 +1,104 @@
+"""BASELINE.json config 3 at full size as a FILE on one MI355X: ~618 M synthetic 150 bp PE reads (30x of 3.088 Gb) over chr1..chr22,
+chrX, chrY with GRCh38 lengths, written once at BGZF level 1 (~51 GB), then `bin/bamqualcheck` (default -c, default k-mer sketch)
+timed on it: reads/s, compressed GB/s in, the reader named, device memory in use.  Checked by the size-independent properties of
+tests/bamqc_text.py and by the first million reads of the same plan against the oracle, byte for byte.
+With --gpus-shared N also: the same file through `bamqualcheck --gpus N` with N workers sharing the one card (each inflates and
+decodes its byte range there; what a node with N cards does, minus the N cards).
+usage: python tools/run_config3_file.py [--reads N] [--level L] [--runs K] [--dir D] [--out J] [--keep] [--gpus-shared N]"""
+import argparse
+import filecmp
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bamqc_amd import hostio  # noqa: E402
+from bamqc_amd.synth import GRCH38  # noqa: E402
+from tests import bamqc_text  # noqa: E402
+from tests.test_gpu_stream import NAMES24, prefix_parity  # noqa: E402
+
+EXE = os.path.join(ROOT, "bin", "bamqualcheck")
+
+
+def timed_run(args, env_extra=None):
+    env = dict(os.environ, BQC_TIMING="1", BQC_T0="%.6f" % time.monotonic())
+    env.update(env_extra or {})
+    t0 = time.perf_counter()
+    r = subprocess.run([EXE] + args, capture_output=True, text=True, env=env)
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    return dt, r.stderr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=618_000_000)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--dir", default=None)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gpus-shared", type=int, default=0)
+    a = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="bqc_c3f_", dir=a.dir)
+    res = {"config": "3: 30x WGS-scale synthetic, 24 GRCh38-length contigs, default -c / -k 32 -q 17, as a FILE", "reads": a.reads, "bgzf_level": a.level}
+    try:
+        bam, fa = os.path.join(tmp, "c3.bam"), os.path.join(tmp, "c3.fa")
+        t0 = time.time()
+        hostio.synth_stream(bam, fa, 1003, a.reads, NAMES24, GRCH38, level=a.level)
+        res["write_input_s"] = time.time() - t0
+        size = os.path.getsize(bam)
+        res["bam_bytes"] = size
+        print("input written: %.1f GB in %.0f s" % (size / 1e9, res["write_input_s"]), flush=True)
+        runs = []
+        for k in range(a.runs):
+            out = os.path.join(tmp, "o%d.bamqc" % k)
+            time.sleep(2.0)
+            dt, err = timed_run(["-r", fa, "-o", out, bam])
+            m = re.search(r"record loop ([0-9.]+) s", err)
+            runs.append({"wall_s": dt, "reads_per_s": a.reads / dt, "compressed_GB_per_s": size / dt / 1e9, "record_loop_s": float(m.group(1)) if m else None,
+                         "reader": "gpu (inflate, CRC, record walk and column decode on the card)" if "records decoded on the GPU" in err else "host",
+                         "timing": [ln for ln in err.splitlines() if ln.startswith("[timing]")]})
+            print("run %d: %.2f s = %.1f M reads/s, %.2f GB/s of compressed input" % (k, dt, a.reads / dt / 1e6, size / dt / 1e9), flush=True)
+        assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "o%d.bamqc" % k), shallow=False) for k in range(1, a.runs))
+        lanes = bamqc_text.parse(os.path.join(tmp, "o0.bamqc"))
+        info = bamqc_text.check_invariants(lanes["L1"], n_records=a.reads, read_len=150)
+        cov = lanes["L1"]["genome_coverage_histogram"]
+        med = sorted(runs, key=lambda x: x["wall_s"])[len(runs) // 2]
+        res.update({"program_wall_s": med["wall_s"], "reads_per_s": med["reads_per_s"], "compressed_GB_per_s": med["compressed_GB_per_s"], "which": "median of %d runs" % a.runs,
+                    "reader": med["reader"], "runs": runs, "primary_reads": info["primary"], "triplets": info["triplets"], "eightmers": info["eightmers"],
+                    "coverage_positions": int(cov.sum()), "mean_depth_main": float((cov * range(101)).sum() / max(1, cov.sum())), "invariants": "ok"})
+        # the host reader on the same file, once (what the GPU reader replaced)
+        dt, err = timed_run(["-r", fa, "-o", os.path.join(tmp, "h.bamqc"), bam], {"BQC_GPU_DECODE": "0"})
+        res["host_reader"] = {"wall_s": dt, "reads_per_s": a.reads / dt, "identical_output": filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "h.bamqc"), shallow=False)}
+        print("host reader: %.2f s = %.1f M reads/s" % (dt, a.reads / dt / 1e6), flush=True)
+        if a.gpus_shared > 1:
+            shared = []
+            for n in sorted({2, a.gpus_shared}):
+                out = os.path.join(tmp, "g%d.bamqc" % n)
+                time.sleep(2.0)
+                dt, err = timed_run(["--gpus", str(n), "-r", fa, "-o", out, bam], {"BQC_GPUS_SHARE_DEVICE": "1"})
+                loops = [float(x) for x in re.findall(r"record loop ([0-9.]+) s", err)]
+                shared.append({"workers": n, "wall_s": dt, "reads_per_s": a.reads / dt, "record_loops_s": loops, "identical_output": filecmp.cmp(os.path.join(tmp, "o0.bamqc"), out, shallow=False),
+                               "what": "%d workers SHARING one card (BQC_GPUS_SHARE_DEVICE=1): each reads, inflates and decodes its byte range; sums through pipes" % n})
+                print("--gpus %d on one card: %.2f s, record loops %s" % (n, dt, loops), flush=True)
+            res["workers_sharing_one_card"] = shared
+        # the first million reads of the same plan against the oracle, byte for byte
+        prefix_parity(tmp, 1003, a.reads, min(a.reads, 1_000_000), NAMES24, GRCH38, ["-c", "chr1"], dict(chroms="chr1"))
+        res["prefix_1M_matches_oracle"] = True
+        print(json.dumps({k: v for k, v in res.items() if k != "runs"}, indent=1), flush=True)
+        if a.out:
+            json.dump(res, open(a.out, "w"), indent=1)
+    finally:
+        if not a.keep:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
