@@ -60,34 +60,89 @@ typedef uint32_t gi_u32x4 __attribute__((ext_vector_type(4)));
 typedef gi_u32x4 __attribute__((aligned(1))) gi_u32x4_u;
 
 namespace {
-struct Bits { // bit reader over [in, end): the word behind the buffered ones is always on its way (its latency hides behind the
-              // symbols decoded meanwhile); loads are clamped to `lim` (inside the compressed buffer), what was consumed is checked at the end
-    const uint8_t* in;  // address of the prefetched word `nw`
-    const uint8_t* lim; // last address a word may be loaded from
+typedef uint64_t __attribute__((aligned(1))) gi_u64_u;
+
+struct Bits { // bit reader over [in, end): the two words behind the buffered ones are always on their way (one 8-byte load per 64 bits of
+              // input; its latency hides behind the symbols decoded meanwhile); loads are clamped to `lim` (inside the compressed buffer),
+              // what was consumed is checked at the end
+    const uint8_t* in;  // address of the next prefetched word (the low half of `nw` while nwn == 2, else its high half)
+    const uint8_t* lim; // last address a load may start at
     uint64_t bb;
+    uint64_t nw;        // prefetched: nwn words of 32 bits, the next one in the low half
     uint32_t bc;
-    uint32_t nw;
+    uint32_t nwn;
     __device__ __forceinline__ void start(const uint8_t* p, const uint8_t* end)
     {
         lim = end + 4; // (the buffer holds at least 64 bytes behind the last block)
         bb = *(const gi_u32_u*)p | (uint64_t)(*(const gi_u32_u*)(p + 4)) << 32;
         bc = 64;
         in = p + 8;
-        nw = *(const gi_u32_u*)(in < lim ? in : lim);
+        nw = *(const gi_u64_u*)(in < lim ? in : lim);
+        nwn = 2;
     }
     __device__ __forceinline__ void refill()
     {
         if (bc <= 32u) {
-            bb |= (uint64_t)nw << bc;
+            bb |= (uint64_t)(uint32_t)nw << bc;
             bc += 32u;
             in += 4;
-            nw = *(const gi_u32_u*)(in < lim ? in : lim);
+            nw >>= 32;
+            if (--nwn == 0u) { nw = *(const gi_u64_u*)(in < lim ? in : lim); nwn = 2u; }
         }
     }
     __device__ __forceinline__ const uint8_t* byte_pos() const { return in - (bc >> 3); } // address of the first unconsumed byte (bc a multiple of 8)
     __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(uint32_t n) { bb >>= n; bc -= n; }
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+// The output side of a lane.  What limits these kernels once the card is full is the number of memory transactions: every lane
+// writes to its own block, so a wave's store is as many transactions as it has active lanes.  Literals are therefore gathered in
+// a register and stored eight at a time; a match of up to 16 bytes at a distance of 16 or more is one 16-byte load and one store
+// (most matches of a BGZF level-1 stream are short), longer ones 32 bytes per step, overlapping ones (distance < 16) word- or
+// byte-wise.  Stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
+struct Out {
+    uint8_t* o0;
+    uint32_t usize;
+    uint32_t o;      // bytes produced, pending literals included
+    uint32_t nlit;   // literals held in `lit` (0..7): the bytes o - nlit .. o - 1
+    uint64_t lit;
+    __device__ __forceinline__ void flush()
+    {
+        if (!nlit) return;
+        uint8_t* d = o0 + (o - nlit);
+        if (o - nlit + 8u <= usize) *(gi_u64_u*)d = lit;
+        else for (uint32_t k = 0; k < nlit; ++k) d[k] = (uint8_t)(lit >> (8u * k));
+        nlit = 0; lit = 0;
+    }
+    __device__ __forceinline__ void literal(uint32_t sym) // (the caller has checked o < usize)
+    {
+        lit |= (uint64_t)sym << (8u * nlit);
+        ++o;
+        if (++nlit == 8u) { *(gi_u64_u*)(o0 + (o - 8u)) = lit; nlit = 0; lit = 0; }
+    }
+    __device__ __forceinline__ void match(uint32_t length, uint32_t dist) // (the caller has checked dist <= o, o + length <= usize)
+    {
+        flush();
+        uint8_t* dst = o0 + o;
+        const uint8_t* src = dst - dist;
+        o += length;
+        if (dist >= 16u && length <= 16u && o - length + 16u <= usize) {
+            *(gi_u32x4_u*)dst = *(const gi_u32x4_u*)src;
+        } else if (dist >= 32u && o + 32u <= usize) { // 32 bytes at a time (both loads first); the overshoot stays inside this block's output
+            for (uint32_t k = 0; k < length; k += 32u) {
+                const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
+                *(gi_u32x4_u*)(dst + k) = a;
+                *(gi_u32x4_u*)(dst + k + 16) = b;
+            }
+        } else if (dist >= 16u && o + 16u <= usize) {
+            for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
+        } else if (dist >= 4u && o + 4u <= usize) {
+            for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
+        } else {
+            for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
+        }
+    }
 };
 
 template <int NL> __device__ __forceinline__ uint32_t lens_get(const uint16_t* L, uint32_t i) { const uint32_t v = L[GI_AT(GI_O_LENS + (i >> 2))]; return (v >> (4 * (i & 3))) & 15u; }
@@ -183,9 +238,9 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     const uint8_t* const cend = c0 + blk.csize;
     Bits B;
     B.start(c0, cend);
-    uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize;
-    uint32_t o = 0;
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull};
+    uint8_t* const o0 = O.o0;
     uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
     for (;;) {
         B.refill();
@@ -198,11 +253,12 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
             const uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
             if ((len ^ nlen) != 0xFFFFu) { st = GI_ERR_DATA; break; }
             p += 4;
-            if (p + len > cend || o + len > usize) { st = GI_ERR_TRUNC; break; }
+            if (p + len > cend || O.o + len > usize) { st = GI_ERR_TRUNC; break; }
+            O.flush();
             uint32_t k = 0;
-            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + o + k) = *(const gi_u32_u*)(p + k);
-            for (; k < len; ++k) o0[o + k] = p[k];
-            o += len;
+            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + O.o + k) = *(const gi_u32_u*)(p + k);
+            for (; k < len; ++k) o0[O.o + k] = p[k];
+            O.o += len;
             B.start(p + len, cend);
             if (bfinal) break;
             continue;
@@ -264,8 +320,8 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
             B.refill();
             const uint32_t sym = decode_sym<NL>(L, B, GI_O_LCNT, GI_O_LSYM, GI_O_LIT, GI_LIT_ROOT);
             if (sym < 256u) {
-                if (o >= usize) { st = GI_ERR_SIZE; break; }
-                o0[o++] = (uint8_t)sym;
+                if (O.o >= usize) { st = GI_ERR_SIZE; break; }
+                O.literal(sym);
                 continue;
             }
             if (sym == 256u) break;
@@ -281,27 +337,13 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
             B.refill();
             const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u; // distance symbols 0..3: 1..4; then pairs with 1..13 extra bits
             const uint32_t dist = (ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u) + B.take(de);
-            if (dist > o || o + length > usize) { st = dist > o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
-            uint8_t* dst = o0 + o;
-            const uint8_t* src = dst - dist;
-            o += length;
-            if (dist >= 32u && o + 32u <= usize) { // 32 bytes at a time (both loads first); the overshoot stays inside this block's output
-                for (uint32_t k = 0; k < length; k += 32u) {
-                    const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
-                    *(gi_u32x4_u*)(dst + k) = a;
-                    *(gi_u32x4_u*)(dst + k + 16) = b;
-                }
-            } else if (dist >= 16u && o + 16u <= usize) {
-                for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
-            } else if (dist >= 4u && o + 4u <= usize) {
-                for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
-            } else {
-                for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
-            }
+            if (dist > O.o || O.o + length > usize) { st = dist > O.o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
+            O.match(length, dist);
         }
         if (st || bfinal) break;
     }
-    if (!st && o != usize) st = GI_ERR_SIZE;
+    O.flush();
+    if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
     if (st) atomicOr(status, st);
 }
@@ -383,9 +425,9 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     const uint8_t* const cend = c0 + blk.csize;
     Bits B;
     B.start(c0, cend);
-    uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize;
-    uint32_t o = 0;
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull};
+    uint8_t* const o0 = O.o0;
     uint32_t st = 0;
     uint8_t lens[320]; // code lengths while the codes are built (private memory)
     for (;;) {
@@ -399,11 +441,12 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
             const uint32_t len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
             if ((len ^ nlen) != 0xFFFFu) { st = GI_ERR_DATA; break; }
             p += 4;
-            if (p + len > cend || o + len > usize) { st = GI_ERR_TRUNC; break; }
+            if (p + len > cend || O.o + len > usize) { st = GI_ERR_TRUNC; break; }
+            O.flush();
             uint32_t k = 0;
-            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + o + k) = *(const gi_u32_u*)(p + k);
-            for (; k < len; ++k) o0[o + k] = p[k];
-            o += len;
+            for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + O.o + k) = *(const gi_u32_u*)(p + k);
+            for (; k < len; ++k) o0[O.o + k] = p[k];
+            O.o += len;
             B.start(p + len, cend);
             if (bfinal) break;
             continue;
@@ -532,8 +575,8 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
             B.drop(cl);
             const uint32_t sym = (uint32_t)L[GL_AT(GL_LS + idx)] | (((uint32_t)L[GL_AT(GL_LB + (idx >> 3))] >> (idx & 7u)) & 1u) << 8;
             if (sym < 256u) {
-                if (o >= usize) { st = GI_ERR_SIZE; break; }
-                o0[o++] = (uint8_t)sym;
+                if (O.o >= usize) { st = GI_ERR_SIZE; break; }
+                O.literal(sym);
                 continue;
             }
             if (sym == 256u) break;
@@ -551,27 +594,13 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
             B.refill();
             const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
             const uint32_t dist = (ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u) + B.take(de);
-            if (dist > o || o + length > usize) { st = dist > o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
-            uint8_t* dst = o0 + o;
-            const uint8_t* src = dst - dist;
-            o += length;
-            if (dist >= 32u && o + 32u <= usize) {
-                for (uint32_t k = 0; k < length; k += 32u) {
-                    const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
-                    *(gi_u32x4_u*)(dst + k) = a;
-                    *(gi_u32x4_u*)(dst + k + 16) = b;
-                }
-            } else if (dist >= 16u && o + 16u <= usize) {
-                for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
-            } else if (dist >= 4u && o + 4u <= usize) {
-                for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
-            } else {
-                for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
-            }
+            if (dist > O.o || O.o + length > usize) { st = dist > O.o ? GI_ERR_DATA : GI_ERR_SIZE; break; }
+            O.match(length, dist);
         }
         if (st || bfinal) break;
     }
-    if (!st && o != usize) st = GI_ERR_SIZE;
+    O.flush();
+    if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
     if (st) atomicOr(status, st);
 }
