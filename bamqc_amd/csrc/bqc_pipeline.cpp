@@ -213,6 +213,43 @@ static int host_pass(bqc_ctx* c, const bqc_batch* b, HostPass& H)
     H.n_pending = 0;
     const uint32_t n_refs = c->opt.n_refs;
     const uint8_t* main_chrom = c->main_chrom.data();
+    if (!set_aside) {
+        // The common case, kept tight — this loop is the one serial pass over every read of the run (the submitting thread's time is what
+        // bounds a whole-genome file once the card reads and inflates it): raw pointers, the read group's state in locals when there is
+        // one read group, the window list touched only when the window changes.
+        const uint16_t* const flags = b->flag;
+        const uint8_t* const lanes = b->lane;
+        const int32_t* const rids = b->rid;
+        const int32_t* const poss = b->pos;
+        CovEntry* const out = H.cov.data();
+        LaneCov* const cov = c->cov.data();
+        std::vector<uint32_t>* const lane_first = H.lane_first.data();
+        uint32_t* const last_rel = plan.last_rel.data();
+        LaneCov local = cov[0];
+        const bool one = nl == 1;
+        bool too_many = false;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t flag = flags[i], lane = lanes[i];
+            const int32_t rid = rids[i];
+            // primary record with a first / last flag, on a main chromosome, mapped, not a duplicate (bamqualcheck.cpp:318-327,392,430-433)
+            if ((flag & 0xD04u) || !(flag & 0xC0u) || (uint32_t)rid >= n_refs || !main_chrom[rid] || lane >= nl) { out[i] = CovEntry{BQC_COV_NONE, 0}; continue; }
+            LaneCov& st = one ? local : cov[lane];
+            const uint32_t beginpos = (uint32_t)poss[i];
+            // CovPlanner::step, inlined (OverallNumbers.hpp:84-110)
+            if (st.first) { st.first = false; st.id = rid; st.shift = (int32_t)beginpos; }
+            if (st.id != rid || (uint32_t)(beginpos - (uint32_t)st.shift) > 2u * BQC_VSIZE) { st.id = rid; st.win += 2; st.shift = (int32_t)beginpos; } // reset: two windows flushed
+            uint32_t pos = beginpos - (uint32_t)st.shift;
+            if (pos > BQC_VSIZE && pos < 2u * BQC_VSIZE) { st.win += 1; st.shift += BQC_VSIZE; pos = beginpos - (uint32_t)st.shift; } // slide: one window flushed
+            const uint64_t rel = st.win - st.batch_base;
+            if (rel > 0xFFFFFFF0ull) { too_many = true; break; }
+            std::vector<uint32_t>& first = lane_first[lane]; // first[k] = first read of the lane whose window is >= k
+            if (first.size() <= rel) first.resize((size_t)rel + 1, i);
+            last_rel[lane] = (uint32_t)rel;
+            out[i] = CovEntry{(uint32_t)rel, pos};
+        }
+        if (one) cov[0] = local;
+        if (too_many) return bqc_fail(c, BQC_ERR_ARG, "batch spans too many coverage windows (split the batch)");
+    } else
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t flag = b->flag[i], lane = b->lane[i];
         const int32_t rid = b->rid[i];

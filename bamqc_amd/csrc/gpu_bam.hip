@@ -339,6 +339,7 @@ struct GbRun {
     std::vector<GiBlock> hb; DevBuf<GiBlock> d_blocks; // block table, host / device
     std::vector<uint32_t> hc; DevBuf<uint32_t> d_crc;  // expected CRC-32s
     DevBuf<uint8_t> d_out;
+    DevBuf<uint32_t> d_tok, d_ntok; // scratch of the inflate kernels' two phases
     uint32_t* d_status = nullptr;
     size_t utotal = 0;
     uint64_t abs0 = 0;   // where this run's first inflated byte lies in the reader's uncompressed stream (which starts at its begin block)
@@ -532,7 +533,8 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         const double t_a = now_s();
         for (int k = 0; k < 2; ++k) { // (the third run buffer is allocated when a third run comes)
             GbRun& R = I.runs[k];
-            ok = ok && R.d_comp.need(I.run_bytes + I.chunk_bytes + (1u << 17) + 64, true) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap, true);
+            ok = ok && R.d_comp.need(I.run_bytes + I.chunk_bytes + (1u << 17) + 64, true) && R.d_blocks.need(nb_cap) && R.d_crc.need(nb_cap) && R.d_out.need(out_cap, true) &&
+                 R.d_tok.need(bqc_gpu_inflate_token_words(out_cap, nb_cap), true) && R.d_ntok.need(nb_cap);
         }
         const double t_b = now_s();
         ok = ok && I.d_seg.need(seg_cap) && I.h_seg.need(seg_cap) && I.d_rec.need(seg_cap * GB_MAXR, true) && I.d_base.need(seg_cap) && I.h_base.need(seg_cap);
@@ -786,7 +788,8 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     } else {
         if (!wait_ready()) { R.rc = -2; return; }
         // (no-ops for the two buffers open() has allocated; the third one is allocated here, whole: the chunks are copied in as they are read)
-        if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(out_cap, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048)) { R.rc = -2; return; }
+        if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(out_cap, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048) ||
+            !R.d_tok.need(bqc_gpu_inflate_token_words(out_cap, run_bytes / 2048), true) || !R.d_ntok.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
         if (stop_at != UINT64_MAX) { // the readers may go as far as this run can want
             { std::lock_guard<std::mutex> lk(rm); read_limit = std::max(read_limit, stop_at + (1u << 17)); }
@@ -821,7 +824,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     R.final = file_eof;
     R.utotal = utotal;
     u_produced += utotal;
-    if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1))) { R.rc = -2; return; }
+    if (he == hipSuccess && (!R.d_blocks.need(nb + 1) || !R.d_crc.need(nb + 1) || !R.d_ntok.need(nb + 1) || !R.d_tok.need(bqc_gpu_inflate_token_words(utotal, nb)))) { R.rc = -2; return; }
     if (he == hipSuccess && nb) he = hipMemcpyAsync(R.d_blocks.p, R.hb.data(), nb * sizeof(GiBlock), hipMemcpyHostToDevice, R.s); // (pageable, small: staged at once)
     if (produced == 0) { // the caller says when the card may get busy: its own set-up (context, tables) behind a running 50 ms kernel was measured to take 0.2-0.65 s instead of 0.1
         std::unique_lock<std::mutex> lk(m);
@@ -833,7 +836,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timing = this->timing && atoi(getenv("BQC_GB_TIMING")) >= 2; // (2: the kernels of every run, waited for)
     if (timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, R.s); }
-    bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, R.d_out.p, R.d_crc.p, R.d_status, R.s);
+    bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, R.d_out.p, R.d_crc.p, R.d_status, R.d_tok.p, R.d_ntok.p, R.s);
     if (timing) (void)hipEventRecord(e1, R.s);
     if (hipEventRecord(R.ready, R.s) != hipSuccess) R.rc = -2;
     if (timing) { // (waits: only with BQC_GB_TIMING)

@@ -19,6 +19,10 @@ void bqc_gpu_inflater_destroy(GpuInflater* g);
 // 0: every block inflated to exactly its usize bytes; > 0: GI_ERR_* bits (corrupt data); < 0: the GPU could not be used
 // device-resident operands, asynchronous on `stream` (a hipStream_t): inflates, and with d_crc (the blocks' expected CRC-32s) checks;
 // *d_status collects GI_ERR_* bits
-void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, void* stream);
+// (the blocks' outputs lie back to back in d_out, in the order of the table); d_tok / d_ntok: scratch of the two phases — 4 bytes x
+// bqc_gpu_inflate_token_words(inflated bytes, blocks) and 4 bytes x blocks
+size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks);
+void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, uint32_t* d_tok, uint32_t* d_ntok,
+                            void* stream);
 int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_bytes, const GiBlock* blocks, size_t n_blocks, uint8_t* out, size_t out_bytes);
 }

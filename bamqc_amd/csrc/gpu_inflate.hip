@@ -96,22 +96,30 @@ struct Bits { // bit reader over [in, end): the two words behind the buffered on
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// The output side of a lane.  What limits these kernels once the card is full is the number of memory transactions: every lane
-// writes to its own block, so a wave's store is as many transactions as it has active lanes.  Literals are therefore gathered in
-// a register and stored eight at a time; a match of up to 16 bytes at a distance of 16 or more is one 16-byte load and one store
-// (most matches of a BGZF level-1 stream are short), longer ones 32 bytes per step, overlapping ones (distance < 16) word- or
-// byte-wise.  Stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
+// The output side of a lane — phase 1 of two.  Measured on a full card (45 K blocks in a launch): the match copies are HALF of the
+// kernel's time although they are a third of its symbols — every lane copies from its own block's output, up to 32 KiB back, 45 K
+// blocks x 64 KiB of output are 2.9 GB: the copies' loads miss every cache, and the launch stops scaling with the number of
+// blocks (without the copies it takes 23 ms for 45 K blocks and 28 ms for 90 K; with them 49 and 96).  So the lanes do not copy:
+// a lane writes its LITERALS to their final places (gathered in a register, eight bytes per store) and lists its matches as
+// 4-byte tokens; k_inflate_resolve (below) then takes every block's output through LDS, a workgroup per block, and resolves the
+// matches there.  Token: distance - 1 (15 bits) | length - 3 (8 bits) << 15 | literals since the token before (8 bits) << 23; bit 31:
+// no match, only the literals (255 of them).  A block of u bytes has at most u / 3 + 1 tokens.
+#define GI_TOK_DUMMY 0x80000000u
 struct Out {
     uint8_t* o0;
     uint32_t usize;
-    uint32_t o;      // bytes produced, pending literals included
+    uint32_t o;      // bytes produced (matches counted, not copied), pending literals included
     uint32_t nlit;   // literals held in `lit` (0..7): the bytes o - nlit .. o - 1
     uint64_t lit;
+    uint32_t* tok;   // this block's tokens
+    uint32_t ntok;
+    uint32_t run;    // literals since the last token (< 255)
+    uint32_t nmatch;
     __device__ __forceinline__ void flush()
     {
         if (!nlit) return;
         uint8_t* d = o0 + (o - nlit);
-        if (o - nlit + 8u <= usize) *(gi_u64_u*)d = lit;
+        if (o - nlit + 8u <= usize) *(gi_u64_u*)d = lit; // (runs past the literals into bytes that are written later, or by phase 2)
         else for (uint32_t k = 0; k < nlit; ++k) d[k] = (uint8_t)(lit >> (8u * k));
         nlit = 0; lit = 0;
     }
@@ -120,30 +128,26 @@ struct Out {
         lit |= (uint64_t)sym << (8u * nlit);
         ++o;
         if (++nlit == 8u) { *(gi_u64_u*)(o0 + (o - 8u)) = lit; nlit = 0; lit = 0; }
+        if (++run == 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run = 0; }
+    }
+    __device__ __forceinline__ void raw(uint32_t n) // n bytes were written directly (a stored block)
+    {
+        o += n;
+        run += n;
+        while (run >= 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run -= 255u; }
     }
     __device__ __forceinline__ void match(uint32_t length, uint32_t dist) // (the caller has checked dist <= o, o + length <= usize)
     {
-        flush();
-        uint8_t* dst = o0 + o;
-        const uint8_t* src = dst - dist;
+        flush(); // (the literals in front of the match; those behind it start a new register)
+        tok[ntok++] = (dist - 1u) | ((length - 3u) << 15) | (run << 23);
+        run = 0;
+        ++nmatch;
         o += length;
-        if (dist >= 16u && length <= 16u && o - length + 16u <= usize) {
-            *(gi_u32x4_u*)dst = *(const gi_u32x4_u*)src;
-        } else if (dist >= 32u && o + 32u <= usize) { // 32 bytes at a time (both loads first); the overshoot stays inside this block's output
-            for (uint32_t k = 0; k < length; k += 32u) {
-                const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
-                *(gi_u32x4_u*)(dst + k) = a;
-                *(gi_u32x4_u*)(dst + k + 16) = b;
-            }
-        } else if (dist >= 16u && o + 16u <= usize) {
-            for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
-        } else if (dist >= 4u && o + 4u <= usize) {
-            for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
-        } else {
-            for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
-        }
     }
 };
+
+// where block bi's tokens start: the blocks of a launch lie back to back in the output, a block of u bytes has at most u / 3 + 1 tokens
+__device__ __forceinline__ uint64_t gi_tok_base(const GiBlock* __restrict__ blocks, uint32_t bi) { return (blocks[bi].uoff - blocks[0].uoff) / 3u + 2ull * bi; }
 
 template <int NL> __device__ __forceinline__ uint32_t lens_get(const uint16_t* L, uint32_t i) { const uint32_t v = L[GI_AT(GI_O_LENS + (i >> 2))]; return (v >> (4 * (i & 3))) & 15u; }
 template <int NL> __device__ __forceinline__ void lens_set(uint16_t* L, uint32_t i, uint32_t len)
@@ -227,7 +231,7 @@ template <int NL> __device__ __forceinline__ uint32_t decode_sym(const uint16_t*
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgpr(96))) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint16_t lds16[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -239,7 +243,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens + gi_tok_base(blocks, bi), 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
     for (;;) {
@@ -258,7 +262,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
             uint32_t k = 0;
             for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + O.o + k) = *(const gi_u32_u*)(p + k);
             for (; k < len; ++k) o0[O.o + k] = p[k];
-            O.o += len;
+            O.raw(len);
             B.start(p + len, cend);
             if (bfinal) break;
             continue;
@@ -345,6 +349,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
+    ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
@@ -414,7 +419,7 @@ __device__ __forceinline__ uint32_t canon_find(const Canon& C, uint32_t bits32, 
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint8_t lds8[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -426,7 +431,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens + gi_tok_base(blocks, bi), 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0;
     uint8_t lens[320]; // code lengths while the codes are built (private memory)
@@ -446,7 +451,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
             uint32_t k = 0;
             for (; k + 4 <= len; k += 4) *(gi_u32_u*)(o0 + O.o + k) = *(const gi_u32_u*)(p + k);
             for (; k < len; ++k) o0[O.o + k] = p[k];
-            O.o += len;
+            O.raw(len);
             B.start(p + len, cend);
             if (bfinal) break;
             continue;
@@ -602,7 +607,71 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
+    ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// phase 2: the matches of a block, resolved in LDS
+// ---------------------------------------------------------------------------------------------------
+// A workgroup per block: the block's output (literals in place, the matches' bytes still missing) comes into LDS, the tokens are taken
+// 256 at a time — a thread per token: where it writes follows from a scan over (literals in front + length) — and resolved in
+// rounds: everything in front of the first unresolved match is final, so every match whose source ends there or earlier is
+// copied now, by its thread, byte by byte forwards (which is also what an overlapping match, distance < length, means); the first
+// unresolved match itself always qualifies.  Most matches point far back and go in the first round; a chain of matches that
+// each copy from the one before takes a round per link (run-length data: correct, and slow).  Then the block goes back.
+__global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ tokens,
+                                                          const uint32_t* __restrict__ ntok)
+{
+    extern __shared__ uint8_t rbuf[]; // [65536] the block
+    __shared__ uint32_t wsum[4], dsts[256], fu[2];
+    const uint32_t bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (bi >= n_blocks) return;
+    const uint32_t n = ntok[bi];
+    if (n == 0u) return; // no match in this block (or it failed): phase 1 has written all of it
+    const GiBlock blk = blocks[bi];
+    uint8_t* const o0 = out + blk.uoff;
+    const uint32_t usize = blk.usize;
+    for (uint32_t i = tid * 16u; i < usize; i += 256u * 16u) *(gi_u32x4*)(rbuf + i) = *(const gi_u32x4_u*)(o0 + i); // (may read up to 15 bytes of the next block: not used)
+    const uint32_t* const tk = tokens + gi_tok_base(blocks, bi);
+    uint32_t base_o = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
+        const uint32_t t = c0 + tid < n ? tk[c0 + tid] : GI_TOK_DUMMY; // (behind the last token: no match, no literals)
+        const bool dummy = t & GI_TOK_DUMMY;
+        const uint32_t lits = (t >> 23) & 0xFFu, len = dummy ? 0u : ((t >> 15) & 0xFFu) + 3u, dist = (t & 0x7FFFu) + 1u;
+        // where this token's match goes: the literals and matches before it
+        uint32_t incl = lits + len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
+        __syncthreads(); // (the round before is over: wsum, dsts and fu may be written)
+        if (lane == 63u) wsum[wave] = incl;
+        if (tid < 2u) fu[tid] = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const uint32_t dst = base_o + before + incl - len, src = dst - dist;
+        const uint32_t src_end = src + min(len, dist); // the end of what it reads in front of its own output
+        bool pending = !dummy && dst + len <= usize && dist <= dst; // (phase 1 has checked both; a damaged token must not write outside)
+        dsts[tid] = dst;
+        for (uint32_t r = 0;; ++r) {
+            if (pending) atomicMin(&fu[r & 1u], tid);
+            if (tid == 0u) fu[(r + 1u) & 1u] = 0xFFFFFFFFu;
+            __syncthreads();
+            const uint32_t f = fu[r & 1u];
+            if (f == 0xFFFFFFFFu) break;
+            const uint32_t final_below = dsts[f]; // everything below the first unresolved match's destination is final
+            if (pending && src_end <= final_below) {
+                for (uint32_t k = 0; k < len; ++k) rbuf[dst + k] = rbuf[src + k];
+                pending = false;
+            }
+            __syncthreads();
+        }
+        base_o += total;
+    }
+    __syncthreads();
+    for (uint32_t i = tid * 16u; i + 16u <= usize; i += 256u * 16u) *(gi_u32x4_u*)(o0 + i) = *(const gi_u32x4*)(rbuf + i);
+    for (uint32_t i = (usize & ~15u) + tid; i < usize; i += 256u) o0[i] = rbuf[i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -675,24 +744,27 @@ __global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out,
     if (lane == 0 && c != expect[bi]) atomicOr(status, (uint32_t)GI_ERR_CRC);
 }
 
-// launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out
-extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, void* stream)
+// launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out (the blocks' outputs back to
+// back); d_tok: 4 bytes x (inflated bytes / 3 + 2 x blocks) of scratch for the tokens, d_ntok: 4 bytes per block
+extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return inflated_bytes / 3 + 2 * n_blocks + 64; }
+
+extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, uint32_t* d_tok,
+                                       uint32_t* d_ntok, void* stream)
 {
     if (!n_blocks) return;
     static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 4; // (10 K blocks: 24 ms with 4 blocks per workgroup, 29 with 8, 34 with 16, 30 with 2)
-    // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go — 41.7 K blocks in
-    // 53 ms against 72 ms; for fewer blocks the root tables are faster (3.4 K blocks: 20 ms against 30).  BQC_GI_LEAN: 0 never, N always
-    // with N blocks per workgroup
+    // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
+    // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
     static const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
-    const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 32 : 0);
-#define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status)
-    if (lean) {
-        if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 64) GI_LAUNCH_L(64); else GI_LAUNCH_L(16);
-        if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
-        return;
-    }
-#define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status)
-    if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)attr;
+    const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 64 : 0);
+#define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
+#define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
+    if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
+    else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
+    static const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
+    if (!no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok, d_ntok);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 
@@ -706,6 +778,8 @@ struct GpuInflater {
     uint8_t* d_comp = nullptr; size_t comp_cap = 0;
     uint8_t* d_out = nullptr; size_t out_cap = 0;
     GiBlock* d_blocks = nullptr; size_t blocks_cap = 0;
+    uint32_t* d_tok = nullptr; size_t tok_cap = 0;   // the two phases' scratch (bytes)
+    uint32_t* d_ntok = nullptr; size_t ntok_cap = 0;
     uint32_t* d_status = nullptr;
     uint32_t* h_status = nullptr; // page-locked
 };
@@ -722,7 +796,6 @@ extern "C" GpuInflater* bqc_gpu_inflater_create(int device)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&g->d_status, 64);
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->h_status, 64, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate<64>), hipFuncAttributeMaxDynamicSharedMemorySize, GI_U16 * 2 * 64);
     if (e != hipSuccess) {
         if (getenv("BQC_GI_TIMING")) fprintf(stderr, "[gpu inflate] not available: %s\n", hipGetErrorString(e));
         if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -741,7 +814,7 @@ extern "C" void bqc_gpu_inflater_destroy(GpuInflater* g)
     (void)hipSetDevice(g->device);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     if (g->done) (void)hipEventDestroy(g->done);
-    (void)hipFree(g->d_comp); (void)hipFree(g->d_out); (void)hipFree(g->d_blocks); (void)hipFree(g->d_status);
+    (void)hipFree(g->d_comp); (void)hipFree(g->d_out); (void)hipFree(g->d_blocks); (void)hipFree(g->d_status); (void)hipFree(g->d_tok); (void)hipFree(g->d_ntok);
     if (g->h_status) (void)hipHostFree(g->h_status);
     delete g;
 }
@@ -766,6 +839,7 @@ extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_
     if (!grow(g->d_comp, g->comp_cap, comp_bytes + 64) || !grow(g->d_out, g->out_cap, out_bytes + 64)) return -1;
     if (!grow(g->d_blocks, bcap_bytes, n_blocks * sizeof(GiBlock))) return -1;
     g->blocks_cap = bcap_bytes / sizeof(GiBlock);
+    if (!grow(g->d_tok, g->tok_cap, 4 * bqc_gpu_inflate_token_words(out_bytes, n_blocks)) || !grow(g->d_ntok, g->ntok_cap, 4 * n_blocks + 64)) return -1;
     static const bool timing = getenv("BQC_GI_TIMING") != nullptr;
     hipEvent_t ev[4] = {};
     if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
@@ -773,11 +847,8 @@ extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_
     if (hipMemsetAsync(g->d_status, 0, 4, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->d_blocks, blocks, n_blocks * sizeof(GiBlock), hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
-    static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 8;
     if (timing) (void)hipEventRecord(ev[1], g->stream);
-#define GI_LAUNCH(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((uint32_t)((n_blocks + NL - 1) / NL)), dim3(NL), GI_U16 * 2 * NL, g->stream, g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, g->d_status)
-    if (getenv("BQC_GI_LEAN") && atoi(getenv("BQC_GI_LEAN"))) bqc_gpu_inflate_launch(g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, nullptr, g->d_status, g->stream); // (tests: the lean kernel through this path too)
-    else if (lanes == 64) GI_LAUNCH(64); else if (lanes == 32) GI_LAUNCH(32); else if (lanes == 16) GI_LAUNCH(16); else GI_LAUNCH(8);
+    bqc_gpu_inflate_launch(g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, nullptr, g->d_status, g->d_tok, g->d_ntok, g->stream); // (the CRC-32s are checked on the host here)
     if (timing) (void)hipEventRecord(ev[2], g->stream);
     if (hipMemcpyAsync(out, g->d_out, out_bytes, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->h_status, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
