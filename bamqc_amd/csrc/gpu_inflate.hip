@@ -96,14 +96,21 @@ struct Bits { // bit reader over [in, end): the two words behind the buffered on
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// The output side of a lane — phase 1 of two.  Measured on a full card (45 K blocks in a launch): the match copies are HALF of the
-// kernel's time although they are a third of its symbols — every lane copies from its own block's output, up to 32 KiB back, 45 K
-// blocks x 64 KiB of output are 2.9 GB: the copies' loads miss every cache, and the launch stops scaling with the number of
-// blocks (without the copies it takes 23 ms for 45 K blocks and 28 ms for 90 K; with them 49 and 96).  So the lanes do not copy:
-// a lane writes its LITERALS to their final places (gathered in a register, eight bytes per store) and lists its matches as
-// 4-byte tokens; k_inflate_resolve (below) then takes every block's output through LDS, a workgroup per block, and resolves the
-// matches there.  Token: distance - 1 (15 bits) | length - 3 (8 bits) << 15 | literals since the token before (8 bits) << 23; bit 31:
-// no match, only the literals (255 of them).  A block of u bytes has at most u / 3 + 1 tokens.
+// The output side of a lane.  Literals are gathered in a register and stored eight at a time; a match of up to 16 bytes at a distance
+// of 16 or more is one 16-byte load and one store (most matches of a BGZF level-1 stream are short: 6.7 bytes on average in the
+// synthetic files, and 96 % of the output comes from matches), longer ones 32 bytes per step, overlapping ones word- or byte-wise.
+// Stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
+//
+// Measured on a full card (45 K blocks in a launch, profiles/r3_inflate_*.json): the match copies are HALF of the kernel's time —
+// every lane copies from its own block's output, up to 32 KiB back, 45 K blocks x 64 KiB of output are 2.9 GB: the copies' loads miss
+// every cache, and the launch stops scaling with the number of blocks (without the copies: 23 ms for 45 K blocks, 28-32 ms for 90 K;
+// with them 46-49 and 93-96); literal stores cost nothing measurable (byte stores or eight at a time).  TWO PHASES (tokens != nullptr,
+// BQC_GI_TWO_PHASE=1) take the copies out of the lanes: a lane writes its literals to their final places and lists its matches as
+// 4-byte tokens; k_inflate_resolve then takes every block's output through LDS, a workgroup per block, and resolves the matches
+// there.  That is correct (the tests run it) and, so far, SLOWER: 9 300 tokens per block whose dependence chains are 21 rounds deep
+// per 256 tokens make the resolve 65 ms for 45 K blocks (24 + 65 against 49 in one phase).  It stays selectable; the default is one
+// phase.  Token: distance - 1 (15 bits) | length - 3 (8 bits) << 15 | literals since the token before (8 bits) << 23; bit 31: no
+// match, only the literals (255 of them).  A block of u bytes has at most u / 3 + 1 tokens.
 #define GI_TOK_DUMMY 0x80000000u
 struct Out {
     uint8_t* o0;
@@ -111,7 +118,7 @@ struct Out {
     uint32_t o;      // bytes produced (matches counted, not copied), pending literals included
     uint32_t nlit;   // literals held in `lit` (0..7): the bytes o - nlit .. o - 1
     uint64_t lit;
-    uint32_t* tok;   // this block's tokens
+    uint32_t* tok;   // this block's tokens; nullptr: one phase, the lane copies its matches itself
     uint32_t ntok;
     uint32_t run;    // literals since the last token (< 255)
     uint32_t nmatch;
@@ -128,21 +135,43 @@ struct Out {
         lit |= (uint64_t)sym << (8u * nlit);
         ++o;
         if (++nlit == 8u) { *(gi_u64_u*)(o0 + (o - 8u)) = lit; nlit = 0; lit = 0; }
-        if (++run == 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run = 0; }
+        if (tok && ++run == 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run = 0; }
     }
     __device__ __forceinline__ void raw(uint32_t n) // n bytes were written directly (a stored block)
     {
         o += n;
+        if (!tok) return;
         run += n;
         while (run >= 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run -= 255u; }
     }
     __device__ __forceinline__ void match(uint32_t length, uint32_t dist) // (the caller has checked dist <= o, o + length <= usize)
     {
         flush(); // (the literals in front of the match; those behind it start a new register)
-        tok[ntok++] = (dist - 1u) | ((length - 3u) << 15) | (run << 23);
-        run = 0;
-        ++nmatch;
+        if (tok) {
+            tok[ntok++] = (dist - 1u) | ((length - 3u) << 15) | (run << 23);
+            run = 0;
+            ++nmatch;
+            o += length;
+            return;
+        }
+        uint8_t* dst = o0 + o;
+        const uint8_t* src = dst - dist;
         o += length;
+        if (dist >= 16u && length <= 16u && o - length + 16u <= usize) {
+            *(gi_u32x4_u*)dst = *(const gi_u32x4_u*)src;
+        } else if (dist >= 32u && o + 32u <= usize) { // 32 bytes at a time (both loads first); the overshoot stays inside this block's output
+            for (uint32_t k = 0; k < length; k += 32u) {
+                const gi_u32x4 a = *(const gi_u32x4_u*)(src + k), b = *(const gi_u32x4_u*)(src + k + 16);
+                *(gi_u32x4_u*)(dst + k) = a;
+                *(gi_u32x4_u*)(dst + k + 16) = b;
+            }
+        } else if (dist >= 16u && o + 16u <= usize) {
+            for (uint32_t k = 0; k < length; k += 16u) *(gi_u32x4_u*)(dst + k) = *(const gi_u32x4_u*)(src + k);
+        } else if (dist >= 4u && o + 4u <= usize) {
+            for (uint32_t k = 0; k < length; k += 4u) *(gi_u32_u*)(dst + k) = *(const gi_u32_u*)(src + k);
+        } else {
+            for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
+        }
     }
 };
 
@@ -243,7 +272,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens + gi_tok_base(blocks, bi), 0u, 0u, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
     for (;;) {
@@ -349,7 +378,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
-    ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (tokens) ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
@@ -431,7 +460,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens + gi_tok_base(blocks, bi), 0u, 0u, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0;
     uint8_t lens[320]; // code lengths while the codes are built (private memory)
@@ -607,7 +636,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
-    ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (tokens) ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
@@ -616,19 +645,44 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 // ---------------------------------------------------------------------------------------------------
 // A workgroup per block: the block's output (literals in place, the matches' bytes still missing) comes into LDS, the tokens are taken
 // 256 at a time — a thread per token: where it writes follows from a scan over (literals in front + length) — and resolved in
-// rounds: everything in front of the first unresolved match is final, so every match whose source ends there or earlier is
-// copied now, by its thread, byte by byte forwards (which is also what an overlapping match, distance < length, means); the first
-// unresolved match itself always qualifies.  Most matches point far back and go in the first round; a chain of matches that
-// each copy from the one before takes a round per link (run-length data: correct, and slow).  Then the block goes back.
+// rounds.  A match is copied, by its thread, byte by byte forwards (which is also what an overlapping match, distance < length,
+// means), as soon as no UNRESOLVED match writes into the bytes it reads: destinations are disjoint and ascending, so the matches
+// that write into [source, source end) are an index range found by two binary searches, once per token; literals were final before
+// the kernel started.  Run-length style data (a literal, then matches that repeat it) resolves at once; a chain of matches that
+// each copy from the one before takes a round per link — that is the data's own dependence.  Then the block goes back.
+namespace {
+// n bytes forwards inside the block, eight reads then eight writes at a time; the caller guarantees d - s >= 8 or n <= d - s
+__device__ __forceinline__ void lds_copy(uint8_t* buf, uint32_t d, uint32_t s, uint32_t n)
+{
+    uint32_t k = 0;
+    for (; k + 8u <= n; k += 8u) {
+        uint8_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = buf[s + k + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) buf[d + k + j] = v[j];
+    }
+    if (k < n) {
+        uint8_t v[8];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = k + j < n ? buf[s + k + j] : (uint8_t)0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) if (k + j < n) buf[d + k + j] = v[j];
+    }
+}
+} // namespace
+
 __global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ tokens,
-                                                          const uint32_t* __restrict__ ntok)
+                                                          const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
 {
     extern __shared__ uint8_t rbuf[]; // [65536] the block
-    __shared__ uint32_t wsum[4], dsts[256], fu[2];
+    __shared__ uint32_t wsum[4], dsts[256], ends[256];
+    __shared__ uint8_t done[256];
     const uint32_t bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (bi >= n_blocks) return;
     const uint32_t n = ntok[bi];
     if (n == 0u) return; // no match in this block (or it failed): phase 1 has written all of it
+    if (stats && tid == 0) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); }
     const GiBlock blk = blocks[bi];
     uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize;
@@ -643,9 +697,8 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restri
         uint32_t incl = lits + len;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
-        __syncthreads(); // (the round before is over: wsum, dsts and fu may be written)
+        __syncthreads(); // (the chunk before is over: the tables may be written; the block is in LDS)
         if (lane == 63u) wsum[wave] = incl;
-        if (tid < 2u) fu[tid] = 0xFFFFFFFFu;
         __syncthreads();
         uint32_t before = 0;
         for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
@@ -653,19 +706,42 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restri
         const uint32_t dst = base_o + before + incl - len, src = dst - dist;
         const uint32_t src_end = src + min(len, dist); // the end of what it reads in front of its own output
         bool pending = !dummy && dst + len <= usize && dist <= dst; // (phase 1 has checked both; a damaged token must not write outside)
-        dsts[tid] = dst;
-        for (uint32_t r = 0;; ++r) {
-            if (pending) atomicMin(&fu[r & 1u], tid);
-            if (tid == 0u) fu[(r + 1u) & 1u] = 0xFFFFFFFFu;
-            __syncthreads();
-            const uint32_t f = fu[r & 1u];
-            if (f == 0xFFFFFFFFu) break;
-            const uint32_t final_below = dsts[f]; // everything below the first unresolved match's destination is final
-            if (pending && src_end <= final_below) {
-                for (uint32_t k = 0; k < len; ++k) rbuf[dst + k] = rbuf[src + k];
-                pending = false;
+        dsts[tid] = dst; ends[tid] = dst + len; done[tid] = pending ? 0 : 1;
+        __syncthreads();
+        // the matches of this chunk that write into [src, src_end): indices [jlo, jhi) (those of earlier chunks are resolved)
+        uint32_t jlo = 0, jhi = 0;
+        if (pending) {
+            uint32_t lo = 0, hi = tid; // first j < tid with ends[j] > src
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ends[m] > src) hi = m; else lo = m + 1u; }
+            jlo = lo;
+            lo = jlo; hi = tid;        // first j in [jlo, tid) with dsts[j] >= src_end
+            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (dsts[m] >= src_end) hi = m; else lo = m + 1u; }
+            jhi = lo;
+        }
+        for (;;) {
+            bool ready = pending;
+            while (ready && jlo < jhi) { if (done[jlo]) ++jlo; else ready = false; }
+            if (ready) {
+                // A byte read of LDS followed by the write that depends on it costs a round trip, so bytes go eight at a time: eight
+                // reads in flight, then eight writes (lds_copy: valid when the distance is 8 or more, or the whole piece lies in front of
+                // its destination).  A short distance — the run-length matches of quality strings — is widened first: what has been
+                // written doubles the stretch that may be copied from, until that stretch is 8 bytes long.
+                uint32_t filled = 0;
+                while (filled < len && dist + filled < 8u) {
+                    const uint32_t nn = min(dist + filled, len - filled);
+                    lds_copy(rbuf, dst + filled, src, nn);
+                    filled += nn;
+                }
+                if (filled < len) lds_copy(rbuf, dst + filled, src, len - filled); // (from the stretch's start: its length is a multiple of the distance)
             }
-            __syncthreads();
+            __syncthreads(); // the copies are in LDS before anybody is told so
+            if (ready) { done[tid] = 1; pending = false; }
+            if (stats && tid == 0) atomicAdd(&stats[2], 1ull);
+            if (!__syncthreads_or(pending ? 1 : 0)) break;
+        }
+        if (stats) {
+            if (tid == 0) atomicAdd(&stats[1], 1ull);
+            if (!dummy) { atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], (unsigned long long)len); if (dist < 8u) atomicAdd(&stats[5], 1ull); if (len > 32u) atomicAdd(&stats[6], 1ull); }
         }
         base_o += total;
     }
@@ -752,19 +828,34 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
                                        uint32_t* d_ntok, void* stream)
 {
     if (!n_blocks) return;
-    static const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 4; // (10 K blocks: 24 ms with 4 blocks per workgroup, 29 with 8, 34 with 16, 30 with 2)
+    const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 4; // (read at every launch: the tests switch kernels; 10 K blocks: 24 ms with 4 blocks per workgroup, 29 with 8, 34 with 16, 30 with 2)
     // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
     // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
-    static const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
+    const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)attr;
-    const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 64 : 0);
+    const bool two_phase = getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) != 0; // (see the comment at struct Out: correct, and slower so far)
+    if (!two_phase || !d_ntok) d_tok = nullptr;
+    const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 32 : 0);
 #define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
 #define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
     if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
     else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
-    static const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
-    if (!no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok, d_ntok);
+    const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
+    static unsigned long long* d_stats = nullptr; // (BQC_GI_STATS: blocks resolved, chunks, rounds, matches, matched bytes, distances < 8, lengths > 32, tokens — printed at exit)
+    static const bool want_stats = [] {
+        if (!getenv("BQC_GI_STATS")) return false;
+        if (hipMalloc((void**)&d_stats, 64) != hipSuccess || hipMemset(d_stats, 0, 64) != hipSuccess) { d_stats = nullptr; return false; }
+        atexit([] {
+            unsigned long long h[8] = {};
+            if (hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu chunks, %llu rounds, %llu matches of %llu bytes, %llu distances < 8, %llu lengths > 32\n", h[0], h[7], h[1], h[2],
+                        h[3], h[4], h[5], h[6]);
+        });
+        return true;
+    }();
+    (void)want_stats;
+    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok, d_ntok, d_stats);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 

@@ -1,4 +1,4 @@
-"""BASELINE.json config 3 at full size as a FILE on one MI355X: ~618 M synthetic 150 bp PE reads (30x of 3.088 Gb) over chr1..chr22,
+"""BASELINE.json configs 3 and 5 at full size as FILES on one MI355X (--config).  Config 3: ~618 M synthetic 150 bp PE reads (30x of 3.088 Gb) over chr1..chr22,
 chrX, chrY with GRCh38 lengths, written once at BGZF level 1 (~51 GB), then `bin/bamqualcheck` (default -c, default k-mer sketch)
 timed on it: reads/s, compressed GB/s in, the reader named, device memory in use.  Checked by the size-independent properties of
 tests/bamqc_text.py and by the first million reads of the same plan against the oracle, byte for byte.
@@ -38,7 +38,8 @@ def timed_run(args, env_extra=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reads", type=int, default=618_000_000)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5), help="3: 30x WGS 150 bp PE over 24 GRCh38 contigs; 5: 5 M reads x 10 kb, indel / soft-clip heavy, -i 30000")
+    ap.add_argument("--reads", type=int, default=None)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--dir", default=None)
@@ -46,12 +47,25 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gpus-shared", type=int, default=0)
     a = ap.parse_args()
-    tmp = tempfile.mkdtemp(prefix="bqc_c3f_", dir=a.dir)
-    res = {"config": "3: 30x WGS-scale synthetic, 24 GRCh38-length contigs, default -c / -k 32 -q 17, as a FILE", "reads": a.reads, "bgzf_level": a.level}
+    if a.config == 3:
+        names, lens, seed, cli, synth_kw, read_len = NAMES24, GRCH38, 1003, [], {}, 150
+        what = "3: 30x WGS-scale synthetic, 24 GRCh38-length contigs, default -c / -k 32 -q 17, as a FILE"
+        pre_n, pre_cli, pre_okw, pre_kw = 1_000_000, ["-c", "chr1"], dict(chroms="chr1"), {}
+        a.reads = a.reads or 618_000_000
+    else:
+        names, lens, seed, read_len = ["chr1"], [250_000_000], 1005, 10_000
+        cli = ["-c", "chr1", "-i", "30000", "--no-sketch", "--max-read-len", "16384"]
+        synth_kw = dict(read_len=10_000, isize=30_000, long_reads=True)
+        what = "5: long-read stress, 10 kb reads with 20-60 CIGAR operations, 1 x 250 Mb contig, -i 30000 --no-sketch, as a FILE"
+        pre_n, pre_cli, pre_kw = 20_000, cli, synth_kw
+        pre_okw = dict(chroms="chr1", isize=30000, klist=(), qlist=(), max_read_len=16384, hist_cap=65536)
+        a.reads = a.reads or 5_000_000
+    tmp = tempfile.mkdtemp(prefix="bqc_c%df_" % a.config, dir=a.dir)
+    res = {"config": what, "reads": a.reads, "bgzf_level": a.level}
     try:
         bam, fa = os.path.join(tmp, "c3.bam"), os.path.join(tmp, "c3.fa")
         t0 = time.time()
-        hostio.synth_stream(bam, fa, 1003, a.reads, NAMES24, GRCH38, level=a.level)
+        hostio.synth_stream(bam, fa, seed, a.reads, names, lens, level=a.level, **synth_kw)
         res["write_input_s"] = time.time() - t0
         size = os.path.getsize(bam)
         res["bam_bytes"] = size
@@ -60,7 +74,7 @@ def main():
         for k in range(a.runs):
             out = os.path.join(tmp, "o%d.bamqc" % k)
             time.sleep(2.0)
-            dt, err = timed_run(["-r", fa, "-o", out, bam])
+            dt, err = timed_run(["-r", fa, "-o", out] + cli + [bam])
             m = re.search(r"record loop ([0-9.]+) s", err)
             runs.append({"wall_s": dt, "reads_per_s": a.reads / dt, "compressed_GB_per_s": size / dt / 1e9, "record_loop_s": float(m.group(1)) if m else None,
                          "reader": "gpu (inflate, CRC, record walk and column decode on the card)" if "records decoded on the GPU" in err else "host",
@@ -68,14 +82,14 @@ def main():
             print("run %d: %.2f s = %.1f M reads/s, %.2f GB/s of compressed input" % (k, dt, a.reads / dt / 1e6, size / dt / 1e9), flush=True)
         assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "o%d.bamqc" % k), shallow=False) for k in range(1, a.runs))
         lanes = bamqc_text.parse(os.path.join(tmp, "o0.bamqc"))
-        info = bamqc_text.check_invariants(lanes["L1"], n_records=a.reads, read_len=150)
+        info = bamqc_text.check_invariants(lanes["L1"], n_records=a.reads, read_len=read_len)
         cov = lanes["L1"]["genome_coverage_histogram"]
         med = sorted(runs, key=lambda x: x["wall_s"])[len(runs) // 2]
         res.update({"program_wall_s": med["wall_s"], "reads_per_s": med["reads_per_s"], "compressed_GB_per_s": med["compressed_GB_per_s"], "which": "median of %d runs" % a.runs,
                     "reader": med["reader"], "runs": runs, "primary_reads": info["primary"], "triplets": info["triplets"], "eightmers": info["eightmers"],
                     "coverage_positions": int(cov.sum()), "mean_depth_main": float((cov * range(101)).sum() / max(1, cov.sum())), "invariants": "ok"})
         # the host reader on the same file, once (what the GPU reader replaced)
-        dt, err = timed_run(["-r", fa, "-o", os.path.join(tmp, "h.bamqc"), bam], {"BQC_GPU_DECODE": "0"})
+        dt, err = timed_run(["-r", fa, "-o", os.path.join(tmp, "h.bamqc")] + cli + [bam], {"BQC_GPU_DECODE": "0"})
         res["host_reader"] = {"wall_s": dt, "reads_per_s": a.reads / dt, "identical_output": filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "h.bamqc"), shallow=False)}
         print("host reader: %.2f s = %.1f M reads/s" % (dt, a.reads / dt / 1e6), flush=True)
         if a.gpus_shared > 1:
@@ -83,15 +97,15 @@ def main():
             for n in sorted({2, a.gpus_shared}):
                 out = os.path.join(tmp, "g%d.bamqc" % n)
                 time.sleep(2.0)
-                dt, err = timed_run(["--gpus", str(n), "-r", fa, "-o", out, bam], {"BQC_GPUS_SHARE_DEVICE": "1"})
+                dt, err = timed_run(["--gpus", str(n), "-r", fa, "-o", out] + cli + [bam], {"BQC_GPUS_SHARE_DEVICE": "1"})
                 loops = [float(x) for x in re.findall(r"record loop ([0-9.]+) s", err)]
                 shared.append({"workers": n, "wall_s": dt, "reads_per_s": a.reads / dt, "record_loops_s": loops, "identical_output": filecmp.cmp(os.path.join(tmp, "o0.bamqc"), out, shallow=False),
                                "what": "%d workers SHARING one card (BQC_GPUS_SHARE_DEVICE=1): each reads, inflates and decodes its byte range; sums through pipes" % n})
                 print("--gpus %d on one card: %.2f s, record loops %s" % (n, dt, loops), flush=True)
             res["workers_sharing_one_card"] = shared
         # the first million reads of the same plan against the oracle, byte for byte
-        prefix_parity(tmp, 1003, a.reads, min(a.reads, 1_000_000), NAMES24, GRCH38, ["-c", "chr1"], dict(chroms="chr1"))
-        res["prefix_1M_matches_oracle"] = True
+        prefix_parity(tmp, seed, a.reads, min(a.reads, pre_n), names, lens, pre_cli, pre_okw, **pre_kw)
+        res["prefix_matches_oracle"] = {"reads": min(a.reads, pre_n), "identical": True}
         print(json.dumps({k: v for k, v in res.items() if k != "runs"}, indent=1), flush=True)
         if a.out:
             json.dump(res, open(a.out, "w"), indent=1)
