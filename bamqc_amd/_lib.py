@@ -21,6 +21,7 @@ _SIGNATURES = {
     "bqc_set_fasta_index": (C.c_int, [C.c_void_p, _abi.i32p]),
     "bqc_last_error": (C.c_char_p, [C.c_void_p]),
     "bqc_set_reference": (C.c_int, [C.c_void_p, C.c_int32, _abi.u8p, C.c_uint64]),
+    "bqc_reserve_references": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "bqc_submit": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch)]),
     "bqc_submit_async": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.POINTER(C.c_uint64)]),
     "bqc_batch_uploaded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),

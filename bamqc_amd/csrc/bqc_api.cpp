@@ -179,8 +179,11 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     bqc_pipeline_destroy(c);
-    for (auto p : c->d_ref) if (p) (void)hipFree(p);
-    for (auto p : c->d_refn) if (p) (void)hipFree(p);
+    auto in_arena = [&](const void* p) { return c->ref_arena && (const uint8_t*)p >= c->ref_arena && (const uint8_t*)p < c->ref_arena + c->ref_arena_cap; };
+    for (auto p : c->d_ref) if (p && !in_arena(p)) (void)hipFree(p);
+    for (auto p : c->d_refn) if (p && !in_arena(p)) (void)hipFree(p);
+    if (c->ref_arena) (void)hipFree(c->ref_arena);
+    if (c->ref_stream) (void)hipStreamDestroy(c->ref_stream);
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
     (void)hipFree(c->d_state); (void)hipFree(c->d_err0); (void)hipFree(c->d_cursor); (void)hipFree(c->d_fasta_index); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_t8used); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
@@ -191,20 +194,44 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     delete c;
 }
 
+extern "C" int bqc_reserve_references(bqc_ctx* c, uint64_t total_bases, uint32_t n_contigs)
+{
+    if (!c) return BQC_ERR_ARG;
+    if (c->ref_arena) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    // per contig: len bytes of codes + (len / 8 + pads) dwords of nibbles, each rounded up to 256 bytes
+    const size_t cap = (size_t)total_bases + (size_t)total_bases / 2 + (size_t)n_contigs * (8 * BQC_FAST_NH + 1024) + 4096;
+    if (hipMalloc((void**)&c->ref_arena, cap) != hipSuccess) { (void)hipGetLastError(); c->ref_arena = nullptr; return 0; } // (not fatal: the contigs are then allocated one by one)
+    c->ref_arena_cap = cap;
+    c->ref_arena_used = 0;
+    return 0;
+}
+
 extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, uint64_t len)
 {
     if (!c || rid < 0 || (uint32_t)rid >= c->opt.n_refs || (!dna5 && len)) return fail(c, BQC_ERR_ARG, "bqc_set_reference: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->d_ref[rid]) { HIPCHK(c, hipFree(c->d_ref[rid])); c->d_ref[rid] = nullptr; }
-    if (c->d_refn[rid]) { HIPCHK(c, hipFree(c->d_refn[rid])); c->d_refn[rid] = nullptr; }
-    uint8_t* p = nullptr;
-    HIPCHK(c, hipMalloc(&p, len ? len : 1));
-    HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
+    auto in_arena = [&](const void* p) { return c->ref_arena && (const uint8_t*)p >= c->ref_arena && (const uint8_t*)p < c->ref_arena + c->ref_arena_cap; };
+    if (c->d_ref[rid]) { if (!in_arena(c->d_ref[rid])) HIPCHK(c, hipFree(c->d_ref[rid])); c->d_ref[rid] = nullptr; }
+    if (c->d_refn[rid]) { if (!in_arena(c->d_refn[rid])) HIPCHK(c, hipFree(c->d_refn[rid])); c->d_refn[rid] = nullptr; }
+    if (!c->ref_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ref_stream, hipStreamNonBlocking));
     const uint64_t nd8 = (len + 7) / 8; // nibble table of the fast path: BQC_FAST_NH pad dwords + nd8 + BQC_FAST_NH pad dwords
+    const size_t b1 = ((len ? len : 1) + 255) & ~(size_t)255, b2 = ((nd8 + 2 * BQC_FAST_NH) * 4 + 255) & ~(size_t)255;
+    uint8_t* p = nullptr;
     uint32_t* pn = nullptr;
-    HIPCHK(c, hipMalloc(&pn, (nd8 + 2 * BQC_FAST_NH) * 4));
-    bqc_launch_ref_nibbles(p, len, pn, nd8, c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ref_arena && c->ref_arena_used + b1 + b2 <= c->ref_arena_cap) {
+        p = c->ref_arena + c->ref_arena_used;
+        pn = (uint32_t*)(p + b1);
+        c->ref_arena_used += b1 + b2;
+    } else {
+        HIPCHK(c, hipMalloc(&p, len ? len : 1));
+        HIPCHK(c, hipMalloc(&pn, (nd8 + 2 * BQC_FAST_NH) * 4));
+    }
+    // the bulk copy and the nibble kernel on a stream of their own: batches that run meanwhile (another thread's, on contigs that
+    // are there already) are not waited for; only the three small pointer tables go through the batches' stream
+    HIPCHK(c, hipMemcpyAsync(p, dna5, len, hipMemcpyHostToDevice, c->ref_stream));
+    bqc_launch_ref_nibbles(p, len, pn, nd8, c->ref_stream);
+    HIPCHK(c, hipStreamSynchronize(c->ref_stream));
     c->d_ref[rid] = p;
     c->d_refn[rid] = pn;
     c->ref_len[rid] = len;

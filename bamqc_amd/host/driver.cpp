@@ -976,18 +976,63 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     const auto t_create = clk::now();
     if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return shard_abort(); }
     if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
-    std::vector<uint8_t> ref_loaded(std::max(1u, n_refs), 0);
-    for (uint32_t r = 0; r < n_refs && !lazy_refs; ++r)
-        if (fasta_index[r] >= 0) {
-            const auto& c = fa[fasta_index[r]].codes;
-            if ((rc = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
-            ref_loaded[r] = 1;
+    // The references go to the card BEHIND the start of the record loop: a thread of its own uploads the contigs in the BAM header's order
+    // (a human genome is 3.1 GB: 0.35-0.45 s that the loop used to wait for) and the submitting thread only waits when a batch holds a
+    // read on a contig that is not there yet — the first one, as a rule.  (bqc_set_reference may be called beside bqc_submit* for contigs
+    // no submitted batch refers to: include/bamqc.h.)
+    std::vector<uint8_t> ref_loaded(std::max(1u, n_refs), 0); // lazy_refs: 1 loaded; background upload: see ref_state
+    std::unique_ptr<std::atomic<uint8_t>[]> ref_state(new std::atomic<uint8_t>[std::max(1u, n_refs)]); // 0 on its way, 1 on the card, 2 failed
+    for (uint32_t r = 0; r < std::max(1u, n_refs); ++r) ref_state[r] = 0;
+    std::mutex ref_m;
+    std::condition_variable ref_cv;
+    std::string ref_err;
+    std::atomic<bool> ref_stop{false};
+    std::thread ref_loader;
+    const bool bg_refs = !lazy_refs;
+    if (bg_refs) { // (one allocation now: an allocation beside running kernels waits for them)
+        uint64_t total = 0;
+        uint32_t nc = 0;
+        for (uint32_t r = 0; r < n_refs; ++r) if (fasta_index[r] >= 0) { total += fa[fasta_index[r]].codes.size(); ++nc; }
+        (void)bqc_reserve_references(ctx, total, nc);
+    }
+    if (bg_refs) ref_loader = std::thread([&] {
+        for (uint32_t r = 0; r < n_refs; ++r) {
+            uint8_t st = 1;
+            if (fasta_index[r] >= 0 && !ref_stop.load()) {
+                auto& c = fa[fasta_index[r]].codes;
+                if (bqc_set_reference(ctx, (int32_t)r, c.data(), c.size())) { std::lock_guard<std::mutex> lk(ref_m); if (ref_err.empty()) ref_err = bqc_last_error(ctx); st = 2; }
+                bool again = false; // (a FASTA record that serves two BAM references stays until the second one is up)
+                for (uint32_t q = r + 1; q < n_refs; ++q) again = again || fasta_index[q] == fasta_index[r];
+                if (!again) raw_vector<uint8_t>().swap(c);
+            }
+            { std::lock_guard<std::mutex> lk(ref_m); ref_state[r] = st; }
+            ref_cv.notify_all();
         }
-    fa.clear();
-    fa.shrink_to_fit();
+    });
+    auto destroy_ctx = [&]() { // (every way out: the uploader first, it uses the context)
+        ref_stop = true;
+        if (ref_loader.joinable()) ref_loader.join();
+        bqc_destroy(ctx);
+    };
+    if (lazy_refs) { fa.clear(); fa.shrink_to_fit(); }
     double t_lazy_refs = 0;
     uint32_t n_lazy_refs = 0;
-    auto ensure_refs = [&](const HostBatch& hb) -> int { // (lazy_refs) the contigs this batch's reads lie on are on the card before it is submitted
+    double t_wait_refs = 0;
+    auto ensure_refs = [&](const HostBatch& hb) -> int { // the contigs this batch's reads lie on are on the card before it is submitted
+        if (bg_refs) { // wait for the uploader where it has not got to yet
+            int32_t last = -1;
+            for (int32_t rid : hb.rid) {
+                if (rid == last || rid < 0 || (uint32_t)rid >= n_refs) continue;
+                last = rid;
+                if (ref_state[rid].load() == 1) continue;
+                const auto w0 = clk::now();
+                std::unique_lock<std::mutex> lk(ref_m);
+                ref_cv.wait(lk, [&] { return ref_state[rid].load() != 0; });
+                t_wait_refs += secs(w0, clk::now());
+                if (ref_state[rid].load() == 2) { fprintf(stderr, "ERROR: %s\n", ref_err.c_str()); return 1; }
+            }
+            return 0;
+        }
         std::vector<size_t> which;
         std::vector<uint32_t> rids;
         int32_t last = -1;
@@ -1057,7 +1102,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
                 fwrite(out.data(), 1, out.size(), stderr);
             }
         }
-        if (lazy_refs && ensure_refs(*hb)) { status = 1; continue; }
+        if (ensure_refs(*hb)) { status = 1; continue; }
         const bqc_batch v = hb->view();
         const auto s0 = clk::now();
         t_wait += secs(w0, s0);
@@ -1076,6 +1121,8 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         t_submit += secs(s0, clk::now());
     }
     recycle(true);
+    ref_stop = true; // (contigs no read has asked for are not waited for)
+    if (ref_loader.joinable()) ref_loader.join();
     if (!status && (rc = bqc_sync(ctx))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; } // what the device found in the last batches
     dec.join();
     if (timing) fprintf(stderr, "[timing] records decoded %s\n", use_gpu_reader ? "on the GPU (csrc/gpu_bam.hip)" : "on the host");
@@ -1085,6 +1132,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             fprintf(stderr, "[timing] device memory in use at the end of the record loop: %.2f GB of %.0f GB; page-locked decode buffers %.2f GB\n", (total_b - free_b) / 1e9, total_b / 1e9, pinned / 1e9);
     }
+    if (timing && bg_refs) fprintf(stderr, "[timing] references uploaded beside the record loop; the submitting thread waited %.3f s for them\n", t_wait_refs);
     if (timing && lazy_refs) fprintf(stderr, "[timing] %u of %u contigs loaded, when their first reads arrived: %.3f s\n", n_lazy_refs, n_refs, t_lazy_refs);
     if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)
@@ -1093,7 +1141,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (Q.err_code == GpuBamReader::kUnsupported && status) Q.err_code = 0; // (an error of the records before it has been reported: that is the run's result)
     if (Q.err_code == GpuBamReader::kUnsupported) { // nothing has been reported yet: the same file again, through the host reader
         if (timing) fprintf(stderr, "[timing] %s\n", Q.err.c_str());
-        bqc_destroy(ctx);
+        destroy_ctx();
         g_pins.release_all();
         return run_program(argc, argv, shard, true);
     }
@@ -1117,19 +1165,19 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         bqc_shard_result sr{};
         const int verdict = shard->hook(shard->user, &si, &sr);
         if (verdict == BQC_SHARD_FALLBACK) { // the split could not be verified: the whole file again, in this process alone
-            bqc_destroy(ctx);
+            destroy_ctx();
             g_pins.release_all();
             return run_program(argc, argv, nullptr);
         }
-        if (verdict != BQC_SHARD_WRITE) { bqc_destroy(ctx); g_pins.release_all(); return verdict == BQC_SHARD_DONE && !status ? 0 : 1; }
+        if (verdict != BQC_SHARD_WRITE) { destroy_ctx(); g_pins.release_all(); return verdict == BQC_SHARD_DONE && !status ? 0 : 1; }
         names.assign(sr.lane_names, sr.lane_names + sr.n_lane_names);
         idx.assign(sr.lane_index, sr.lane_index + sr.n_lane_names);
     }
-    if (status) { bqc_destroy(ctx); return 1; }
+    if (status) { destroy_ctx(); return 1; }
     const bqc_counts* counts = nullptr;
     const auto t_loop_end = clk::now();
     since_launch("record loop and its checks over");
-    if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); bqc_destroy(ctx); return 1; }
+    if ((rc = bqc_finalize(ctx, &counts))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); destroy_ctx(); return 1; }
     const auto t_final = clk::now();
     bqc_header_info hi;
     hi.sample_id = rd.header().sample_id.c_str();
@@ -1143,7 +1191,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     const bool fast_exit = !rc && getenv("BQC_FAST_EXIT") && getenv("BQC_FAST_EXIT")[0] == '1';
     const char* done_fd = fast_exit ? getenv("BQC_DONE_FD") : nullptr; // the front end (tools/bamqualcheck.cpp) waits for a byte there
     auto teardown = [&]() { // (device memory and page locks are released explicitly: left to the kernel's process teardown they cost 0.2 s more)
-        bqc_destroy(ctx);
+        destroy_ctx();
         g_pins.release_all();
     };
     if (!done_fd) teardown();

@@ -196,6 +196,11 @@ const char* bqc_last_error(const bqc_ctx* ctx); /* ctx may be NULL: last create 
  * library copies it to device memory (replaces Genome/readFastaRecord,
  * TripletCounting.hpp:60-104). */
 int bqc_set_reference(bqc_ctx* ctx, int32_t rid, const uint8_t* dna5, uint64_t len);
+/* Optional, before the first bqc_set_reference: one device allocation for contigs of total_bases bases in all, which
+ * bqc_set_reference then carves from (an allocation made while kernels run waits for them). */
+int bqc_reserve_references(bqc_ctx* ctx, uint64_t total_bases, uint32_t n_contigs);
+/* (May be called from a second thread while another one submits batches, for a contig that no batch submitted so far has a read
+ * on: the program uploads a genome's contigs behind the start of its record loop that way.) */
 
 /* One batch of decoded records into the pipeline: host pass (coverage anchors), copy into a page-locked staging slot,
  * host-to-device copy, device pre-pass and kernels — three batches in flight, the call returns when the batch is queued.
