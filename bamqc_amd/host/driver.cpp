@@ -1000,7 +1000,13 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
             uint8_t st = 1;
             if (fasta_index[r] >= 0 && !ref_stop.load()) {
                 auto& c = fa[fasta_index[r]].codes;
-                if (bqc_set_reference(ctx, (int32_t)r, c.data(), c.size())) { std::lock_guard<std::mutex> lk(ref_m); if (ref_err.empty()) ref_err = bqc_last_error(ctx); st = 2; }
+                // (page-locked for the copy: from pageable memory the 3 GB go through the runtime's staging buffers at ~10 GB/s and hold
+                // the copy engine the record loop's own uploads need for 0.3 s — measured: the loop 0.5 s longer; locked, a contig is
+                // a 57 GB/s transfer of a few milliseconds)
+                const bool locked = c.size() >= (1u << 20) && bqc_host_register(c.data(), c.size()) == 0;
+                const int src = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size());
+                if (locked) (void)bqc_host_unregister(c.data());
+                if (src) { std::lock_guard<std::mutex> lk(ref_m); if (ref_err.empty()) ref_err = bqc_last_error(ctx); st = 2; }
                 bool again = false; // (a FASTA record that serves two BAM references stays until the second one is up)
                 for (uint32_t q = r + 1; q < n_refs; ++q) again = again || fasta_index[q] == fasta_index[r];
                 if (!again) raw_vector<uint8_t>().swap(c);

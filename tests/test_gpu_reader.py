@@ -119,8 +119,8 @@ def test_gpu_reader_hands_over_a_batch_not_the_file(tmp_path):
     wall = {}
     for name, path in (("clean", clean), ("odd", odd)) * 3:  # (the best of three each: start-up times of small runs scatter)
         t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(root, "bin", "bamqualcheck"), "-r", fa, "-o", str(tmp_path / (name + ".bamqc")), "-c", "chr1,chr2", path],
-                           env=dict(os.environ, BQC_GPU_DECODE="1", BQC_TIMING="1", BQC_NO_FORK="1"), capture_output=True, text=True)
+        r = subprocess.run([os.path.join(root, "bin", "bamqualcheck"), "-r", fa, "-o", str(tmp_path / (name + ".bamqc")), "-c", "chr1,chr2", "--batch-reads", "100000", path],  # (batches of 100 K reads: the odd record's batch is the last of eight)
+                           env=dict(os.environ, BQC_GPU_DECODE="1", BQC_TIMING="1", BQC_NO_FORK="1", BQC_GB_TIMING="1"), capture_output=True, text=True)
         wall[name] = min(wall.get(name, 1e9), time.perf_counter() - t0)
         assert r.returncode == 0, r.stderr
         assert "records decoded on the GPU" in r.stderr and ("1 batches held records" in r.stderr) == (name == "odd"), r.stderr

@@ -33,6 +33,14 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(unsigned long l
 #define BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x96\n"
 #define ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
 #define CHAIN(i) "v_add_u32 %0, %0, %8\n"
+#define OR2(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define XOR2(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define SUB2(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
+#define LSHR2(i) "v_lshrrev_b32 %" #i ", 1, %" #i "\n"
+#define MIN2(i) "v_min_u32 %" #i ", %" #i ", %8\n"
+#define MOV1(i) "v_mov_b32 %" #i ", %8\n"
+#define BREV1(i) "v_bfrev_b32 %" #i ", %" #i "\n"
+#define ADD2REG(i) "v_add_u32 %" #i ", %" #i ", %" #i "\n"
         if (OP == 0) { EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) EIGHT(ADD) }
         if (OP == 1) { EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) EIGHT(PERM) }
         if (OP == 2) { EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) EIGHT(ALIGN) }
@@ -45,6 +53,16 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(unsigned long l
         if (OP == 9) { EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) EIGHT(ADDLIT) }
         if (OP == 10) { EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) EIGHT(AND2) EIGHT(LSHL2) }
         if (OP == 11) { EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) EIGHT(BITOP3) EIGHT(ADD3) }
+        if (OP == 13) { EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) EIGHT(AND2) }
+        if (OP == 14) { EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) EIGHT(LSHL2) }
+        if (OP == 15) { EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) EIGHT(OR2) }
+        if (OP == 16) { EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) EIGHT(XOR2) }
+        if (OP == 17) { EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) EIGHT(SUB2) }
+        if (OP == 18) { EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) EIGHT(LSHR2) }
+        if (OP == 19) { EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) EIGHT(MIN2) }
+        if (OP == 20) { EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) EIGHT(MOV1) }
+        if (OP == 21) { EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) EIGHT(BREV1) }
+        if (OP == 22) { EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) EIGHT(ADD2REG) }
         if (OP == 12) { EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) EIGHT(CHAIN) } // one dependent chain: latency
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -109,6 +127,16 @@ int main(int argc, char** argv)
     run<10>("and_lshl_vop2", n_cu, d_out, js, first);
     run<11>("bitop3_add3", n_cu, d_out, js, first);
     run<12>("add_chain", n_cu, d_out, js, first);
+    run<13>("and_b32", n_cu, d_out, js, first);
+    run<14>("lshlrev_b32", n_cu, d_out, js, first);
+    run<15>("or_b32", n_cu, d_out, js, first);
+    run<16>("xor_b32", n_cu, d_out, js, first);
+    run<17>("sub_u32", n_cu, d_out, js, first);
+    run<18>("lshrrev_b32", n_cu, d_out, js, first);
+    run<19>("min_u32", n_cu, d_out, js, first);
+    run<20>("mov_b32", n_cu, d_out, js, first);
+    run<21>("bfrev_b32", n_cu, d_out, js, first);
+    run<22>("add_same_reg", n_cu, d_out, js, first);
     fprintf(js, "\n]}\n");
     fclose(js);
     return 0;
