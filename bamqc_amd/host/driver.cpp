@@ -992,8 +992,8 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // BQC_BG_REFS=1: the uploader runs BESIDE the record loop (which then starts 0.35 s earlier).  Measured on a 100 M-read file over a
     // human-sized genome: the loop itself becomes 0.5-0.6 s longer (1.45-1.55 s against 0.9), from pageable and from page-locked memory
     // alike — page-locking and large copies beside running inflate kernels hold up the other threads' calls into the runtime — so by
-    // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs, copies from
-    // page-locked memory on a stream of their own (0.2 s instead of 0.37 s for 3.1 GB).
+    // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs and a stream of
+    // its own for the copies.
     const bool refs_beside_loop = bg_refs && getenv("BQC_BG_REFS") && getenv("BQC_BG_REFS")[0] == '1';
     if (bg_refs) { // (one allocation now: an allocation beside running kernels waits for them)
         uint64_t total = 0;
@@ -1006,12 +1006,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
             uint8_t st = 1;
             if (fasta_index[r] >= 0 && !ref_stop.load()) {
                 auto& c = fa[fasta_index[r]].codes;
-                // (page-locked for the copy: from pageable memory the 3 GB go through the runtime's staging buffers at ~10 GB/s and hold
-                // the copy engine the record loop's own uploads need for 0.3 s — measured: the loop 0.5 s longer; locked, a contig is
-                // a 57 GB/s transfer of a few milliseconds)
-                const bool locked = c.size() >= (1u << 20) && bqc_host_register(c.data(), c.size()) == 0;
+                // (from pageable memory: page-locking the 3.1 GB first — hipHostRegister — and copying at the link's speed measured SLOWER
+                // for the whole genome, 0.63-0.82 s against 0.35-0.46 s)
                 const int src = bqc_set_reference(ctx, (int32_t)r, c.data(), c.size());
-                if (locked) (void)bqc_host_unregister(c.data());
                 if (src) { std::lock_guard<std::mutex> lk(ref_m); if (ref_err.empty()) ref_err = bqc_last_error(ctx); st = 2; }
                 bool again = false; // (a FASTA record that serves two BAM references stays until the second one is up)
                 for (uint32_t q = r + 1; q < n_refs; ++q) again = again || fasta_index[q] == fasta_index[r];

@@ -24,8 +24,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
-                    help="config2 (default, the configuration the metric is quoted on): 10 M x 150 bp PE; config5: long reads, 10 kb, indel / soft-clip heavy")
+    ap.add_argument("--workload", choices=("config2", "config5", "config3"), default="config2",
+                    help="config2 (default, the configuration the metric is quoted on): 10 M x 150 bp PE; config5: long reads, 10 kb, indel / soft-clip heavy; "
+                         "config3: the 30x WGS-scale BAM FILE (618 M reads, ~54 GB at BGZF level 1: written first, ~3 min) through bin/bamqualcheck, live — "
+                         "the line's value is then the program's reads/s, not a kernel rate")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (default: 10 M for config2, 100 k for config5)")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--sketch", action="store_true", help="steps include the k-mer sketch of the program's default options (-k 32 -q 17)")
@@ -35,6 +37,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra device timings (default options with sketch; long reads)")
     ap.add_argument("--e2e-prefix", type=int, default=1_000_000, help="reads of the e2e input checked against the oracle")
     args = ap.parse_args()
+    if args.workload == "config3":
+        return config3_line(args)
     long_reads = args.workload == "config5"
     if args.reads is None:
         args.reads = 100_000 if long_reads else 10_000_000
@@ -135,7 +139,7 @@ def main():
         # cannot be read in-process
         traffic, limiter = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r3_traffic.json")) else "r2_traffic.json")))
             if tj.get("kernel") == dom and args.reads == 10_000_000 and args.read_len == 150 and not args.sketch:
                 traffic = tj["traffic_bytes_per_launch"]
                 limiter = tj.get("limiter")
@@ -154,7 +158,7 @@ def main():
                        "reads_per_gpu_per_step": args.reads, "parallelism": "shard by read batch; RCCL reduce of state vector at end"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
                          "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": traffic,
-                         "traffic_source": "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated)" if traffic else None,
+                         "traffic_source": "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated; limiter against the MEASURED issue ceiling of profiles/r3_valu_issue.json)" if traffic else None,
                          "limiter": limiter or {"what": "valu+lds issue (integer SWAR and LDS atomics per base), not HBM: see DESIGN.md 4.2"},
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_read": abytes / args.reads,
                          "kernel_ms": kavg},
@@ -168,6 +172,15 @@ def main():
         del cols
         if world == 1 and not args.no_extra and not long_reads and not args.sketch:
             out["extra"] = extra_timings(refs)
+        try:  # the headline WGS configuration as a FILE: measured by tools/run_config_file.py under gpurun (generating its 54 GB input takes 3 minutes;
+            # `--workload config3` measures it live), copied here with its source named
+            c3 = json.load(open(os.path.join(ROOT, "profiles", "r3_config3_file.json")))
+            out["e2e_config3"] = {"source": "profiles/r3_config3_file.json (tools/run_config_file.py --config 3; not re-measured in this run)", "reads": c3["reads"],
+                                  "bam_GB": c3["bam_bytes"] / 1e9, "wall_s": c3["program_wall_s"], "reads_per_s": c3["reads_per_s"], "compressed_GB_per_s": c3["compressed_GB_per_s"],
+                                  "reader": c3["reader"], "which": c3["which"], "host_reader_reads_per_s": c3["host_reader"]["reads_per_s"],
+                                  "prefix_matches_oracle": c3.get("prefix_matches_oracle")}
+        except Exception:
+            pass
         if e2e is not None:
             cv = out.get("cpu_baseline", {}).get("value")
             e2e["speedup_vs_cpu_port"] = (e2e["reads_per_s"] / cv) if cv else None
@@ -178,6 +191,25 @@ def main():
         agg.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def config3_line(args):
+    """--workload config3: BASELINE.json config 3 at full size as a FILE through the program, live (tools/run_config_file.py)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="bqc_c3line_") as tmp:
+        out = os.path.join(tmp, "c3.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config_file.py"), "--config", "3", "--runs", str(max(1, min(args.steps, 5))), "--out", out] +
+                           (["--reads", str(args.reads)] if args.reads else []), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        c3 = json.load(open(out))
+    line = {"metric": "BAM records/sec (and GB/s vs HBM roofline), 150 bp PE, 1/2/4/8 MI355X", "value": c3["reads_per_s"], "unit": "reads/s",
+            "value_kind": "the PROGRAM: BAM file (BGZF level 1) -> bin/bamqualcheck, default options -> .bamqc; wall time of the whole process, median of the runs",
+            "n_gpus": 1, "steps": len(c3["runs"]), "warmup": 0, "ms_per_step": c3["program_wall_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32/u64 integer", "data": "synthetic",
+            "config": {"workload": "config 3: %d reads x 150 bp PE, 24 GRCh38-length contigs, as a %.1f GB BAM file" % (c3["reads"], c3["bam_bytes"] / 1e9)},
+            "e2e_config3": c3}
+    print(json.dumps(line), flush=True)
 
 
 def extra_timings(refs):
