@@ -107,21 +107,19 @@ struct Bits { // bit reader over [in, end): the two words behind the buffered on
 // with them 46-49 and 93-96); literal stores cost nothing measurable (byte stores or eight at a time).  TWO PHASES (tokens != nullptr,
 // BQC_GI_TWO_PHASE=1) take the copies out of the lanes: a lane writes its literals to their final places and lists its matches as
 // 4-byte tokens; k_inflate_resolve then takes every block's output through LDS, a workgroup per block, and resolves the matches
-// there.  That is correct (the tests run it) and, so far, SLOWER: 9 300 tokens per block whose dependence chains are 21 rounds deep
-// per 256 tokens make the resolve 65 ms for 45 K blocks (24 + 65 against 49 in one phase).  It stays selectable; the default is one
-// phase.  Token: distance - 1 (15 bits) | length - 3 (8 bits) << 15 | literals since the token before (8 bits) << 23; bit 31: no
-// match, only the literals (255 of them).  A block of u bytes has at most u / 3 + 1 tokens.
-#define GI_TOK_DUMMY 0x80000000u
+// there.  That is correct (the tests run it) and SLOWER: a block has 9 300 matches whose dependence chains (a match copies what the
+// match before it wrote) are ~775 links long, and a link costs a round of the resolve kernel — 65 ms for 45 K blocks with rounds
+// between workgroup barriers, 83 ms with a bitmap of final bytes and no barriers (1 457 rounds per wave at ~1 500 cycles), against the
+// 25 ms the copies cost inside the lanes.  It stays selectable; the default is one phase.  Token (8 bytes): where the match goes
+// (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32.  A block of u bytes has at most u / 3 matches.
 struct Out {
     uint8_t* o0;
     uint32_t usize;
-    uint32_t o;      // bytes produced (matches counted, not copied), pending literals included
+    uint32_t o;      // bytes produced (in two phases: matches counted, not copied), pending literals included
     uint32_t nlit;   // literals held in `lit` (0..7): the bytes o - nlit .. o - 1
     uint64_t lit;
-    uint32_t* tok;   // this block's tokens; nullptr: one phase, the lane copies its matches itself
+    uint64_t* tok;   // this block's tokens; nullptr: one phase, the lane copies its matches itself
     uint32_t ntok;
-    uint32_t run;    // literals since the last token (< 255)
-    uint32_t nmatch;
     __device__ __forceinline__ void flush()
     {
         if (!nlit) return;
@@ -135,22 +133,13 @@ struct Out {
         lit |= (uint64_t)sym << (8u * nlit);
         ++o;
         if (++nlit == 8u) { *(gi_u64_u*)(o0 + (o - 8u)) = lit; nlit = 0; lit = 0; }
-        if (tok && ++run == 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run = 0; }
     }
-    __device__ __forceinline__ void raw(uint32_t n) // n bytes were written directly (a stored block)
-    {
-        o += n;
-        if (!tok) return;
-        run += n;
-        while (run >= 255u) { tok[ntok++] = GI_TOK_DUMMY | (255u << 23); run -= 255u; }
-    }
+    __device__ __forceinline__ void raw(uint32_t n) { o += n; } // n bytes were written directly (a stored block)
     __device__ __forceinline__ void match(uint32_t length, uint32_t dist) // (the caller has checked dist <= o, o + length <= usize)
     {
         flush(); // (the literals in front of the match; those behind it start a new register)
-        if (tok) {
-            tok[ntok++] = (dist - 1u) | ((length - 3u) << 15) | (run << 23);
-            run = 0;
-            ++nmatch;
+        if (tok) { // token: where it goes (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32
+            tok[ntok++] = (uint64_t)o | ((uint64_t)length << 16) | ((uint64_t)dist << 32);
             o += length;
             return;
         }
@@ -175,7 +164,7 @@ struct Out {
     }
 };
 
-// where block bi's tokens start: the blocks of a launch lie back to back in the output, a block of u bytes has at most u / 3 + 1 tokens
+// where block bi's tokens start: the blocks of a launch lie back to back in the output, a block of u bytes has at most u / 3 matches
 __device__ __forceinline__ uint64_t gi_tok_base(const GiBlock* __restrict__ blocks, uint32_t bi) { return (blocks[bi].uoff - blocks[0].uoff) / 3u + 2ull * bi; }
 
 template <int NL> __device__ __forceinline__ uint32_t lens_get(const uint16_t* L, uint32_t i) { const uint32_t v = L[GI_AT(GI_O_LENS + (i >> 2))]; return (v >> (4 * (i & 3))) & 15u; }
@@ -260,7 +249,7 @@ template <int NL> __device__ __forceinline__ uint32_t decode_sym(const uint16_t*
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgpr(96))) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint64_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint16_t lds16[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -272,7 +261,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u, 0u, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
     for (;;) {
@@ -378,7 +367,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
-    if (tokens) ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (tokens) ntok[bi] = st ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
@@ -448,7 +437,7 @@ __device__ __forceinline__ uint32_t canon_find(const Canon& C, uint32_t bits32, 
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
+                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint64_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint8_t lds8[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -460,7 +449,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u, 0u, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0;
     uint8_t lens[320]; // code lengths while the codes are built (private memory)
@@ -636,115 +625,88 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     O.flush();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
-    if (tokens) ntok[bi] = st || !O.nmatch ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (tokens) ntok[bi] = st ? 0u : O.ntok; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // phase 2: the matches of a block, resolved in LDS
 // ---------------------------------------------------------------------------------------------------
-// A workgroup per block: the block's output (literals in place, the matches' bytes still missing) comes into LDS, the tokens are taken
-// 256 at a time — a thread per token: where it writes follows from a scan over (literals in front + length) — and resolved in
-// rounds.  A match is copied, by its thread, byte by byte forwards (which is also what an overlapping match, distance < length,
-// means), as soon as no UNRESOLVED match writes into the bytes it reads: destinations are disjoint and ascending, so the matches
-// that write into [source, source end) are an index range found by two binary searches, once per token; literals were final before
-// the kernel started.  Run-length style data (a literal, then matches that repeat it) resolves at once; a chain of matches that
-// each copy from the one before takes a round per link — that is the data's own dependence.  Then the block goes back.
-namespace {
-// n bytes forwards inside the block, eight reads then eight writes at a time; the caller guarantees d - s >= 8 or n <= d - s
-__device__ __forceinline__ void lds_copy(uint8_t* buf, uint32_t d, uint32_t s, uint32_t n)
-{
-    uint32_t k = 0;
-    for (; k + 8u <= n; k += 8u) {
-        uint8_t v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = buf[s + k + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) buf[d + k + j] = v[j];
-    }
-    if (k < n) {
-        uint8_t v[8];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) v[j] = k + j < n ? buf[s + k + j] : (uint8_t)0;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) if (k + j < n) buf[d + k + j] = v[j];
-    }
-}
-} // namespace
-
-__global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ tokens,
+// A workgroup (four waves) per block: the block's output (literals in place, the matches' bytes still missing) comes into LDS,
+// beside it a BITMAP with a bit per byte: "final".  Literals are final from the start (the matches' destinations are cleared in a
+// first pass over the tokens); thread t takes the tokens t, t + 256, ... and in every round copies up to 16 bytes of its current match
+// if the bits of the bytes it would read are all set — the data first, then the bits of what it wrote (LDS operations of a wave
+// execute in order, the waves see each other's work through the bitmap: there is no barrier in the loop).  A byte is written
+// once, so a set bit stays true; the earliest unresolved match of the block can always go on (everything in front of it is
+// final), so somebody always makes progress.  An overlapping match (distance < length: run-length data) advances by its distance
+// per round, reading what it wrote the round before.
+// Measured: 83 ms for 45 K blocks — 1 457 rounds per wave at ~1 500 cycles (about 300 instructions: sixteen predicated byte reads
+// and writes), for dependence chains of ~775 links per block; the first version of this kernel (thread per token in chunks of 256,
+// rounds between workgroup barriers, dependence ranges by binary search) took 65 ms.  The bound is the chain: a link costs at least
+// an LDS round trip, ~40 us per block, 3-4 ms for 45 K blocks on 512 resident blocks — neither version is near it.
+__global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint64_t* __restrict__ tokens,
                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
 {
-    extern __shared__ uint8_t rbuf[]; // [65536] the block
-    __shared__ uint32_t wsum[4], dsts[256], ends[256];
-    __shared__ uint8_t done[256];
-    const uint32_t bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    extern __shared__ uint8_t rbuf[]; // [65536] the block, then [2048 + 2] words of bitmap
+    uint32_t* const bm = (uint32_t*)(rbuf + 65536);
+    const uint32_t bi = blockIdx.x, tid = threadIdx.x;
     if (bi >= n_blocks) return;
     const uint32_t n = ntok[bi];
     if (n == 0u) return; // no match in this block (or it failed): phase 1 has written all of it
-    if (stats && tid == 0) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); }
     const GiBlock blk = blocks[bi];
     uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize;
+    const uint64_t* const tk = tokens + gi_tok_base(blocks, bi);
     for (uint32_t i = tid * 16u; i < usize; i += 256u * 16u) *(gi_u32x4*)(rbuf + i) = *(const gi_u32x4_u*)(o0 + i); // (may read up to 15 bytes of the next block: not used)
-    const uint32_t* const tk = tokens + gi_tok_base(blocks, bi);
-    uint32_t base_o = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
-        const uint32_t t = c0 + tid < n ? tk[c0 + tid] : GI_TOK_DUMMY; // (behind the last token: no match, no literals)
-        const bool dummy = t & GI_TOK_DUMMY;
-        const uint32_t lits = (t >> 23) & 0xFFu, len = dummy ? 0u : ((t >> 15) & 0xFFu) + 3u, dist = (t & 0x7FFFu) + 1u;
-        // where this token's match goes: the literals and matches before it
-        uint32_t incl = lits + len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
-        __syncthreads(); // (the chunk before is over: the tables may be written; the block is in LDS)
-        if (lane == 63u) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
-        const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        const uint32_t dst = base_o + before + incl - len, src = dst - dist;
-        const uint32_t src_end = src + min(len, dist); // the end of what it reads in front of its own output
-        bool pending = !dummy && dst + len <= usize && dist <= dst; // (phase 1 has checked both; a damaged token must not write outside)
-        dsts[tid] = dst; ends[tid] = dst + len; done[tid] = pending ? 0 : 1;
-        __syncthreads();
-        // the matches of this chunk that write into [src, src_end): indices [jlo, jhi) (those of earlier chunks are resolved)
-        uint32_t jlo = 0, jhi = 0;
-        if (pending) {
-            uint32_t lo = 0, hi = tid; // first j < tid with ends[j] > src
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (ends[m] > src) hi = m; else lo = m + 1u; }
-            jlo = lo;
-            lo = jlo; hi = tid;        // first j in [jlo, tid) with dsts[j] >= src_end
-            while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (dsts[m] >= src_end) hi = m; else lo = m + 1u; }
-            jhi = lo;
+    for (uint32_t i = tid; i < 2050u; i += 256u) bm[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += 256u) { // the matches' destinations are not final yet
+        const uint64_t k = tk[t];
+        uint32_t d = (uint32_t)k & 0xFFFFu, len = (uint32_t)(k >> 16) & 0xFFFFu;
+        if (d + len > usize) len = usize > d ? usize - d : 0u; // (phase 1 has checked it; a damaged token must not reach outside)
+        while (len) {
+            const uint32_t w = d >> 5, sft = d & 31u, c = min(len, 32u - sft);
+            atomicAnd(&bm[w], ~((c == 32u ? 0xFFFFFFFFu : (1u << c) - 1u) << sft));
+            d += c; len -= c;
         }
-        for (;;) {
-            bool ready = pending;
-            while (ready && jlo < jhi) { if (done[jlo]) ++jlo; else ready = false; }
-            if (ready) {
-                // A byte read of LDS followed by the write that depends on it costs a round trip, so bytes go eight at a time: eight
-                // reads in flight, then eight writes (lds_copy: valid when the distance is 8 or more, or the whole piece lies in front of
-                // its destination).  A short distance — the run-length matches of quality strings — is widened first: what has been
-                // written doubles the stretch that may be copied from, until that stretch is 8 bytes long.
-                uint32_t filled = 0;
-                while (filled < len && dist + filled < 8u) {
-                    const uint32_t nn = min(dist + filled, len - filled);
-                    lds_copy(rbuf, dst + filled, src, nn);
-                    filled += nn;
-                }
-                if (filled < len) lds_copy(rbuf, dst + filled, src, len - filled); // (from the stretch's start: its length is a multiple of the distance)
-            }
-            __syncthreads(); // the copies are in LDS before anybody is told so
-            if (ready) { done[tid] = 1; pending = false; }
-            if (stats && tid == 0) atomicAdd(&stats[2], 1ull);
-            if (!__syncthreads_or(pending ? 1 : 0)) break;
-        }
-        if (stats) {
-            if (tid == 0) atomicAdd(&stats[1], 1ull);
-            if (!dummy) { atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], (unsigned long long)len); if (dist < 8u) atomicAdd(&stats[5], 1ull); if (len > 32u) atomicAdd(&stats[6], 1ull); }
-        }
-        base_o += total;
     }
+    __syncthreads();
+    uint32_t t = tid, dst = 0, src = 0, rem = 0, dist = 1;
+    uint64_t nxt = t < n ? tk[t] : 0ull;
+    auto take = [&]() { // the prefetched token becomes the current one; the one after it is requested
+        dst = (uint32_t)nxt & 0xFFFFu; rem = (uint32_t)(nxt >> 16) & 0xFFFFu; dist = (uint32_t)(nxt >> 32);
+        if (dist == 0u || dist > dst || dst + rem > usize) rem = 0; // (see above)
+        src = dst - dist;
+        nxt = t + 256u < n ? tk[t + 256u] : 0ull;
+    };
+    bool have = t < n;
+    if (have) take();
+    unsigned long long rounds = 0;
+    while (__ballot(have)) {
+        ++rounds;
+        if (have) {
+            if (rem == 0u) { t += 256u; have = t < n; if (have) take(); }
+            else {
+                const uint32_t need = min(min(rem, 16u), dist);
+                const uint32_t w = src >> 5, sft = src & 31u;
+                const uint32_t bits = (uint32_t)(((uint64_t)bm[w] | ((uint64_t)bm[w + 1u] << 32)) >> sft), mask = (1u << need) - 1u;
+                if ((bits & mask) == mask) {
+                    uint8_t v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if ((uint32_t)j < need) v[j] = rbuf[src + j];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if ((uint32_t)j < need) rbuf[dst + j] = v[j];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the bytes before their bits
+                    const uint32_t dw = dst >> 5, ds = dst & 31u;
+                    atomicOr(&bm[dw], mask << ds);
+                    if (ds + need > 32u) atomicOr(&bm[dw + 1u], mask >> (32u - ds));
+                    src += need; dst += need; rem -= need;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (the bitmap is read again in the next round)
+    }
+    if (stats && (tid & 63u) == 0u) { atomicAdd(&stats[2], rounds); if (tid == 0u) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); } }
     __syncthreads();
     for (uint32_t i = tid * 16u; i + 16u <= usize; i += 256u * 16u) *(gi_u32x4_u*)(o0 + i) = *(const gi_u32x4*)(rbuf + i);
     for (uint32_t i = (usize & ~15u) + tid; i < usize; i += 256u) o0[i] = rbuf[i];
@@ -822,7 +784,9 @@ __global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out,
 
 // launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out (the blocks' outputs back to
 // back); d_tok: 4 bytes x (inflated bytes / 3 + 2 x blocks) of scratch for the tokens, d_ntok: 4 bytes per block
-extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return inflated_bytes / 3 + 2 * n_blocks + 64; }
+extern "C" int bqc_gpu_inflate_two_phase() { return getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) != 0 ? 1 : 0; }
+// (4-byte words: a token is 8 bytes; 64 words when the two phases are off: nothing is listed then)
+extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return bqc_gpu_inflate_two_phase() ? 2 * (inflated_bytes / 3 + 2 * n_blocks + 64) : 64; }
 
 extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, uint32_t* d_tok,
                                        uint32_t* d_ntok, void* stream)
@@ -832,13 +796,14 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
     // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
     const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 2052 * 4);
     (void)attr;
-    const bool two_phase = getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) != 0; // (see the comment at struct Out: correct, and slower so far)
+    const bool two_phase = bqc_gpu_inflate_two_phase() != 0; // (see the comment at struct Out)
     if (!two_phase || !d_ntok) d_tok = nullptr;
     const int lean = lean_env >= 0 ? lean_env : (n_blocks > 18000u ? 32 : 0);
-#define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
-#define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok, d_ntok)
+    uint64_t* const d_tok64 = (uint64_t*)d_tok;
+#define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
+#define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
     if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
     else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
     const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
@@ -849,13 +814,12 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
         atexit([] {
             unsigned long long h[8] = {};
             if (hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu chunks, %llu rounds, %llu matches of %llu bytes, %llu distances < 8, %llu lengths > 32\n", h[0], h[7], h[1], h[2],
-                        h[3], h[4], h[5], h[6]);
+                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu wave-rounds\n", h[0], h[7], h[2]);
         });
         return true;
     }();
     (void)want_stats;
-    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok, d_ntok, d_stats);
+    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536 + 2052 * 4, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 

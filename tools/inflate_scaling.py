@@ -63,7 +63,7 @@ def main():
         d_crc = torch.from_numpy(crc.view(np.int32)).to(dev)
         d_out = torch.empty(u + 4096, dtype=torch.uint8, device=dev)
         d_st = torch.zeros(16, dtype=torch.int32, device=dev)
-        d_tok = torch.empty(u // 3 + 2 * n + 64, dtype=torch.int32, device=dev)
+        d_tok = torch.empty(2 * (u // 3 + 2 * n + 64), dtype=torch.int32, device=dev)
         d_ntok = torch.empty(n + 16, dtype=torch.int32, device=dev)
         ms = []
         for it in range(4):
