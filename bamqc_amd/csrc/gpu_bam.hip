@@ -1,6 +1,6 @@
 // gpu_bam.hip — BAM input decoded on the GPU (row N2 of the scope table, step 2: see gpu_bam.h).
 //
-//   file --fread--> page-locked buffer --H2D--> k_inflate + k_gi_crc (gpu_inflate.hip) --> the uncompressed stream, in device memory
+//   file --pread, three threads--> ring of page-locked chunks --H2D--> k_inflate + k_gi_crc (gpu_inflate.hip) --> the uncompressed stream, in device memory
 //        --> k_gb_walk: where the records are        --> k_gb_decode: the fixed columns + where each record's payload goes
 //        --> k_gb_copy: bases / qualities / CIGARs into packed columns (device)   --> D2H of the fixed columns only (26 B per read)
 //
@@ -9,15 +9,18 @@
 // record start in its segment (the first offset at which three records in a row look like records) and walks from there to the
 // segment's end; the host then checks, segment by segment, that every guess is exactly where the previous segment's walk
 // arrived — by induction from the known first record the chain is then the serial walk's; a segment whose guess is not there
-// is walked again, alone, from the known position.  A record the host reader has a rule for beyond the plain case (corrupt, a read
-// group that is not in the header, a second NM tag, ...) makes next_batch return kUnsupported: the caller starts over with the
-// host reader, which is the one to decide what the user is told.
+// is walked again, alone, from the known position.  A BATCH that holds a record the host reader has a rule for beyond the plain case
+// (a read group that is not in the header, a second NM tag, no RG tag, ...) is decoded by the host reader's own code
+// (bam_decode_records) from the bytes on the card; a walk that cannot be verified, a corrupt record or a file that ends inside a
+// record make next_batch return kUnsupported: the caller starts over with the host reader, which is the one to decide what the
+// user is told.
 //
-// The file is taken in few, large RUNS of BGZF blocks (an inflate launch costs 20-50 ms whatever the number of blocks: gpu_inflate.hip):
-// a producer thread reads (the first run while the HIP runtime is still starting), copies and launches on one stream; next_batch
-// walks and decodes the current run's window on another; what a run leaves over (an unfinished record) is copied in front of the
-// next run's bytes.  Every buffer is allocated in open(): allocations, releases and page-locking behind a running inflate kernel
-// wait for it.
+// The file — or one worker's byte range of it (set_range: the multi-GPU program) — is taken in few, large RUNS of BGZF blocks (an
+// inflate launch costs 20-50 ms whatever the number of blocks: gpu_inflate.hip): reader threads fill a ring of page-locked chunks, a
+// producer thread parses the block headers, copies and launches on one stream (the first run is read while the HIP runtime is
+// still starting); next_batch walks and decodes the current run's window on another; what a run leaves over (an unfinished
+// record) is copied in front of the next run's bytes.  Every buffer is allocated in open(): allocations, releases and page-locking
+// behind a running inflate kernel wait for it.
 //
 // Record layout, tag types: the public SAM/BAM specification; the rules applied to a record are those of the host reader
 // (bam_io.cpp: next_batch, citing bamqualcheck.cpp:72-100 getLane, QualityCheck.hpp:201-209 NM, TripletCounting.hpp:113-127 AS).
@@ -359,7 +362,6 @@ struct GpuBamReader::Impl {
     // a shard of the file (GpuBamReader::set_range): the producer reads from begin_off on and notes where the block at mark_off
     // lies in the uncompressed stream; behind it only small runs follow (the consumer wants the rest of one record)
     uint64_t begin_off = 0, mark_off = UINT64_MAX;
-    uint64_t read_off = 0;      // (producer) file offset of the next byte to read
     uint64_t parsed_off = 0;    // (producer) file offset of the next block header to parse
     uint64_t u_produced = 0;    // (producer) uncompressed bytes of the runs before the current one
     std::atomic<uint64_t> mark_abs{UINT64_MAX}; // the mark in the uncompressed stream, once the producer has got there
@@ -379,7 +381,6 @@ struct GpuBamReader::Impl {
     std::condition_variable cv;
     bool stop = false;
     uint64_t produced = 0, taken = 0, freed = 0; // runs handed over / taken by the consumer / given back (run k lives in runs[k % kRuns])
-    std::vector<uint8_t> tail;           // partial block behind the last run
     bool file_eof = false;
     // consumer: the window [cur, end) of the current run's buffer
     GbRun* cur_run = nullptr;
@@ -507,7 +508,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         I.need_locate = I.begin_off != 0;
         if (I.begin_off) first_record_u = 0; // (the header lies in the first shard)
     }
-    I.read_off = I.parsed_off = I.begin_off;
+    I.parsed_off = I.begin_off;
     I.skip_u = first_record_u;
     I.n_ref = (int32_t)hdr.ref_names.size();
     { // (the sizes the producer works with are final before it starts)
