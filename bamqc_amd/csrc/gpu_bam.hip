@@ -61,6 +61,8 @@ struct GbCols { // device copies of the fixed columns + per-record payload place
 struct GbLanes { const uint8_t* blob; const uint32_t* off; const uint32_t* len; const uint32_t* index; uint32_t n, lane_count; };
 
 typedef uint32_t __attribute__((aligned(1))) gb_u32_u;
+typedef uint32_t gb_u32x4 __attribute__((ext_vector_type(4)));
+typedef gb_u32x4 __attribute__((aligned(1))) gb_u32x4_u;
 typedef uint16_t __attribute__((aligned(1))) gb_u16_u;
 
 namespace {
@@ -245,9 +247,18 @@ __global__ __launch_bounds__(256) void k_gb_copy(const uint8_t* __restrict__ bas
     uint8_t* dc = cigar + 4ull * C.co[i];
     uint8_t* ds = seq + C.so[i];
     uint8_t* dq = qual + C.qo[i];
-    for (uint32_t k = lane; k < 4u * n_cig; k += 64) dc[k] = cg[k];
-    for (uint32_t k = lane; k < (l_seq + 1u) / 2u; k += 64) ds[k] = sq[k];
-    for (uint32_t k = lane; k < l_seq; k += 64) dq[k] = ql[k];
+    // sixteen bytes per lane and step while a kilobyte is left (long reads), then four (unaligned loads and stores), the last 1-3
+    // bytes one by one
+    auto copy = [&](uint8_t* d, const uint8_t* s_, uint32_t n_bytes) {
+        uint32_t at = 0;
+        for (; at + 1024u <= n_bytes; at += 1024u) *(gb_u32x4_u*)(d + at + 16u * lane) = *(const gb_u32x4_u*)(s_ + at + 16u * lane);
+        const uint32_t whole = n_bytes & ~3u;
+        for (uint32_t k = at + 4u * lane; k < whole; k += 256u) *(gb_u32_u*)(d + k) = *(const gb_u32_u*)(s_ + k);
+        if (lane < (n_bytes & 3u)) d[whole + lane] = s_[whole + lane];
+    };
+    copy(dc, cg, 4u * n_cig);
+    copy(ds, sq, (l_seq + 1u) / 2u);
+    copy(dq, ql, l_seq);
 }
 
 // ---------------------------------------------------------------------------------------------------
