@@ -204,6 +204,7 @@ extern "C" int bqc_reserve_references(bqc_ctx* c, uint64_t total_bases, uint32_t
     if (hipMalloc((void**)&c->ref_arena, cap) != hipSuccess) { (void)hipGetLastError(); c->ref_arena = nullptr; return 0; } // (not fatal: the contigs are then allocated one by one)
     c->ref_arena_cap = cap;
     c->ref_arena_used = 0;
+    if (!c->ref_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ref_stream, hipStreamNonBlocking)); // (a process's streams cost 10-30 ms each to create: now, not beside running kernels)
     return 0;
 }
 

@@ -954,6 +954,11 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         const auto c2 = clk::now();
         rc = bqc_create(&bo, &ctx);
         if (rc) create_err = bqc_last_error(nullptr);
+        else if (!shard) { // one allocation for the contigs, sized from the BAM header, while nothing runs on the card yet (an allocation beside running kernels waits for them)
+            uint64_t total = 0;
+            for (uint32_t r = 0; r < n_refs; ++r) total += H.ref_lens[r];
+            (void)bqc_reserve_references(ctx, total, n_refs);
+        }
         t_create_s = secs(c0, clk::now());
         t_c_warm = secs(c0, c1); t_c_reader = secs(c1, c2); t_c_create = secs(c2, clk::now());
     });
@@ -995,12 +1000,6 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs and a stream of
     // its own for the copies.
     const bool refs_beside_loop = bg_refs && getenv("BQC_BG_REFS") && getenv("BQC_BG_REFS")[0] == '1';
-    if (bg_refs) { // (one allocation now: an allocation beside running kernels waits for them)
-        uint64_t total = 0;
-        uint32_t nc = 0;
-        for (uint32_t r = 0; r < n_refs; ++r) if (fasta_index[r] >= 0) { total += fa[fasta_index[r]].codes.size(); ++nc; }
-        (void)bqc_reserve_references(ctx, total, nc);
-    }
     if (bg_refs) ref_loader = std::thread([&] {
         for (uint32_t r = 0; r < n_refs; ++r) {
             uint8_t st = 1;
