@@ -183,7 +183,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     for (auto p : c->d_ref) if (p && !in_arena(p)) (void)hipFree(p);
     for (auto p : c->d_refn) if (p && !in_arena(p)) (void)hipFree(p);
     if (c->ref_arena) (void)hipFree(c->ref_arena);
-    if (c->ref_stream) (void)hipStreamDestroy(c->ref_stream);
+
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
     (void)hipFree(c->d_state); (void)hipFree(c->d_err0); (void)hipFree(c->d_cursor); (void)hipFree(c->d_fasta_index); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_t8used); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
@@ -204,7 +204,6 @@ extern "C" int bqc_reserve_references(bqc_ctx* c, uint64_t total_bases, uint32_t
     if (hipMalloc((void**)&c->ref_arena, cap) != hipSuccess) { (void)hipGetLastError(); c->ref_arena = nullptr; return 0; } // (not fatal: the contigs are then allocated one by one)
     c->ref_arena_cap = cap;
     c->ref_arena_used = 0;
-    if (!c->ref_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ref_stream, hipStreamNonBlocking)); // (a process's streams cost 10-30 ms each to create: now, not beside running kernels)
     return 0;
 }
 
@@ -215,7 +214,6 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
     auto in_arena = [&](const void* p) { return c->ref_arena && (const uint8_t*)p >= c->ref_arena && (const uint8_t*)p < c->ref_arena + c->ref_arena_cap; };
     if (c->d_ref[rid]) { if (!in_arena(c->d_ref[rid])) HIPCHK(c, hipFree(c->d_ref[rid])); c->d_ref[rid] = nullptr; }
     if (c->d_refn[rid]) { if (!in_arena(c->d_refn[rid])) HIPCHK(c, hipFree(c->d_refn[rid])); c->d_refn[rid] = nullptr; }
-    if (!c->ref_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->ref_stream, hipStreamNonBlocking));
     const uint64_t nd8 = (len + 7) / 8; // nibble table of the fast path: BQC_FAST_NH pad dwords + nd8 + BQC_FAST_NH pad dwords
     const size_t b1 = ((len ? len : 1) + 255) & ~(size_t)255, b2 = ((nd8 + 2 * BQC_FAST_NH) * 4 + 255) & ~(size_t)255;
     uint8_t* p = nullptr;
@@ -228,11 +226,11 @@ extern "C" int bqc_set_reference(bqc_ctx* c, int32_t rid, const uint8_t* dna5, u
         HIPCHK(c, hipMalloc(&p, len ? len : 1));
         HIPCHK(c, hipMalloc(&pn, (nd8 + 2 * BQC_FAST_NH) * 4));
     }
-    // the bulk copy and the nibble kernel on a stream of their own: batches that run meanwhile (another thread's, on contigs that
-    // are there already) are not waited for; only the three small pointer tables go through the batches' stream
-    HIPCHK(c, hipMemcpyAsync(p, dna5, len, hipMemcpyHostToDevice, c->ref_stream));
-    bqc_launch_ref_nibbles(p, len, pn, nd8, c->ref_stream);
-    HIPCHK(c, hipStreamSynchronize(c->ref_stream));
+    // (a plain synchronous copy from the caller's pageable memory: 8.9 GB/s for a human genome's 3.1 GB — measured in round 3 against
+    // hipMemcpyAsync on a stream of its own, 4.8 GB/s, and against page-locking the contigs first, 4-5 GB/s all told)
+    HIPCHK(c, hipMemcpy(p, dna5, len, hipMemcpyHostToDevice));
+    bqc_launch_ref_nibbles(p, len, pn, nd8, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->d_ref[rid] = p;
     c->d_refn[rid] = pn;
     c->ref_len[rid] = len;

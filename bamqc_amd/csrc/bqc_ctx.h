@@ -133,7 +133,6 @@ struct bqc_ctx {
     // caller that uploads contigs while batches run reserves first); pointers inside it are not released one by one
     uint8_t* ref_arena = nullptr;
     size_t ref_arena_cap = 0, ref_arena_used = 0;
-    hipStream_t ref_stream = nullptr;        // bulk copies and the nibble kernel of bqc_set_reference: beside the batches' streams
     std::vector<uint32_t*> d_refn; // one-hot nibble copy for the short-read fast path
     std::vector<uint64_t> ref_len;
     uint8_t** d_ref_ptrs = nullptr;

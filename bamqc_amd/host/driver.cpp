@@ -997,8 +997,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // BQC_BG_REFS=1: the uploader runs BESIDE the record loop (which then starts 0.35 s earlier).  Measured on a 100 M-read file over a
     // human-sized genome: the loop itself becomes 0.5-0.6 s longer (1.45-1.55 s against 0.9), from pageable and from page-locked memory
     // alike — page-locking and large copies beside running inflate kernels hold up the other threads' calls into the runtime — so by
-    // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs and a stream of
-    // its own for the copies.
+    // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs, made with the context.
     const bool refs_beside_loop = bg_refs && getenv("BQC_BG_REFS") && getenv("BQC_BG_REFS")[0] == '1';
     if (bg_refs) ref_loader = std::thread([&] {
         for (uint32_t r = 0; r < n_refs; ++r) {
