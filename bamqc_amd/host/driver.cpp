@@ -999,7 +999,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     // alike — page-locking and large copies beside running inflate kernels hold up the other threads' calls into the runtime — so by
     // default the uploader is waited for before the loop starts; what is kept of it: one allocation for all contigs, made with the context.
     const bool refs_beside_loop = bg_refs && getenv("BQC_BG_REFS") && getenv("BQC_BG_REFS")[0] == '1';
-    if (bg_refs) ref_loader = std::thread([&] {
+    auto upload_all = [&] {
         for (uint32_t r = 0; r < n_refs; ++r) {
             uint8_t st = 1;
             if (fasta_index[r] >= 0 && !ref_stop.load()) {
@@ -1015,8 +1015,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
             { std::lock_guard<std::mutex> lk(ref_m); ref_state[r] = st; }
             ref_cv.notify_all();
         }
-    });
-    if (bg_refs && !refs_beside_loop && ref_loader.joinable()) ref_loader.join();
+    };
+    if (bg_refs && refs_beside_loop) ref_loader = std::thread(upload_all);
+    else if (bg_refs) upload_all(); // (in this thread, before the loop: the default)
     auto destroy_ctx = [&]() { // (every way out: the uploader first, it uses the context)
         ref_stop = true;
         if (ref_loader.joinable()) ref_loader.join();
