@@ -465,7 +465,7 @@ struct GpuBamReader::Impl {
     static const int kSlots = 6, kReaders = 3;
     static constexpr size_t kHeadroom = 1u << 17;
     Slot slots[kSlots];
-    size_t chunk_bytes = 8u << 20; // (six of them are page-locked in open(): 172 ms per GB)
+    size_t chunk_bytes = 16u << 20; // (six of them are page-locked in open(): 16 ms; with 8 MB chunks the loop of a 54 GB file was 0.2 s longer)
     std::vector<std::thread> readers;
     std::mutex rm;
     std::condition_variable rcv;
