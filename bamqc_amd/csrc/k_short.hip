@@ -283,8 +283,16 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         const uint32_t cpw = (n_chunks + gridDim.x - 1) / gridDim.x;
         t8_period = max(t8_period, (cpw + BQC_T8_SPW - 2) / (BQC_T8_SPW - 1));
     }
-    for (uint32_t ci = blockIdx.x;; ci += gridDim.x) { // one extra pass at the end flushes the last lane (single call site)
-        const bool done = ci >= n_chunks;
+    // Which chunks a workgroup walks.  Workgroup ids go round the eight XCDs (id % 8), each with an L2 of its own, and neighbouring
+    // chunks share lines (the columns of one stretch of the stream, the reference under it): with parts bit 16 an XCD's workgroups
+    // take one CONTIGUOUS eighth of the chunk table, so that a line two chunks share is fetched into one L2, not two.
+    uint32_t ci = blockIdx.x, ci_step = gridDim.x, ci_end = n_chunks;
+    if ((parts & 16u) && (gridDim.x & 7u) == 0u && n_chunks >= gridDim.x) {
+        const uint32_t per = (n_chunks + 7u) >> 3, lo = (blockIdx.x & 7u) * per;
+        ci = lo + (blockIdx.x >> 3); ci_step = gridDim.x >> 3; ci_end = min(n_chunks, lo + per);
+    }
+    for (;; ci += ci_step) { // one extra pass at the end flushes the last lane (single call site)
+        const bool done = ci >= ci_end;
         Chunk ch{0, 0, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         if (!done) ch = b.chunks_fast[ci];
         if (ch.lane != cur_lane) { // block-uniform
@@ -647,7 +655,12 @@ extern "C" void bqc_launch_ref_nibbles(const uint8_t* dna5, uint64_t len, uint32
 extern "C" uint32_t bqc_short_parts()
 {
     static uint32_t parts = 0xFFFFFFFFu;
-    if (parts == 0xFFFFFFFFu) { const char* e = getenv("BQC_SHORT_PARTS"); parts = e ? (uint32_t)atoi(e) : 15u; }
+    if (parts == 0xFFFFFFFFu) {
+        const char* e = getenv("BQC_SHORT_PARTS");
+        parts = e ? (uint32_t)atoi(e) : 15u;
+        const char* x = getenv("BQC_SHORT_XCD"); // 1: an XCD's workgroups take a contiguous eighth of the chunks (see k_short)
+        if (x && atoi(x) != 0) parts |= 16u;
+    }
     return parts;
 }
 

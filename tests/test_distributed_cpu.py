@@ -102,3 +102,26 @@ def test_byte_range_shards_partition_the_record_stream(tmp_path):
     good = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, BQC_TEST_SHARD_SKEW="1"))
     assert good.returncode == 0 and bad.returncode == 0 and good.stdout != bad.stdout
+
+
+def test_cxx_launcher_without_a_gpu_fails_cleanly(tmp_path):
+    """`bamqualcheck --gpus 2` on a box without a GPU: every worker fails at context creation, reports through the shard hook, the
+    front end tells all of them to stop and returns 1 — no worker is left waiting for the others (the coordinator's error path;
+    the success paths need a card: tests/test_gpu_sharded.py)."""
+    import subprocess
+    import torch
+    from bamqc_amd import hostio
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box WITHOUT a GPU")
+    bam, fa = str(tmp_path / "s.bam"), str(tmp_path / "s.fa")
+    hostio.synth_write(bam, fa, seed=3, n_reads=5000, ref_names=["chr1"], ref_lens=[200_000])
+    exe = os.path.join(ROOT, "bin", "bamqualcheck")
+    for env in ({}, {"BQC_REDUCE": "pipe"}):
+        r = subprocess.run([exe, "--gpus", "2", "-r", fa, "-o", str(tmp_path / "o.bamqc"), "-c", "chr1", bam], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1, (r.stdout, r.stderr)
+        assert "no HIP device" in r.stderr or "hipSetDevice" in r.stderr
+    r = subprocess.run([exe, "--gpus", "3", "--version"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.count("bamqualcheck version") == 1  # answered once, by the front end
+    r = subprocess.run([exe, "--gpus", "0", "-r", fa, "-o", str(tmp_path / "o.bamqc"), bam], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--gpus" in r.stderr
