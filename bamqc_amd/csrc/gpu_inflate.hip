@@ -96,22 +96,18 @@ struct Bits { // bit reader over [in, end): the two words behind the buffered on
     __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
 };
 
-// The output side of a lane.  Literals are gathered in a register and stored eight at a time; a match of up to 16 bytes at a distance
-// of 16 or more is one 16-byte load and one store (most matches of a BGZF level-1 stream are short: 6.7 bytes on average in the
-// synthetic files, and 96 % of the output comes from matches), longer ones 32 bytes per step, overlapping ones word- or byte-wise.
-// Stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
-//
-// Measured on a full card (45 K blocks in a launch, profiles/r3_inflate_*.json): the match copies are HALF of the kernel's time —
-// every lane copies from its own block's output, up to 32 KiB back, 45 K blocks x 64 KiB of output are 2.9 GB: the copies' loads miss
-// every cache, and the launch stops scaling with the number of blocks (without the copies: 23 ms for 45 K blocks, 28-32 ms for 90 K;
-// with them 46-49 and 93-96); literal stores cost nothing measurable (byte stores or eight at a time).  TWO PHASES (tokens != nullptr,
-// BQC_GI_TWO_PHASE=1) take the copies out of the lanes: a lane writes its literals to their final places and lists its matches as
-// 4-byte tokens; k_inflate_resolve then takes every block's output through LDS, a workgroup per block, and resolves the matches
-// there.  That is correct (the tests run it) and SLOWER: a block has 9 300 matches whose dependence chains (a match copies what the
-// match before it wrote) are ~775 links long, and a link costs a round of the resolve kernel — 65 ms for 45 K blocks with rounds
-// between workgroup barriers, 83 ms with a bitmap of final bytes and no barriers (1 457 rounds per wave at ~1 500 cycles), against the
-// 25 ms the copies cost inside the lanes.  It stays selectable; the default is one phase.  Token (8 bytes): where the match goes
-// (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32.  A block of u bytes has at most u / 3 matches.
+// The output side of a lane.  Literals are gathered in a register and stored eight at a time.  Matches: measured on a full card (45 K
+// blocks in a launch, profiles/r3_inflate_*.json), copying them inside the lanes is HALF of the kernel's time — every lane copies from
+// its own block's output, up to 32 KiB back, 45 K blocks x 64 KiB of output are 2.9 GB: the copies' loads miss every cache (FETCH_SIZE
+// 20 GB for 2.7 GB of algorithmic bytes), and the launch stops scaling with the number of blocks (without the copies: 23 ms for 45 K
+// blocks, 28-32 ms for 90 K; with them 46-49 and 93-96); literal stores cost nothing measurable.  So the work is done in TWO PHASES
+// (the default; BQC_GI_TWO_PHASE=0: one): a lane writes its literals to their final places and lists its matches as 8-byte tokens —
+// where the match goes (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32; a block of u bytes has at most u / 3 —
+// and k_inflate_resolve (below) fills the matches in, a workgroup per block, by pointer jumping in LDS: 36 ms for 45 K blocks
+// instead of 49, 56-67 ms for 90 K instead of 98.  With tokens == nullptr the lane copies its matches itself: up to 16 bytes at a
+// distance of 16 or more are one 16-byte load and one store (most matches of a BGZF level-1 stream are short: 6.7 bytes on average in
+// the synthetic files, and 90-96 % of the output comes from matches), longer ones 32 bytes per step, overlapping ones word- or
+// byte-wise; stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
 struct Out {
     uint8_t* o0;
     uint32_t usize;
@@ -630,86 +626,66 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 }
 
 // ---------------------------------------------------------------------------------------------------
-// phase 2: the matches of a block, resolved in LDS
+// phase 2: the matches of a block, resolved by pointer jumping
 // ---------------------------------------------------------------------------------------------------
-// A workgroup (four waves) per block: the block's output (literals in place, the matches' bytes still missing) comes into LDS,
-// beside it a BITMAP with a bit per byte: "final".  Literals are final from the start (the matches' destinations are cleared in a
-// first pass over the tokens); thread t takes the tokens t, t + 256, ... and in every round copies up to 16 bytes of its current match
-// if the bits of the bytes it would read are all set — the data first, then the bits of what it wrote (LDS operations of a wave
-// execute in order, the waves see each other's work through the bitmap: there is no barrier in the loop).  A byte is written
-// once, so a set bit stays true; the earliest unresolved match of the block can always go on (everything in front of it is
-// final), so somebody always makes progress.  An overlapping match (distance < length: run-length data) advances by its distance
-// per round, reading what it wrote the round before.
-// Measured: 83 ms for 45 K blocks — 1 457 rounds per wave at ~1 500 cycles (about 300 instructions: sixteen predicated byte reads
-// and writes), for dependence chains of ~775 links per block; the first version of this kernel (thread per token in chunks of 256,
-// rounds between workgroup barriers, dependence ranges by binary search) took 65 ms.  The bound is the chain: a link costs at least
-// an LDS round trip, ~40 us per block, 3-4 ms for 45 K blocks on 512 resident blocks — neither version is near it.
-__global__ __launch_bounds__(256) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint64_t* __restrict__ tokens,
-                                                          const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
+// A match says "byte p is byte p - distance"; following that from byte to byte ends at a literal, which phase 1 has written.  A
+// workgroup of 1024 threads per block keeps ONE 16-bit index per output byte in LDS (128 KB): a literal points at itself, a match
+// byte at its source (one pass over the tokens); then every byte's index is replaced by its index's index — idx[p] = idx[idx[p]] —
+// until nothing changes: the length of every chain halves per round, so a block is done in at most 16 rounds whatever its chains look
+// like (the dependence chains of the synthetic level-1 streams are ~775 matches long: the two kernels that FOLLOWED them — a round
+// per link, between workgroup barriers or through a bitmap of final bytes — took 65 and 83 ms for 45 K blocks).  Reading an index
+// that another thread is just replacing is harmless: old and new value are both ancestors.  Last, every match byte is fetched from
+// its literal (a gather inside the block's 64 KiB, which the workgroup has just touched) and stored, four bytes per thread.
+__global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint64_t* __restrict__ tokens,
+                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
 {
-    extern __shared__ uint8_t rbuf[]; // [65536] the block, then [2048 + 2] words of bitmap
-    uint32_t* const bm = (uint32_t*)(rbuf + 65536);
+    extern __shared__ uint16_t ridx[]; // [65536]
     const uint32_t bi = blockIdx.x, tid = threadIdx.x;
     if (bi >= n_blocks) return;
     const uint32_t n = ntok[bi];
     if (n == 0u) return; // no match in this block (or it failed): phase 1 has written all of it
     const GiBlock blk = blocks[bi];
     uint8_t* const o0 = out + blk.uoff;
-    const uint32_t usize = blk.usize;
+    const uint32_t usize = blk.usize, upad = (usize + 7u) & ~7u;
     const uint64_t* const tk = tokens + gi_tok_base(blocks, bi);
-    for (uint32_t i = tid * 16u; i < usize; i += 256u * 16u) *(gi_u32x4*)(rbuf + i) = *(const gi_u32x4_u*)(o0 + i); // (may read up to 15 bytes of the next block: not used)
-    for (uint32_t i = tid; i < 2050u; i += 256u) bm[i] = 0xFFFFFFFFu;
+    uint32_t* const pair = (uint32_t*)ridx;
+    for (uint32_t q = tid; q < upad / 2u; q += 1024u) pair[q] = (2u * q) | ((2u * q + 1u) << 16); // every byte its own root
     __syncthreads();
-    for (uint32_t t = tid; t < n; t += 256u) { // the matches' destinations are not final yet
+    for (uint32_t t = tid; t < n; t += 1024u) { // match bytes point at their sources
         const uint64_t k = tk[t];
-        uint32_t d = (uint32_t)k & 0xFFFFu, len = (uint32_t)(k >> 16) & 0xFFFFu;
-        if (d + len > usize) len = usize > d ? usize - d : 0u; // (phase 1 has checked it; a damaged token must not reach outside)
-        while (len) {
-            const uint32_t w = d >> 5, sft = d & 31u, c = min(len, 32u - sft);
-            atomicAnd(&bm[w], ~((c == 32u ? 0xFFFFFFFFu : (1u << c) - 1u) << sft));
-            d += c; len -= c;
-        }
+        const uint32_t d = (uint32_t)k & 0xFFFFu, len = (uint32_t)(k >> 16) & 0xFFFFu, dist = (uint32_t)(k >> 32);
+        if (dist == 0u || dist > d || d + len > usize) continue; // (phase 1 has checked it; a damaged token must not reach outside)
+        for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
     }
     __syncthreads();
-    uint32_t t = tid, dst = 0, src = 0, rem = 0, dist = 1;
-    uint64_t nxt = t < n ? tk[t] : 0ull;
-    auto take = [&]() { // the prefetched token becomes the current one; the one after it is requested
-        dst = (uint32_t)nxt & 0xFFFFu; rem = (uint32_t)(nxt >> 16) & 0xFFFFu; dist = (uint32_t)(nxt >> 32);
-        if (dist == 0u || dist > dst || dst + rem > usize) rem = 0; // (see above)
-        src = dst - dist;
-        nxt = t + 256u < n ? tk[t + 256u] : 0ull;
-    };
-    bool have = t < n;
-    if (have) take();
-    unsigned long long rounds = 0;
-    while (__ballot(have)) {
-        ++rounds;
-        if (have) {
-            if (rem == 0u) { t += 256u; have = t < n; if (have) take(); }
-            else {
-                const uint32_t need = min(min(rem, 16u), dist);
-                const uint32_t w = src >> 5, sft = src & 31u;
-                const uint32_t bits = (uint32_t)(((uint64_t)bm[w] | ((uint64_t)bm[w + 1u] << 32)) >> sft), mask = (1u << need) - 1u;
-                if ((bits & mask) == mask) {
-                    uint8_t v[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) if ((uint32_t)j < need) v[j] = rbuf[src + j];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) if ((uint32_t)j < need) rbuf[dst + j] = v[j];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the bytes before their bits
-                    const uint32_t dw = dst >> 5, ds = dst & 31u;
-                    atomicOr(&bm[dw], mask << ds);
-                    if (ds + need > 32u) atomicOr(&bm[dw + 1u], mask >> (32u - ds));
-                    src += need; dst += need; rem -= need;
-                }
-            }
+    uint32_t rounds = 0;
+    for (; rounds < 16u; ++rounds) {
+        uint32_t changed = 0;
+#pragma unroll 4
+        for (uint32_t q = tid; q < upad / 2u; q += 1024u) {
+            const uint32_t v = pair[q], a = v & 0xFFFFu, b = v >> 16;
+            const uint32_t a2 = ridx[a], b2 = ridx[b];
+            changed |= (a2 ^ a) | (b2 ^ b);
+            pair[q] = a2 | (b2 << 16);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (the bitmap is read again in the next round)
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
-    if (stats && (tid & 63u) == 0u) { atomicAdd(&stats[2], rounds); if (tid == 0u) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); } }
-    __syncthreads();
-    for (uint32_t i = tid * 16u; i + 16u <= usize; i += 256u * 16u) *(gi_u32x4_u*)(o0 + i) = *(const gi_u32x4*)(rbuf + i);
-    for (uint32_t i = (usize & ~15u) + tid; i < usize; i += 256u) o0[i] = rbuf[i];
+    if (stats && tid == 0u) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); atomicAdd(&stats[2], (unsigned long long)rounds); }
+    // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte)
+    for (uint32_t p = 4u * tid; p < usize; p += 4096u) {
+        const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
+        const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
+        if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
+        if (p + 4u <= usize) {
+            const uint32_t w = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24);
+            *(gi_u32_u*)(o0 + p) = w;
+        } else {
+            const uint32_t ii[4] = {i0, i1, i2, i3};
+            uint8_t vv[4];
+            for (uint32_t j = 0; p + j < usize; ++j) vv[j] = o0[ii[j]];
+            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = vv[j];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -784,7 +760,7 @@ __global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out,
 
 // launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out (the blocks' outputs back to
 // back); d_tok: 4 bytes x (inflated bytes / 3 + 2 x blocks) of scratch for the tokens, d_ntok: 4 bytes per block
-extern "C" int bqc_gpu_inflate_two_phase() { return getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) != 0 ? 1 : 0; }
+extern "C" int bqc_gpu_inflate_two_phase() { return getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) == 0 ? 0 : 1; } // (default: two phases)
 // (4-byte words: a token is 8 bytes; 64 words when the two phases are off: nothing is listed then)
 extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return bqc_gpu_inflate_two_phase() ? 2 * (inflated_bytes / 3 + 2 * n_blocks + 64) : 64; }
 
@@ -796,7 +772,7 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
     // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
     const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 2052 * 4);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 64);
     (void)attr;
     const bool two_phase = bqc_gpu_inflate_two_phase() != 0; // (see the comment at struct Out)
     if (!two_phase || !d_ntok) d_tok = nullptr;
@@ -814,12 +790,12 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
         atexit([] {
             unsigned long long h[8] = {};
             if (hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu wave-rounds\n", h[0], h[7], h[2]);
+                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu rounds\n", h[0], h[7], h[2]);
         });
         return true;
     }();
     (void)want_stats;
-    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 65536 + 2052 * 4, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
+    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), 131072 + 64, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 
