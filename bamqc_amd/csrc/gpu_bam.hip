@@ -848,7 +848,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timing = this->timing && atoi(getenv("BQC_GB_TIMING")) >= 2; // (2: the kernels of every run, waited for)
     if (timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, R.s); }
-    bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, R.d_out.p, R.d_crc.p, R.d_status, R.d_tok.p, R.d_ntok.p, R.s);
+    bqc_gpu_inflate_launch(R.d_comp.p, R.d_blocks.p, (uint32_t)nb, utotal, R.d_out.p, R.d_crc.p, R.d_status, R.d_tok.p, R.d_ntok.p, R.s);
     if (timing) (void)hipEventRecord(e1, R.s);
     if (hipEventRecord(R.ready, R.s) != hipSuccess) R.rc = -2;
     if (timing) { // (waits: only with BQC_GB_TIMING)

@@ -23,7 +23,7 @@ void bqc_gpu_inflater_destroy(GpuInflater* g);
 // bqc_gpu_inflate_token_words(inflated bytes, blocks) and 4 bytes x blocks
 size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks);
 int bqc_gpu_inflate_two_phase(); // BQC_GI_TWO_PHASE
-void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, uint32_t* d_tok, uint32_t* d_ntok,
-                            void* stream);
+void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint64_t total_out, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status,
+                            uint32_t* d_tok, uint32_t* d_ntok, void* stream);
 int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_bytes, const GiBlock* blocks, size_t n_blocks, uint8_t* out, size_t out_bytes);
 }

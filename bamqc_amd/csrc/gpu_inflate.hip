@@ -101,10 +101,10 @@ struct Bits { // bit reader over [in, end): the two words behind the buffered on
 // its own block's output, up to 32 KiB back, 45 K blocks x 64 KiB of output are 2.9 GB: the copies' loads miss every cache (FETCH_SIZE
 // 20 GB for 2.7 GB of algorithmic bytes), and the launch stops scaling with the number of blocks (without the copies: 23 ms for 45 K
 // blocks, 28-32 ms for 90 K; with them 46-49 and 93-96); literal stores cost nothing measurable.  So the work is done in TWO PHASES
-// (the default; BQC_GI_TWO_PHASE=0: one): a lane writes its literals to their final places and lists its matches as 8-byte tokens —
-// where the match goes (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32; a block of u bytes has at most u / 3 —
-// and k_inflate_resolve (below) fills the matches in, a workgroup per block, by pointer jumping in LDS: 36 ms for 45 K blocks
-// instead of 49, 56-67 ms for 90 K instead of 98.  With tokens == nullptr the lane copies its matches itself: up to 16 bytes at a
+// (the default; BQC_GI_TWO_PHASE=0: one): a lane writes its literals to their final places and, for a match, leaves distance and length
+// in the first three of the bytes the match will fill (a match is at least three bytes long) and sets the bit of its first byte in a
+// bitmap; k_inflate_resolve (below) fills the matches in, a workgroup per block, by pointer jumping in LDS: 36 ms for 45 K blocks
+// instead of 49, 56-67 ms for 90 K instead of 98.  With bm == nullptr the lane copies its matches itself: up to 16 bytes at a
 // distance of 16 or more are one 16-byte load and one store (most matches of a BGZF level-1 stream are short: 6.7 bytes on average in
 // the synthetic files, and 90-96 % of the output comes from matches), longer ones 32 bytes per step, overlapping ones word- or
 // byte-wise; stores may run past the current end of the output — never past the block's — and are overwritten by what follows.
@@ -114,8 +114,9 @@ struct Out {
     uint32_t o;      // bytes produced (in two phases: matches counted, not copied), pending literals included
     uint32_t nlit;   // literals held in `lit` (0..7): the bytes o - nlit .. o - 1
     uint64_t lit;
-    uint64_t* tok;   // this block's tokens; nullptr: one phase, the lane copies its matches itself
-    uint32_t ntok;
+    uint32_t* bm;    // two phases: this block's bitmap of match starts (bit p: a match begins at byte p); nullptr: one phase
+    uint32_t bmi, bmw; // the bitmap word being filled and its index (the words are visited in ascending order; the bitmap was zeroed)
+    uint32_t nmatch;
     __device__ __forceinline__ void flush()
     {
         if (!nlit) return;
@@ -134,8 +135,17 @@ struct Out {
     __device__ __forceinline__ void match(uint32_t length, uint32_t dist) // (the caller has checked dist <= o, o + length <= usize)
     {
         flush(); // (the literals in front of the match; those behind it start a new register)
-        if (tok) { // token: where it goes (16 bits: a block is at most 64 KiB) | length << 16 | distance << 32
-            tok[ntok++] = (uint64_t)o | ((uint64_t)length << 16) | ((uint64_t)dist << 32);
+        if (bm) {
+            // the match is not copied: its description goes where its first three bytes will be (a match is at least three bytes long) —
+            // distance - 1 in 15 bits, length - 3 in the third byte — and its start is marked in the block's bitmap
+            const uint32_t tok = (dist - 1u) | ((length - 3u) << 16);
+            uint8_t* d = o0 + o;
+            if (o + 4u <= usize) *(gi_u32_u*)d = tok; // (the fourth byte belongs to what follows and is written after this)
+            else { d[0] = (uint8_t)tok; d[1] = (uint8_t)(tok >> 8); d[2] = (uint8_t)(tok >> 16); }
+            const uint32_t w = o >> 5;
+            if (w != bmi) { if (bmw) bm[bmi] = bmw; bmi = w; bmw = 0; }
+            bmw |= 1u << (o & 31u);
+            ++nmatch;
             o += length;
             return;
         }
@@ -158,10 +168,12 @@ struct Out {
             for (uint32_t k = 0; k < length; ++k) dst[k] = src[k];
         }
     }
+    __device__ __forceinline__ void finish() { flush(); if (bm && bmw) bm[bmi] = bmw; }
 };
 
-// where block bi's tokens start: the blocks of a launch lie back to back in the output, a block of u bytes has at most u / 3 matches
-__device__ __forceinline__ uint64_t gi_tok_base(const GiBlock* __restrict__ blocks, uint32_t bi) { return (blocks[bi].uoff - blocks[0].uoff) / 3u + 2ull * bi; }
+// where block bi's bitmap of match starts begins (in 32-bit words): the blocks of a launch lie back to back in the output; a block of u
+// bytes gets at least ceil(u / 32) words of its own
+__device__ __forceinline__ uint64_t gi_bm_base(const GiBlock* __restrict__ blocks, uint32_t bi) { return ((blocks[bi].uoff - blocks[0].uoff) >> 5) + (uint64_t)bi; }
 
 template <int NL> __device__ __forceinline__ uint32_t lens_get(const uint16_t* L, uint32_t i) { const uint32_t v = L[GI_AT(GI_O_LENS + (i >> 2))]; return (v >> (4 * (i & 3))) & 15u; }
 template <int NL> __device__ __forceinline__ void lens_set(uint16_t* L, uint32_t i, uint32_t len)
@@ -245,7 +257,7 @@ template <int NL> __device__ __forceinline__ uint32_t decode_sym(const uint16_t*
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgpr(96))) void k_inflate(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint64_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint16_t lds16[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -257,7 +269,7 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, bitmap ? bitmap + gi_bm_base(blocks, bi) : nullptr, 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0; // 0 ok, else the reason (GI_ERR_*)
     for (;;) {
@@ -360,10 +372,10 @@ template <int NL> __global__ __launch_bounds__(NL) __attribute__((amdgpu_num_vgp
         }
         if (st || bfinal) break;
     }
-    O.flush();
+    O.finish();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC; // bits from beyond the stream were consumed
-    if (tokens) ntok[bi] = st ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (bitmap) ntok[bi] = st ? 0u : O.nmatch; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
@@ -433,7 +445,7 @@ __device__ __forceinline__ uint32_t canon_find(const Canon& C, uint32_t bits32, 
 } // namespace
 
 template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uint8_t* __restrict__ comp, const GiBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint64_t* __restrict__ tokens, uint32_t* __restrict__ ntok)
+                                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ ntok)
 {
     extern __shared__ uint8_t lds8[];
     const uint32_t bi = blockIdx.x * NL + threadIdx.x;
@@ -445,7 +457,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     Bits B;
     B.start(c0, cend);
     const uint32_t usize = blk.usize;
-    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, tokens ? tokens + gi_tok_base(blocks, bi) : nullptr, 0u};
+    Out O{out + blk.uoff, usize, 0u, 0u, 0ull, bitmap ? bitmap + gi_bm_base(blocks, bi) : nullptr, 0u, 0u, 0u};
     uint8_t* const o0 = O.o0;
     uint32_t st = 0;
     uint8_t lens[320]; // code lengths while the codes are built (private memory)
@@ -618,25 +630,28 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
         }
         if (st || bfinal) break;
     }
-    O.flush();
+    O.finish();
     if (!st && O.o != usize) st = GI_ERR_SIZE;
     if (!st && (uint64_t)(B.in - c0) * 8u - B.bc > (uint64_t)blk.csize * 8u) st = GI_ERR_TRUNC;
-    if (tokens) ntok[bi] = st ? 0u : O.ntok; // (0: nothing for phase 2 to do)
+    if (bitmap) ntok[bi] = st ? 0u : O.nmatch; // (0: nothing for phase 2 to do)
     if (st) atomicOr(status, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // phase 2: the matches of a block, resolved by pointer jumping
 // ---------------------------------------------------------------------------------------------------
-// A match says "byte p is byte p - distance"; following that from byte to byte ends at a literal, which phase 1 has written.  A
+// A match says "byte p is byte p - distance"; following that from byte to byte ends at a literal, which phase 1 has written.  Phase 1
+// leaves no list of matches: a match's distance and length sit in the first three bytes of its own (still empty) destination, and a
+// bitmap with a bit per output byte marks where matches start (1/8 of the output's size; a list of 8-byte tokens was as large as
+// the output: allocating and releasing 8 GB of it per run buffer cost the 10 M-read run 0.1 s and the next run 0.6 s).  A
 // workgroup of 1024 threads per block keeps ONE 16-bit index per output byte in LDS (128 KB): a literal points at itself, a match
-// byte at its source (one pass over the tokens); then every byte's index is replaced by its index's index — idx[p] = idx[idx[p]] —
+// byte at its source (one pass over the bitmap); then every byte's index is replaced by its index's index — idx[p] = idx[idx[p]] —
 // until nothing changes: the length of every chain halves per round, so a block is done in at most 16 rounds whatever its chains look
 // like (the dependence chains of the synthetic level-1 streams are ~775 matches long: the two kernels that FOLLOWED them — a round
 // per link, between workgroup barriers or through a bitmap of final bytes — took 65 and 83 ms for 45 K blocks).  Reading an index
 // that another thread is just replacing is harmless: old and new value are both ancestors.  Last, every match byte is fetched from
 // its literal (a gather inside the block's 64 KiB, which the workgroup has just touched) and stored, four bytes per thread.
-__global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint64_t* __restrict__ tokens,
+__global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ bitmap,
                                                            const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
 {
     extern __shared__ uint16_t ridx[]; // [65536]
@@ -647,15 +662,21 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
     const GiBlock blk = blocks[bi];
     uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize, upad = (usize + 7u) & ~7u;
-    const uint64_t* const tk = tokens + gi_tok_base(blocks, bi);
+    const uint32_t* const bm = bitmap + gi_bm_base(blocks, bi);
     uint32_t* const pair = (uint32_t*)ridx;
     for (uint32_t q = tid; q < upad / 2u; q += 1024u) pair[q] = (2u * q) | ((2u * q + 1u) << 16); // every byte its own root
     __syncthreads();
-    for (uint32_t t = tid; t < n; t += 1024u) { // match bytes point at their sources
-        const uint64_t k = tk[t];
-        const uint32_t d = (uint32_t)k & 0xFFFFu, len = (uint32_t)(k >> 16) & 0xFFFFu, dist = (uint32_t)(k >> 32);
-        if (dist == 0u || dist > d || d + len > usize) continue; // (phase 1 has checked it; a damaged token must not reach outside)
-        for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
+    for (uint32_t w = tid; w < (usize + 31u) / 32u; w += 1024u) { // match bytes point at their sources: the matches that start in word w of the bitmap
+        uint32_t bits = bm[w];
+        while (bits) {
+            const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            if (d + 3u > usize) continue;
+            const uint32_t tok = (uint32_t)o0[d] | ((uint32_t)o0[d + 1u] << 8) | ((uint32_t)o0[d + 2u] << 16); // phase 1 left the match's description in its first bytes
+            const uint32_t dist = (tok & 0x7FFFu) + 1u, len = (tok >> 16) + 3u;
+            if (dist > d || d + len > usize) continue; // (phase 1 has checked it; damaged memory must not reach outside)
+            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
+        }
     }
     __syncthreads();
     uint32_t rounds = 0;
@@ -759,13 +780,15 @@ __global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out,
 }
 
 // launches on device-resident operands (csrc/gpu_bam.hip): blocks[i].coff into comp, .uoff into out (the blocks' outputs back to
-// back); d_tok: 4 bytes x (inflated bytes / 3 + 2 x blocks) of scratch for the tokens, d_ntok: 4 bytes per block
+// back, total_out bytes from the first block's start to the last one's end); d_tok: 4 bytes x bqc_gpu_inflate_token_words() of
+// scratch (the bitmap of match starts), d_ntok: 4 bytes per block
 extern "C" int bqc_gpu_inflate_two_phase() { return getenv("BQC_GI_TWO_PHASE") && atoi(getenv("BQC_GI_TWO_PHASE")) == 0 ? 0 : 1; } // (default: two phases)
-// (4-byte words: a token is 8 bytes; 64 words when the two phases are off: nothing is listed then)
-extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return bqc_gpu_inflate_two_phase() ? 2 * (inflated_bytes / 3 + 2 * n_blocks + 64) : 64; }
+// 4-byte words of scratch for a launch: the bitmap of match starts, a bit per output byte and a word of slack per block (64 words when
+// the two phases are off)
+extern "C" size_t bqc_gpu_inflate_token_words(size_t inflated_bytes, size_t n_blocks) { return bqc_gpu_inflate_two_phase() ? inflated_bytes / 32 + n_blocks + 64 : 64; }
 
-extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint8_t* d_out, const uint32_t* d_crc, uint32_t* d_status, uint32_t* d_tok,
-                                       uint32_t* d_ntok, void* stream)
+extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_blocks, uint32_t n_blocks, uint64_t total_out, uint8_t* d_out, const uint32_t* d_crc,
+                                       uint32_t* d_status, uint32_t* d_tok, uint32_t* d_ntok, void* stream)
 {
     if (!n_blocks) return;
     const int lanes = getenv("BQC_GI_LANES") ? atoi(getenv("BQC_GI_LANES")) : 4; // (read at every launch: the tests switch kernels; 10 K blocks: 24 ms with 4 blocks per workgroup, 29 with 8, 34 with 16, 30 with 2)
@@ -778,7 +801,8 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     if (!two_phase || !d_ntok) d_tok = nullptr;
     // (two phases, inflate + CRC: 9 K blocks 16 ms with the root tables against 22 lean; 18 K: 34 against 24; 45 K: 63 against 36; 90 K: lean 64-wide 56 against 68 32-wide)
     const int lean = lean_env >= 0 ? lean_env : (n_blocks > 60000u ? 64 : n_blocks > 12000u ? 32 : 0);
-    uint64_t* const d_tok64 = (uint64_t*)d_tok;
+    uint32_t* const d_tok64 = d_tok; // (the bitmap of match starts: zeroed for every launch, phase 1 only stores the words that are not zero)
+    if (d_tok) (void)hipMemsetAsync(d_tok, 0, 4 * (size_t)bqc_gpu_inflate_token_words(total_out, n_blocks), (hipStream_t)stream);
 #define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
 #define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
     if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
@@ -880,7 +904,7 @@ extern "C" int bqc_gpu_inflate(GpuInflater* g, const uint8_t* comp, size_t comp_
     if (hipMemcpyAsync(g->d_comp, comp, comp_bytes, hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->d_blocks, blocks, n_blocks * sizeof(GiBlock), hipMemcpyHostToDevice, g->stream) != hipSuccess) return -1;
     if (timing) (void)hipEventRecord(ev[1], g->stream);
-    bqc_gpu_inflate_launch(g->d_comp, g->d_blocks, (uint32_t)n_blocks, g->d_out, nullptr, g->d_status, g->d_tok, g->d_ntok, g->stream); // (the CRC-32s are checked on the host here)
+    bqc_gpu_inflate_launch(g->d_comp, g->d_blocks, (uint32_t)n_blocks, out_bytes, g->d_out, nullptr, g->d_status, g->d_tok, g->d_ntok, g->stream); // (the CRC-32s are checked on the host here)
     if (timing) (void)hipEventRecord(ev[2], g->stream);
     if (hipMemcpyAsync(out, g->d_out, out_bytes, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;
     if (hipMemcpyAsync(g->h_status, g->d_status, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return -1;

@@ -37,7 +37,7 @@ def main():
     _lib.load()
     fn = C.CDLL(_lib.LIB_PATH).bqc_gpu_inflate_launch
     fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     with tempfile.TemporaryDirectory(prefix="bqc_gis_") as tmp:
         bam = os.path.join(tmp, "x.bam")
         hostio.synth_stream(bam, None, 1002, reads, ["chr1", "chr2", "chr3", "chr4"], [25_000_000] * 4, level=level)
@@ -63,13 +63,13 @@ def main():
         d_crc = torch.from_numpy(crc.view(np.int32)).to(dev)
         d_out = torch.empty(u + 4096, dtype=torch.uint8, device=dev)
         d_st = torch.zeros(16, dtype=torch.int32, device=dev)
-        d_tok = torch.empty(2 * (u // 3 + 2 * n + 64), dtype=torch.int32, device=dev)
+        d_tok = torch.empty(u // 32 + n + 64, dtype=torch.int32, device=dev)
         d_ntok = torch.empty(n + 16, dtype=torch.int32, device=dev)
         ms = []
         for it in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            fn(d_comp.data_ptr(), d_tab.data_ptr(), n, d_out.data_ptr(), d_crc.data_ptr(), d_st.data_ptr(), d_tok.data_ptr(), d_ntok.data_ptr(), None)
+            fn(d_comp.data_ptr(), d_tab.data_ptr(), n, u, d_out.data_ptr(), d_crc.data_ptr(), d_st.data_ptr(), d_tok.data_ptr(), d_ntok.data_ptr(), None)
             e1.record()
             torch.cuda.synchronize()
             if it:
