@@ -637,6 +637,8 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
     if (st) atomicOr(status, st);
 }
 
+#include "gpu_inflate_wave.inc"
+
 // ---------------------------------------------------------------------------------------------------
 // phase 2: the matches of a block, resolved by pointer jumping
 // ---------------------------------------------------------------------------------------------------
@@ -805,9 +807,6 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     if (d_tok) (void)hipMemsetAsync(d_tok, 0, 4 * (size_t)bqc_gpu_inflate_token_words(total_out, n_blocks), (hipStream_t)stream);
 #define GI_LAUNCH_L(NL) hipLaunchKernelGGL(k_inflate_lean<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GL_BYTES * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
 #define GI_LAUNCH_D(NL) hipLaunchKernelGGL(k_inflate<NL>, dim3((n_blocks + NL - 1) / NL), dim3(NL), GI_U16 * 2 * NL, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok)
-    if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
-    else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
-    const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
     static unsigned long long* d_stats = nullptr; // (BQC_GI_STATS: blocks resolved, chunks, rounds, matches, matched bytes, distances < 8, lengths > 32, tokens — printed at exit)
     static const bool want_stats = [] {
         if (!getenv("BQC_GI_STATS")) return false;
@@ -815,11 +814,18 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
         atexit([] {
             unsigned long long h[8] = {};
             if (hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu tokens, %llu rounds\n", h[0], h[7], h[2]);
+                fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu matches, %llu rounds; phase 1 by waves: %llu deflate blocks, %llu scan rounds; clocks per wave: header + tables %.0f, scan %.0f, write %.0f\n", h[0], h[7], h[2], h[4], h[3],
+                        (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / (h[4] ? h[4] : 1), (double)h[1] / (h[4] ? h[4] : 1));
         });
         return true;
     }();
     (void)want_stats;
+    // phase 1 by a wave per block (gpu_inflate_wave.inc) unless BQC_GI_WAVE=0 (a lane per block: the kernels above); one phase: always a lane per block
+    const bool wave = d_tok && !(getenv("BQC_GI_WAVE") && atoi(getenv("BQC_GI_WAVE")) == 0) && lean_env < 0 && !getenv("BQC_GI_LANES");
+    if (wave) hipLaunchKernelGGL(k_inflate_wave, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok, d_stats);
+    else if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
+    else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
+    const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
     if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), 131072 + 64, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }

@@ -16,14 +16,14 @@ class GiBlock(C.Structure):
     _fields_ = [("coff", C.c_uint64), ("uoff", C.c_uint64), ("csize", C.c_uint32), ("usize", C.c_uint32)]
 
 
-@pytest.fixture(autouse=True, params=["default", "lean32", "lean64", "one_phase", "one_phase_lean32"])
+@pytest.fixture(autouse=True, params=["default", "lanes", "lean32", "lean64", "one_phase", "one_phase_lean32"])
 def kernel_variant(request, monkeypatch):
-    """Every test of this module runs through each inflate kernel: the one with root tables in LDS (the default for small launches)
-    and the lean one at two workgroup widths, with the matches filled in by the second-phase kernel (k_inflate_resolve: the default),
-    and both with the lanes copying their matches themselves (one phase)."""
-    env = {"default": {}, "lean32": {"BQC_GI_LEAN": "32"}, "lean64": {"BQC_GI_LEAN": "64"}, "one_phase": {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "0"},
+    """Every test of this module runs through each inflate kernel: a wave per block (k_inflate_wave: the default) and a lane per
+    block — with root tables in LDS and the lean one at two workgroup widths — all with the matches filled in by the second-phase
+    kernel (k_inflate_resolve), and the lane-per-block kernels also with the lanes copying their matches themselves (one phase)."""
+    env = {"default": {}, "lanes": {"BQC_GI_WAVE": "0"}, "lean32": {"BQC_GI_LEAN": "32"}, "lean64": {"BQC_GI_LEAN": "64"}, "one_phase": {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "0"},
            "one_phase_lean32": {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "32"}}[request.param]
-    for k in ("BQC_GI_LEAN", "BQC_GI_TWO_PHASE"):
+    for k in ("BQC_GI_LEAN", "BQC_GI_TWO_PHASE", "BQC_GI_WAVE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
