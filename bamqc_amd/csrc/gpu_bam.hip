@@ -233,11 +233,15 @@ __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ ba
     if (exc) atomicOr(status, exc);
 }
 
-// wave per record: CIGAR words, packed bases and qualities into the batch's packed columns
+// CIGAR words, packed bases and qualities into the batch's packed columns: 16 lanes per record, 16 bytes per lane and step.  A 150 bp
+// record is 10 pieces of qualities, 5 of bases and one of CIGAR: one step with every lane busy (a wave per record moved the three
+// arrays one after the other, 4 bytes per lane, with 19, 38 and 1 of 64 lanes busy: 0.67 ms per million records, three dependent round
+// trips per wave).  A last piece of fewer than 16 bytes is moved as the array's last 16 (it overlaps the piece before it: the same
+// bytes twice); an array shorter than 16 bytes by dwords and bytes.  Long reads: the 16 lanes stride over the pieces.
 __global__ __launch_bounds__(256) void k_gb_copy(const uint8_t* __restrict__ base, GbCols C, uint32_t n, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual,
                                                   uint8_t* __restrict__ cigar /* bytes */)
 {
-    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 16 + (threadIdx.x >> 4), gl = threadIdx.x & 15u;
     if (i >= n) return;
     const uint8_t* r = base + C.rec_off[i] + 4;
     const uint32_t l_name = r[8], n_cig = C.n_cigar[i], l_seq = C.l_seq[i];
@@ -247,18 +251,24 @@ __global__ __launch_bounds__(256) void k_gb_copy(const uint8_t* __restrict__ bas
     uint8_t* dc = cigar + 4ull * C.co[i];
     uint8_t* ds = seq + C.so[i];
     uint8_t* dq = qual + C.qo[i];
-    // sixteen bytes per lane and step while a kilobyte is left (long reads), then four (unaligned loads and stores), the last 1-3
-    // bytes one by one
-    auto copy = [&](uint8_t* d, const uint8_t* s_, uint32_t n_bytes) {
-        uint32_t at = 0;
-        for (; at + 1024u <= n_bytes; at += 1024u) *(gb_u32x4_u*)(d + at + 16u * lane) = *(const gb_u32x4_u*)(s_ + at + 16u * lane);
-        const uint32_t whole = n_bytes & ~3u;
-        for (uint32_t k = at + 4u * lane; k < whole; k += 256u) *(gb_u32_u*)(d + k) = *(const gb_u32_u*)(s_ + k);
-        if (lane < (n_bytes & 3u)) d[whole + lane] = s_[whole + lane];
-    };
-    copy(dc, cg, 4u * n_cig);
-    copy(ds, sq, (l_seq + 1u) / 2u);
-    copy(dq, ql, l_seq);
+    const uint32_t nc = 4u * n_cig, ns = (l_seq + 1u) / 2u, nq = l_seq;
+    const uint32_t pq = (nq + 15u) >> 4, ps = (ns + 15u) >> 4, pc = (nc + 15u) >> 4;
+    for (uint32_t k = gl; k < pq + ps + pc; k += 16u) {
+        const uint8_t* s_;
+        uint8_t* d;
+        uint32_t len, piece;
+        if (k < pq) { s_ = ql; d = dq; len = nq; piece = k; }
+        else if (k < pq + ps) { s_ = sq; d = ds; len = ns; piece = k - pq; }
+        else { s_ = cg; d = dc; len = nc; piece = k - pq - ps; }
+        const uint32_t at = 16u * piece;
+        if (at + 16u <= len) *(gb_u32x4_u*)(d + at) = *(const gb_u32x4_u*)(s_ + at);
+        else if (len >= 16u) *(gb_u32x4_u*)(d + len - 16u) = *(const gb_u32x4_u*)(s_ + len - 16u);
+        else {
+            uint32_t b_ = 0;
+            for (; b_ + 4u <= len; b_ += 4u) *(gb_u32_u*)(d + b_) = *(const gb_u32_u*)(s_ + b_);
+            for (; b_ < len; ++b_) d[b_] = s_[b_];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1055,7 +1065,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         hipError_t he = hipMemcpyAsync(I.d_base.p, I.h_base.p, (size_t)last_taken * sizeof(GbBase), hipMemcpyHostToDevice, I.s);
         if (he != hipSuccess) return fail_dev("copy failed");
         hipLaunchKernelGGL(k_gb_decode, dim3(last_taken), dim3(64), 0, I.s, base, I.d_seg.p, I.d_rec.p, I.d_base.p, C, LN, I.d_main.p, I.n_main, I.d_status);
-        hipLaunchKernelGGL(k_gb_copy, dim3((uint32_t)((N + 3) / 4)), dim3(256), 0, I.s, base, C, (uint32_t)N, pay + o_seq, pay + o_qual, pay + o_cig);
+        hipLaunchKernelGGL(k_gb_copy, dim3((uint32_t)((N + 15) / 16)), dim3(256), 0, I.s, base, C, (uint32_t)N, pay + o_seq, pay + o_qual, pay + o_cig);
         he = hipMemcpyAsync(o.flag.data(), C.flag, N * 2, hipMemcpyDeviceToHost, I.s);
         if (he == hipSuccess) he = hipMemcpyAsync(o.n_cigar.data(), C.n_cigar, N * 2, hipMemcpyDeviceToHost, I.s);
         if (he == hipSuccess) he = hipMemcpyAsync(o.mapq.data(), C.mapq, N, hipMemcpyDeviceToHost, I.s);

@@ -653,6 +653,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 // per link, between workgroup barriers or through a bitmap of final bytes — took 65 and 83 ms for 45 K blocks).  Reading an index
 // that another thread is just replacing is harmless: old and new value are both ancestors.  Last, every match byte is fetched from
 // its literal (a gather inside the block's 64 KiB, which the workgroup has just touched) and stored, four bytes per thread.
+#define GI_RESOLVE_LDS (131072 + 64)
 __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ bitmap,
                                                            const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
 {
@@ -666,47 +667,85 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
     const uint32_t usize = blk.usize, upad = (usize + 7u) & ~7u;
     const uint32_t* const bm = bitmap + gi_bm_base(blocks, bi);
     uint32_t* const pair = (uint32_t*)ridx;
+    long long tc[5] = {stats ? clock64() : 0, 0, 0, 0, 0}; // (BQC_GI_STATS: where the workgroup's clocks go)
+    const long long wc0 = stats ? wall_clock64() : 0;
     for (uint32_t q = tid; q < upad / 2u; q += 1024u) pair[q] = (2u * q) | ((2u * q + 1u) << 16); // every byte its own root
     __syncthreads();
+    if (stats) tc[1] = clock64();
     for (uint32_t w = tid; w < (usize + 31u) / 32u; w += 1024u) { // match bytes point at their sources: the matches that start in word w of the bitmap
+        // (at most eleven: a match is three bytes or more).  Their descriptions are fetched together, then used: one memory round trip
+        // per bitmap word, not one per match
         uint32_t bits = bm[w];
-        while (bits) {
-            const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
-            bits &= bits - 1u;
-            if (d + 3u > usize) continue;
-            const uint32_t tok = (uint32_t)o0[d] | ((uint32_t)o0[d + 1u] << 8) | ((uint32_t)o0[d + 2u] << 16); // phase 1 left the match's description in its first bytes
-            const uint32_t dist = (tok & 0x7FFFu) + 1u, len = (tok >> 16) + 3u;
+        uint32_t dd[11], tk[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            dd[k] = 0xFFFFFFFFu; tk[k] = 0;
+            if (bits) {
+                const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                if (d + 3u <= usize) { dd[k] = d; tk[k] = *(const gi_u32_u*)(o0 + d); } // phase 1 left the match's description in its first three bytes (the fourth: whatever follows)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const uint32_t d = dd[k];
+            if (d == 0xFFFFFFFFu) continue;
+            const uint32_t dist = (tk[k] & 0x7FFFu) + 1u, len = ((tk[k] >> 16) & 0xFFu) + 3u;
             if (dist > d || d + len > usize) continue; // (phase 1 has checked it; damaged memory must not reach outside)
-            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
+            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist); // (tried: the bytes beyond a match's first eight from a list, a wave per listed match — slower: 78 K clocks instead of 45 K for this pass)
         }
     }
     __syncthreads();
-    uint32_t rounds = 0;
+    if (stats) tc[2] = clock64();
+    uint32_t rounds = 0, done = 0; // done: bit k — both bytes of this thread's k-th pair point at roots (a byte whose index did not move in a round: final)
     for (; rounds < 16u; ++rounds) {
-        uint32_t changed = 0;
+        uint32_t changed = 0, k = 0;
 #pragma unroll 4
-        for (uint32_t q = tid; q < upad / 2u; q += 1024u) {
+        for (uint32_t q = tid; q < upad / 2u; q += 1024u, ++k) {
+            if ((done >> k) & 1u) continue;
             const uint32_t v = pair[q], a = v & 0xFFFFu, b = v >> 16;
             const uint32_t a2 = ridx[a], b2 = ridx[b];
-            changed |= (a2 ^ a) | (b2 ^ b);
-            pair[q] = a2 | (b2 << 16);
+            const uint32_t moved = (a2 ^ a) | (b2 ^ b);
+            if (moved) { changed = 1u; pair[q] = a2 | (b2 << 16); }
+            else done |= 1u << k;
         }
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
-    if (stats && tid == 0u) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); atomicAdd(&stats[2], (unsigned long long)rounds); }
-    // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte)
-    for (uint32_t p = 4u * tid; p < usize; p += 4096u) {
-        const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
-        const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
-        if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
-        if (p + 4u <= usize) {
-            const uint32_t w = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24);
-            *(gi_u32_u*)(o0 + p) = w;
-        } else {
-            const uint32_t ii[4] = {i0, i1, i2, i3};
-            uint8_t vv[4];
-            for (uint32_t j = 0; p + j < usize; ++j) vv[j] = o0[ii[j]];
-            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = vv[j];
+    if (stats) tc[3] = clock64();
+    // Every match byte from its literal, four bytes per thread and step (the block's tail byte by byte): ALL loads first, then the
+    // stores — the loads read literals, the stores write match bytes, but the compiler must take a store for a possible source of
+    // the next load and would wait for memory sixteen times in a row.
+    uint32_t wv[16], some = 0;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const uint32_t p = 4u * tid + 4096u * it;
+        wv[it] = 0;
+        if (p < usize) {
+            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
+            const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
+            if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
+            some |= 1u << it;
+            wv[it] = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24); // (behind the block's end: bytes that are not stored)
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const uint32_t p = 4u * tid + 4096u * it;
+        if (!(some & (1u << it))) continue;
+        if (p + 4u <= usize) *(gi_u32_u*)(o0 + p) = wv[it];
+        else {
+            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
+            const uint32_t ii[4] = {v0 & 0xFFFFu, v0 >> 16, v1 & 0xFFFFu, v1 >> 16};
+            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = (uint8_t)(wv[it] >> (8u * j));
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid == 0u) {
+            tc[4] = clock64();
+            atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); atomicAdd(&stats[2], (unsigned long long)rounds);
+            for (int k = 0; k < 4; ++k) atomicAdd(&stats[8 + k], (unsigned long long)(tc[k + 1] - tc[k]));
+            atomicAdd(&stats[12], (unsigned long long)(wall_clock64() - wc0));
         }
     }
 }
@@ -797,7 +836,7 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
     // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
     const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 64);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, GI_RESOLVE_LDS);
     (void)attr;
     const bool two_phase = bqc_gpu_inflate_two_phase() != 0; // (see the comment at struct Out)
     if (!two_phase || !d_ntok) d_tok = nullptr;
@@ -810,10 +849,15 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     static unsigned long long* d_stats = nullptr; // (BQC_GI_STATS: blocks resolved, chunks, rounds, matches, matched bytes, distances < 8, lengths > 32, tokens — printed at exit)
     static const bool want_stats = [] {
         if (!getenv("BQC_GI_STATS")) return false;
-        if (hipMalloc((void**)&d_stats, 64) != hipSuccess || hipMemset(d_stats, 0, 64) != hipSuccess) { d_stats = nullptr; return false; }
+        if (hipMalloc((void**)&d_stats, 128) != hipSuccess || hipMemset(d_stats, 0, 128) != hipSuccess) { d_stats = nullptr; return false; }
         atexit([] {
-            unsigned long long h[8] = {};
-            if (hipMemcpy(h, d_stats, 64, hipMemcpyDeviceToHost) == hipSuccess)
+            unsigned long long h[16] = {};
+            if (hipMemcpy(h, d_stats, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[gpu inflate] resolve clocks per block: set-up %.0f, matches listed %.0f, pointer jumping %.0f, gather %.0f\n", (double)h[8] / (h[0] ? h[0] : 1),
+                        (double)h[9] / (h[0] ? h[0] : 1), (double)h[10] / (h[0] ? h[0] : 1), (double)h[11] / (h[0] ? h[0] : 1));
+                fprintf(stderr, "[gpu inflate] clock64 ticks per wall_clock64 tick (100 MHz): %.2f\n", (double)(h[8] + h[9] + h[10] + h[11]) / (h[12] ? h[12] : 1));
+            }
+            if (h[0] || h[4])
                 fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu matches, %llu rounds; phase 1 by waves: %llu deflate blocks, %llu scan rounds; clocks per wave: header + tables %.0f, scan %.0f, write %.0f\n", h[0], h[7], h[2], h[4], h[3],
                         (double)h[5] / (h[4] ? h[4] : 1), (double)h[6] / (h[4] ? h[4] : 1), (double)h[1] / (h[4] ? h[4] : 1));
         });
@@ -826,7 +870,7 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     else if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
     else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
     const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
-    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), 131072 + 64, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
+    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), GI_RESOLVE_LDS, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
     if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 
