@@ -44,7 +44,7 @@
 #include "gpu_inflate.h"
 #include "../host/parallel.h"
 
-#define GB_SEG 16384u
+#define GB_SEG 16384u // (4 KiB segments measured slower: 28 walk launches of 0.20 ms per 10 M reads instead of 18 of 0.27 — more segments whose guess has to be redone — and k_gb_decode 0.18 instead of 0.14 ms per batch)
 #define GB_MAXR (GB_SEG / 36u + 1u)
 
 enum { GB_INCOMPLETE = 1, GB_CORRUPT = 2, GB_NO_START = 4 };
