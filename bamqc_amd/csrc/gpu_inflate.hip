@@ -2,32 +2,25 @@
 // (gpu_bam.hip: the inflated bytes stay in device memory — the program's default for whole BAM files), and, opt-in and for
 // comparison only (BQC_GPU_INFLATE=1 / bqc_gpu_inflate_device), by the host reader's BGZF layer, which copies the bytes back.
 //
-// BGZF blocks are independent, at most 64 KiB, and carry their uncompressed size: ONE LANE PER BLOCK.  The state a decoder needs is
-// kept in LDS, shared out lane by lane (2.1 KB each): 9-bit root table of the literal/length code and 7-bit root table of the
-// distance code as u16 entries `symbol << 4 | code bits`, and for the longer codes (rare: the frequent symbols have short codes)
-// the canonical code itself — counts per length and the symbols in code order — decoded bit by bit.  Every per-lane array is laid
-// out [entry][lane], so that the lanes' accesses to the same entry fall on different banks.  The bit buffer is refilled one word
-// ahead (the load's latency hides behind the symbols decoded meanwhile); literals are byte stores; a match is copied 32 / 16 / 4 / 1
-// bytes at a time from the lane's own output (requests of one wave to one address are served in order); length and distance
-// bases are computed, not looked up.  What comes out is checked against the block's CRC-32 like the CPU decoder's output: by k_gi_crc
-// below for the reader on the card, on the host for the copy-back path.
+// BGZF blocks are independent, at most 64 KiB, and carry their uncompressed size.  The default path (round 3) takes a launch in TWO
+// PHASES: k_inflate_wave (gpu_inflate_wave.inc) — a WAVE per block decodes the symbols, 64 pieces of the stream at once from guessed
+// starts that are verified lane to lane, and writes literals and match descriptions — and k_inflate_resolve — a workgroup per block
+// fills the matches in by pointer jumping over a 16-bit index per output byte in LDS; then k_gi_crc checks every block against its
+// CRC-32.  45 K blocks (2.9 GB of output): 17.9 + 9 + 1.7 ms.  What it replaced stays selectable and tested: ONE LANE PER BLOCK
+// (BQC_GI_WAVE=0: k_inflate with root tables in LDS — 2.1 KB per lane: 9-bit root table of the literal/length code, 7-bit of the
+// distance code as u16 `symbol << 4 | code bits`, the canonical code itself for longer codes, every per-lane array laid out
+// [entry][lane] — or k_inflate_lean with 356 bytes per lane), and the lanes copying their matches themselves (BQC_GI_TWO_PHASE=0:
+// 32 / 16 / 4 / 1 bytes at a time from the lane's own output).
 //
-// Measured (MI355X, a run of 12.9 K blocks = 268 MB -> 844 MB, BGZF level 1): kernel 46 / 40 / 35 / 32 ms with 64 / 32 / 16 / 8
-// lanes per workgroup, H2D 5 ms, D2H into pageable memory 35 ms; the host decoder (16 threads) needs 80 ms for the same bytes.  A
-// lane spends ~1.5 us per symbol whatever the workgroup width: that is one round trip to HBM per iteration of the wave — a
+// History of the lane-per-block kernels (MI355X; why they are no longer the default): a run of 12.9 K blocks = 268 MB -> 844 MB took
+// 46 / 40 / 35 / 32 ms with 64 / 32 / 16 / 8 lanes per workgroup; a lane spends ~1.5 us per symbol whatever the workgroup width — a
 // match reads the lane's own output up to 32 KiB back, 13 K lanes x 64 KiB of output are far more than the L2 holds, and in every
-// iteration some lane of the wave has a match.  The kernel is latency-bound: its time is the time of one block (22 ms for 3.4 K
-// blocks, 32 ms for 13 K) until the card is full (76 lanes per CU with these tables: 19 K blocks), so the reader keeps several
-// moderate runs in flight (host/bgzf.cpp: workers with a stream and page-locked bounce buffers each, beside the host's decoder).
-// With the bytes copied BACK the program does not get faster: 10 M reads 0.59-0.69 s against 0.51-0.53 s, 40 M reads 1.62 s (two
-// workers on the card beside the host's 16 threads) against 1.52 s — copies, the runtime's locks shared with the batch pipeline, and
-// the record decode that follows is host work either way.  It pays once the records are walked and decoded on the card as well
-// (gpu_bam.hip: 10 M reads in 0.36 s, record loop 0.11 s, of which the inflate kernels are 0.06 s).
-// Tried and measured slower (30-60 %): listing the matches while the symbols are decoded and resolving them in a second loop — the
-// copies' round trips are the floor either way, and inside the symbol loop the lanes without a match make progress meanwhile.
-// Also slower (8 %): holding a short match's bytes in registers until the lane's second match after it (the compiler's vmcnt(0)
-// waits make the deferral void).  Next: literal bytes gathered in registers and stored 8-16 at a time (a refill of the bit buffer
-// waits with vmcnt(0), which on gfx9 also holds the last literal's store: without the copies a launch still takes 2/3 of its time).
+// iteration some lane of the wave has a match: the kernel's time is the time of one block (22 ms for 3.4 K blocks, 32 ms for 13 K)
+// until the card is full.  Measured in round 3: the copies are half of the time (FETCH_SIZE 20 GB for 2.7 GB of algorithmic bytes),
+// literal stores are free; resolving the matches inside the lane after the symbols was 30-60 % slower, holding short matches in
+// registers 8 % slower.  With the bytes copied BACK to the host the program does not get faster (10 M reads
+// 0.59-0.69 s against 0.51-0.53 s: BQC_GPU_INFLATE=1 keeps that path for comparison); it pays once the records are walked and decoded
+// on the card as well (gpu_bam.hip).
 //
 // Format: RFC 1951 (public); acceptance rules as the host decoder's (bamqc_amd/host/inflate_fast.cpp): over-subscribed or
 // incomplete code sets, a missing end-of-block code, distances before the block's start, output other than ISIZE bytes, input
@@ -692,7 +685,9 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
             if (d == 0xFFFFFFFFu) continue;
             const uint32_t dist = (tk[k] & 0x7FFFu) + 1u, len = ((tk[k] >> 16) & 0xFFu) + 3u;
             if (dist > d || d + len > usize) continue; // (phase 1 has checked it; damaged memory must not reach outside)
-            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist); // (tried: the bytes beyond a match's first eight from a list, a wave per listed match — slower: 78 K clocks instead of 45 K for this pass)
+            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist); // (a wave's loop runs as long as its longest match; tried instead: the bytes beyond a match's
+                                                                                       // first eight from a list, a wave per listed match — 78 K clocks for this pass instead of 45 K; the
+                                                                                       // matches' descriptions in LDS and every thread walking its 32 bytes in order — 74 K)
         }
     }
     __syncthreads();
