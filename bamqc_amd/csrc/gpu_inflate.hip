@@ -30,6 +30,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels_common.h"
 #include "gpu_inflate.h"
 
@@ -648,7 +650,7 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 // its literal (a gather inside the block's 64 KiB, which the workgroup has just touched) and stored, four bytes per thread.
 #define GI_RESOLVE_LDS (131072 + 64)
 __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ bitmap,
-                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) 8 counters */)
+                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) counters */)
 {
     extern __shared__ uint16_t ridx[]; // [65536]
     const uint32_t bi = blockIdx.x, tid = threadIdx.x;
@@ -665,73 +667,51 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
     for (uint32_t q = tid; q < upad / 2u; q += 1024u) pair[q] = (2u * q) | ((2u * q + 1u) << 16); // every byte its own root
     __syncthreads();
     if (stats) tc[1] = clock64();
-    for (uint32_t w = tid; w < (usize + 31u) / 32u; w += 1024u) { // match bytes point at their sources: the matches that start in word w of the bitmap
-        // (at most eleven: a match is three bytes or more).  Their descriptions are fetched together, then used: one memory round trip
-        // per bitmap word, not one per match
+    // Match bytes point at their sources: the matches that start in word w of the bitmap.  (Measured, none faster — the kernel is bound
+    // by its LDS traffic, not by memory latency: the words' match descriptions fetched together before they are used, +0.4 ms per 45 K
+    // blocks; the bytes beyond a match's first eight from a list, a wave per listed match: 78 K clocks for this pass instead of 45 K;
+    // the descriptions in LDS and every thread walking its 32 bytes in order: 74 K.)
+    for (uint32_t w = tid; w < (usize + 31u) / 32u; w += 1024u) {
         uint32_t bits = bm[w];
-        uint32_t dd[11], tk[11];
-#pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            dd[k] = 0xFFFFFFFFu; tk[k] = 0;
-            if (bits) {
-                const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
-                bits &= bits - 1u;
-                if (d + 3u <= usize) { dd[k] = d; tk[k] = *(const gi_u32_u*)(o0 + d); } // phase 1 left the match's description in its first three bytes (the fourth: whatever follows)
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const uint32_t d = dd[k];
-            if (d == 0xFFFFFFFFu) continue;
-            const uint32_t dist = (tk[k] & 0x7FFFu) + 1u, len = ((tk[k] >> 16) & 0xFFu) + 3u;
+        while (bits) {
+            const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            if (d + 3u > usize) continue;
+            const uint32_t tok = (uint32_t)o0[d] | ((uint32_t)o0[d + 1u] << 8) | ((uint32_t)o0[d + 2u] << 16); // phase 1 left the match's description in its first bytes
+            const uint32_t dist = (tok & 0x7FFFu) + 1u, len = (tok >> 16) + 3u;
             if (dist > d || d + len > usize) continue; // (phase 1 has checked it; damaged memory must not reach outside)
-            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist); // (a wave's loop runs as long as its longest match; tried instead: the bytes beyond a match's
-                                                                                       // first eight from a list, a wave per listed match — 78 K clocks for this pass instead of 45 K; the
-                                                                                       // matches' descriptions in LDS and every thread walking its 32 bytes in order — 74 K)
+            for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
         }
     }
     __syncthreads();
     if (stats) tc[2] = clock64();
-    uint32_t rounds = 0, done = 0; // done: bit k — both bytes of this thread's k-th pair point at roots (a byte whose index did not move in a round: final)
-    for (; rounds < 16u; ++rounds) {
-        uint32_t changed = 0, k = 0;
+    uint32_t rounds = 0;
+    for (; rounds < 16u; ++rounds) { // (skipping the pairs that already point at roots — a mask per thread — changed nothing measurable)
+        uint32_t changed = 0;
 #pragma unroll 4
-        for (uint32_t q = tid; q < upad / 2u; q += 1024u, ++k) {
-            if ((done >> k) & 1u) continue;
+        for (uint32_t q = tid; q < upad / 2u; q += 1024u) {
             const uint32_t v = pair[q], a = v & 0xFFFFu, b = v >> 16;
             const uint32_t a2 = ridx[a], b2 = ridx[b];
-            const uint32_t moved = (a2 ^ a) | (b2 ^ b);
-            if (moved) { changed = 1u; pair[q] = a2 | (b2 << 16); }
-            else done |= 1u << k;
+            changed |= (a2 ^ a) | (b2 ^ b);
+            pair[q] = a2 | (b2 << 16);
         }
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
     if (stats) tc[3] = clock64();
-    // Every match byte from its literal, four bytes per thread and step (the block's tail byte by byte): ALL loads first, then the
-    // stores — the loads read literals, the stores write match bytes, but the compiler must take a store for a possible source of
-    // the next load and would wait for memory sixteen times in a row.
-    uint32_t wv[16], some = 0;
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const uint32_t p = 4u * tid + 4096u * it;
-        wv[it] = 0;
-        if (p < usize) {
-            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
-            const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
-            if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
-            some |= 1u << it;
-            wv[it] = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24); // (behind the block's end: bytes that are not stored)
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const uint32_t p = 4u * tid + 4096u * it;
-        if (!(some & (1u << it))) continue;
-        if (p + 4u <= usize) *(gi_u32_u*)(o0 + p) = wv[it];
-        else {
-            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
-            const uint32_t ii[4] = {v0 & 0xFFFFu, v0 >> 16, v1 & 0xFFFFu, v1 >> 16};
-            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = (uint8_t)(wv[it] >> (8u * j));
+    // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte).  (All loads in front of all
+    // stores — the compiler has to take a store for a possible source of the next load — measured no faster.)
+    for (uint32_t p = 4u * tid; p < usize; p += 4096u) {
+        const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
+        const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
+        if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
+        if (p + 4u <= usize) {
+            const uint32_t w = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24);
+            *(gi_u32_u*)(o0 + p) = w;
+        } else {
+            const uint32_t ii[4] = {i0, i1, i2, i3};
+            uint8_t vv[4];
+            for (uint32_t j = 0; p + j < usize; ++j) vv[j] = o0[ii[j]];
+            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = vv[j];
         }
     }
     if (stats) {
@@ -861,7 +841,7 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     (void)want_stats;
     // phase 1 by a wave per block (gpu_inflate_wave.inc) unless BQC_GI_WAVE=0 (a lane per block: the kernels above); one phase: always a lane per block
     const bool wave = d_tok && !(getenv("BQC_GI_WAVE") && atoi(getenv("BQC_GI_WAVE")) == 0) && lean_env < 0 && !getenv("BQC_GI_LANES");
-    if (wave) hipLaunchKernelGGL(k_inflate_wave, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok, d_stats);
+    if (wave) hipLaunchKernelGGL(k_inflate_wave, dim3(getenv("BQC_GI_WAVE_GRID") && atoi(getenv("BQC_GI_WAVE_GRID")) > 0 ? std::min<uint32_t>(n_blocks, (uint32_t)atoi(getenv("BQC_GI_WAVE_GRID"))) : n_blocks), dim3(64), 0, (hipStream_t)stream, d_comp, d_blocks, n_blocks, d_out, d_status, d_tok64, d_ntok, d_stats);
     else if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
     else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
     const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)

@@ -141,12 +141,14 @@ def test_paired_config1_output_feeds_the_downstream_consumer(tmp_path):
 
 def test_optional_paths_write_the_same_bytes(tmp_path):
     """Switchable paths that are off by default must not change a byte: references uploaded beside the record loop (BQC_BG_REFS),
-    k_short's XCD-contiguous chunk walk (BQC_SHORT_XCD), the inflate kernels in one phase (BQC_GI_TWO_PHASE=0)."""
+    k_short's XCD-contiguous chunk walk (BQC_SHORT_XCD), the inflate kernels in one phase (BQC_GI_TWO_PHASE=0), phase 1 by a lane
+    per block (BQC_GI_WAVE=0, BQC_GI_LEAN)."""
     bam, fa = str(tmp_path / "m.bam"), str(tmp_path / "m.fa")
     hostio.synth_write(bam, fa, seed=17, n_reads=40_000, ref_names=["chr1", "chr2", "chrX"], ref_lens=[600_000, 300_000, 200_000], n_lanes=2)
     want = str(tmp_path / "oracle.bamqc")
     assert oracle_bamqualcheck(bam, fa, want) == 0
-    for k, env in enumerate(({"BQC_BG_REFS": "1"}, {"BQC_SHORT_XCD": "1"}, {"BQC_GI_TWO_PHASE": "0"}, {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "32"}, {"BQC_GI_LEAN": "32"})):
+    for k, env in enumerate(({"BQC_BG_REFS": "1"}, {"BQC_SHORT_XCD": "1"}, {"BQC_GI_TWO_PHASE": "0"}, {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "32"}, {"BQC_GI_LEAN": "32"},
+                            {"BQC_GI_WAVE": "0"})):
         got = str(tmp_path / ("got%d.bamqc" % k))
         r = subprocess.run([EXE, "-r", fa, "-o", got, bam], capture_output=True, text=True, env=dict(os.environ, **READER, **env))
         assert r.returncode == 0, (env, r.stderr)

@@ -118,6 +118,66 @@ def test_many_blocks_fill_the_card(gi):
     assert got == b"".join(base) * 40
 
 
+def test_many_deflate_blocks_in_a_stream_and_long_codes(gi):
+    """What the wave-per-block kernel cuts differently from a serial decoder: streams of twenty deflate blocks (the wave starts over with
+    a header and new tables behind every end-of-block symbol, wherever in a piece it lies), blocks far shorter than a piece, codes
+    longer than the root tables for literals (300 distinct symbols with a steep distribution) and for distances (matches at every
+    distance class with few repeats), and a block that is one long run of literals."""
+    rng = np.random.default_rng(23)
+    streams, want = [], []
+    for seed in range(6):
+        r = np.random.default_rng(100 + seed)
+        c = zlib.compressobj(1 + seed, zlib.DEFLATED, -15)
+        parts, s = [], b""
+        for k in range(20):
+            kind = (k + seed) % 4
+            if kind == 0:
+                x = bytes(r.integers(0, 256, int(r.integers(1, 2500)), dtype=np.uint8))            # mostly stored or near-incompressible
+            elif kind == 1:
+                x = bytes((r.geometric(0.05, int(r.integers(10, 4000))) % 256).astype(np.uint8))    # long codes for the rare symbols
+            elif kind == 2:
+                x = (b"pattern%03d/" % k) * int(r.integers(1, 300))
+            else:
+                x = bytes(r.integers(0, 3, int(r.integers(1, 60)), dtype=np.uint8))                 # a block of a few symbols
+            parts.append(x)
+            s += c.compress(x) + c.flush(zlib.Z_FULL_FLUSH if k % 3 else zlib.Z_SYNC_FLUSH)
+        s += c.flush()
+        data = b"".join(parts)
+        assert len(data) <= 65536 and len(s) <= 65536
+        streams.append(s)
+        want.append(data)
+    # distances of every class, each used once or twice: many distance codes of 9 bits and more
+    base = bytes(rng.integers(0, 256, 40000, dtype=np.uint8))
+    far = bytearray(base)
+    for k in range(400):
+        d = int(rng.integers(1, 32000)); at = int(rng.integers(32100, 39000)); n = int(rng.integers(3, 40))
+        far[at:at + n] = far[at - d:at - d + n]
+    streams.append(raw_deflate(bytes(far), 9)); want.append(bytes(far))
+    lit = bytes((rng.integers(0, 64, 60000, dtype=np.uint8) + 32).astype(np.uint8))                   # literals only, 6 bits each
+    streams.append(raw_deflate(lit, 6, zlib.Z_HUFFMAN_ONLY)); want.append(lit)
+    rc, got = run(gi, streams)
+    assert rc == 0
+    o = 0
+    for i, w in enumerate(want):
+        assert got[o:o + len(w)] == w, "stream %d differs" % i
+        o += len(w)
+
+
+def test_a_distance_before_the_block_in_the_middle_of_a_stream(gi):
+    """A match that reaches in front of the block's first byte, met far inside the stream (a piece in the middle of the wave: found in
+    the write pass): a stream compressed against a preset dictionary, inflated without it."""
+    rng = np.random.default_rng(29)
+    zdict = bytes(rng.integers(0, 256, 20000, dtype=np.uint8))
+    data = bytes(rng.integers(0, 256, 6000, dtype=np.uint8)) + zdict[12000:16000] + bytes(rng.integers(0, 256, 30000, dtype=np.uint8))  # (the copy lies 14 000 bytes back, 6 000 are there)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, zdict)
+    bad = c.compress(data) + c.flush()
+    with pytest.raises(zlib.error):
+        zlib.decompress(bad, -15)
+    good = raw_deflate(data)
+    rc, _ = run(gi, [good] * 5 + [bad] + [good] * 5, [len(data)] * 11)
+    assert rc > 0
+
+
 @pytest.mark.parametrize("kind", ["truncated", "flipped", "wrong_size_short", "wrong_size_long", "bad_type", "bad_stored_len", "far_distance"])
 def test_corrupt_streams_are_reported(gi, kind):
     rng = np.random.default_rng(3)
