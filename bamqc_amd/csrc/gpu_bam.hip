@@ -15,8 +15,8 @@
 // record make next_batch return kUnsupported: the caller starts over with the host reader, which is the one to decide what the
 // user is told.
 //
-// The file — or one worker's byte range of it (set_range: the multi-GPU program) — is taken in few, large RUNS of BGZF blocks (an
-// inflate launch costs 20-50 ms whatever the number of blocks: gpu_inflate.hip): reader threads fill a ring of page-locked chunks, a
+// The file — or one worker's byte range of it (set_range: the multi-GPU program) — is taken in few, large RUNS of BGZF blocks (large
+// inflate launches are the cheapest per block: 10 ms for 9 K blocks, 29 ms for 45 K, gpu_inflate.hip): reader threads fill a ring of page-locked chunks, a
 // producer thread parses the block headers, copies and launches on one stream (the first run is read while the HIP runtime is
 // still starting); next_batch walks and decodes the current run's window on another; what a run leaves over (an unfinished
 // record) is copied in front of the next run's bytes.  Every buffer is allocated in open(): allocations, releases and page-locking
@@ -391,7 +391,7 @@ struct GpuBamReader::Impl {
     uint64_t win_abs0 = 0;      // (consumer) position of win[head] in the uncompressed stream
     uint64_t abs_of(size_t x) const { return win_abs0 + x - head; } // (x < head: what the run before left over)
     uint64_t stop_off() const { return mark_off == UINT64_MAX ? UINT64_MAX : (parsed_off < mark_off ? mark_off : parsed_off) + kBeyond; }
-    size_t run_bytes = 832u << 20; // (an inflate launch costs 20-50 ms whatever the number of blocks: few, large runs; the first one is 64 MB)
+    size_t run_bytes = 832u << 20; // (large inflate launches are the cheapest per block: few, large runs; the first one is 64 MB)
     size_t head = 16u << 20;    // room in front of a run's output for the unfinished record before it
     size_t out_cap = 0;         // bytes of a run's output buffer (head included): set in open() before the producer starts
     static const int kRuns = 3; // one being walked, one being inflated, one being read
