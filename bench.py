@@ -340,6 +340,14 @@ def e2e_leg(args, refs, cpu_kernel_value):
         t_cpu = time.perf_counter() - t0
         timed = sorted(runs[:5], key=lambda x: x["wall_s"])
         best = timed[len(timed) // 2]  # the MEDIAN of five runs (each started a second after the one before has left)
+        # the reader's inflate launches on the same file, each waited for (BQC_GB_TIMING=2): the largest kernels of a whole-file run
+        r = subprocess.run([exe, "-r", fa, "-o", os.path.join(tmp, "t.bamqc"), "-c", ",".join(names), bam], capture_output=True, text=True,
+                           env=dict(os.environ, BQC_GB_TIMING="2"))
+        inflate_runs = []
+        for m in re.finditer(r"run of (\d+) blocks, ([0-9.]+) MB -> ([0-9.]+) MB: inflate \+ crc ([0-9.]+) ms", r.stderr):
+            nb, mb_in, mb_out, ms = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))
+            inflate_runs.append({"blocks": nb, "compressed_MB": mb_in, "inflated_MB": mb_out, "ms_inflate_resolve_crc": ms,
+                                 "GB_per_s_in_plus_out": (mb_in + mb_out) / ms, "frac_of_8TBps": (mb_in + mb_out) / ms / 8000.0})
         # Ten files back to back, as a QC pipeline runs them: every front end starts the moment the one before has left, i.e. while
         # that run's worker process is still handing its page-locked buffers and its GPU context back — the price of the early exit
         # of tools/bamqualcheck.cpp is inside this wall time.
@@ -357,6 +365,8 @@ def e2e_leg(args, refs, cpu_kernel_value):
                 "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "wall_s_min": timed[0]["wall_s"], "wall_s_max": timed[-1]["wall_s"],
                 "back_to_back": {"files": n_b2b, "wall_s": t_b2b, "s_per_file": t_b2b / n_b2b, "reads_per_s": n_b2b * args.reads / t_b2b},
                 "host_cpus": cpu_limit(),
+                "inflate_launches": {"what": "k_inflate_wave + k_inflate_resolve + k_gi_crc per run of BGZF blocks of this file (each launch waited for; not bound by HBM: DESIGN.md 4.5)",
+                                     "runs": inflate_runs},
                 "runs": runs, "write_input_s": t_write,
                 "matches_oracle": filecmp.cmp(got, want, shallow=False), "oracle_prefix_reads": npre,
                 "cpu_port_e2e_reads_per_s": npre / t_cpu,
