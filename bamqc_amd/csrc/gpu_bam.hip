@@ -752,7 +752,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
     const size_t out_limit = std::min(kMaxRunOut, out_cap - head - 64);
     if (produced == 0) {
         // the first run: at least 64 MB (the first batch is there when the device is), and whatever more can be read until the device is up
-        static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)640 << 20;
+        static const size_t first_cap = getenv("BQC_GB_FIRST_MB") ? (size_t)std::max(64, atoi(getenv("BQC_GB_FIRST_MB"))) << 20 : (size_t)320 << 20; // (10 M-read file, 896 MB: 0.29 s with 640, 0.26 with 320, 0.27 with 192, 0.28 with 128 — tools/first_run_mb.py)
         const size_t piece = 32u << 20;
         size_t cap = std::min<size_t>(run_bytes, first_cap);
         if (stop_at != UINT64_MAX) cap = (size_t)std::min<uint64_t>(cap, stop_at + (1u << 17) - begin_off);
