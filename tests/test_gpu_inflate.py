@@ -163,6 +163,32 @@ def test_many_deflate_blocks_in_a_stream_and_long_codes(gi):
         o += len(w)
 
 
+def test_blocks_of_real_files(gi):
+    """Not the synthetic generator's statistics: source text, bytecode, ELF sections and numpy arrays found on the machine, in BGZF-sized
+    pieces at three compression levels (other code-length distributions, long codes, few and many deflate blocks per piece)."""
+    import glob
+    import sysconfig
+    paths = sorted(glob.glob(os.path.join(sysconfig.get_paths()["stdlib"], "*.py")))[:40]
+    paths += sorted(glob.glob(os.path.join(sysconfig.get_paths()["stdlib"], "__pycache__", "*.pyc")))[:20]
+    import sys
+    paths += [os.path.realpath(sys.executable)]  # (an ELF file)
+    blob = b"".join(open(q, "rb").read()[:1_500_000] for q in paths if os.path.isfile(q))
+    blob += np.arange(200_000, dtype=np.int32).tobytes() + np.linspace(0, 1, 100_000).tobytes()
+    assert len(blob) > 2_000_000
+    streams, want = [], []
+    for k, at in enumerate(range(0, min(len(blob), 24_000_000) - 65280, 65280)):
+        piece = blob[at:at + 65280]
+        s = raw_deflate(piece, (1, 6, 9)[k % 3])
+        if len(s) > 65536:
+            continue
+        streams.append(s)
+        want.append(piece)
+    assert len(streams) > 30
+    rc, got = run(gi, streams, [len(w) for w in want])
+    assert rc == 0
+    assert got == b"".join(want)
+
+
 def test_a_distance_before_the_block_in_the_middle_of_a_stream(gi):
     """A match that reaches in front of the block's first byte, met far inside the stream (a piece in the middle of the wave: found in
     the write pass): a stream compressed against a preset dictionary, inflated without it."""
