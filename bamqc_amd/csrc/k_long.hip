@@ -24,7 +24,9 @@
 #define KL_CYC    (KL_TRIP + 1024)                 // [2 mates][A C G T other qual][1024]: cycle t of the row (lane w = 1 + t / 16) at (t % 16) * 64 + w
 #define KL_LUT    (KL_CYC + 2 * 6 * 1024)          // [17][8] masks for "the first n of the lane's cycles" (k_short's table)
 #define KL_WORDS  (KL_LUT + 17 * 8)
+#ifndef KL_WAVES
 #define KL_WAVES  12
+#endif
 
 __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0)
 {
