@@ -64,6 +64,9 @@ def main():
                  "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
                  % (args.gpus, args.gpus, args.gpus, args.steps, args.warmup))
     dev = torch.device("cuda", local)
+    sharded_flag = os.path.join(tempfile_dir(), "bqc_bench_sharded_%s.done" % os.environ.get("MASTER_PORT", "0"))
+    if world > 1 and rank == 0 and os.path.exists(sharded_flag):
+        os.remove(sharded_flag)
 
     from bamqc_amd import Aggregator, _abi, synth
     lens = [250_000_000] if long_reads else [25_000_000] * 4
@@ -128,6 +131,22 @@ def main():
             total = agg.finalize()
             assert int(total[0]["scalars"][4]) == (args.reads * args.steps * world - int(total[0]["scalars"][0]) - int(total[0]["scalars"][3])) % 2 ** 32
 
+    e2e_sharded = None
+    if world > 1 and not args.no_e2e and not long_reads:
+        # What N GPUs do for a user: the PROGRAM `bin/bamqualcheck --gpus N` (one worker per card on its byte range of the file, ONE RCCL
+        # reduce from C++) on a BAM file, as child processes of rank 0 — a failure or a hang of that leg cannot take the line below with
+        # it.  The other ranks wait for a file, not in a collective: an RCCL barrier would spin on their cards beside the workers.
+        if rank == 0:
+            try:
+                e2e_sharded = e2e_sharded_leg(args, world, one_gpu_rehearsal)
+            except BaseException as e:  # noqa: BLE001 - whatever went wrong there, the benchmark's line is still printed
+                e2e_sharded = {"error": repr(e)[:400]}
+            open(sharded_flag, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(sharded_flag) and time.time() - t_wait < 900:
+                time.sleep(0.2)
+
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         value = world * args.reads * args.steps / elapsed
@@ -181,6 +200,8 @@ def main():
                                   "prefix_matches_oracle": c3.get("prefix_matches_oracle")}
         except Exception:
             pass
+        if e2e_sharded is not None:
+            out["e2e_sharded"] = e2e_sharded
         if e2e is not None:
             cv = out.get("cpu_baseline", {}).get("value")
             e2e["speedup_vs_cpu_port"] = (e2e["reads_per_s"] / cv) if cv else None
@@ -191,6 +212,75 @@ def main():
         agg.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def tempfile_dir():
+    import tempfile
+    return tempfile.gettempdir()
+
+
+def e2e_sharded_leg(args, world, one_gpu_rehearsal):
+    """`bin/bamqualcheck --gpus N` on a BAM file of 25 M reads per GPU (BGZF level 1, 2.2 GB per GPU: every worker's byte range is large
+    enough for the reader on the card), three runs, beside one single-GPU run of the same file: wall times, speed-up, byte identity of the outputs,
+    the size-independent properties of the output.  Child processes with a time limit each."""
+    import filecmp
+    import shutil
+    import signal
+    import statistics
+    import subprocess
+    import tempfile
+    from bamqc_amd import hostio
+    from tests import bamqc_text
+    exe = os.path.join(ROOT, "bin", "bamqualcheck")
+    reads = int(os.environ.get("BQC_BENCH_SHARDED_READS", str(min(25_000_000 * world, 200_000_000))))  # (2.2 GB of BAM per GPU: a worker's start-up of ~0.3 s is not all there is to see)
+    tmp = tempfile.mkdtemp(prefix="bqc_e2e_sharded_")
+    try:
+        names, lens = ["chr1", "chr2", "chr3", "chr4"], [25_000_000] * 4
+        bam, fa = os.path.join(tmp, "s.bam"), os.path.join(tmp, "s.fa")
+        t0 = time.time()
+        hostio.synth_stream(bam, fa, 1002, reads, names, lens, read_len=args.read_len, level=1)
+        t_write = time.time() - t0
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                  "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        env["BQC_TIMING"] = "1"
+        if one_gpu_rehearsal:
+            env["BQC_GPUS_SHARE_DEVICE"] = "1"  # (the workers share the one card; sums through pipes)
+
+        def run(extra, out):
+            t1 = time.perf_counter()
+            p = subprocess.Popen([exe] + extra + ["-r", fa, "-o", out, "-c", ",".join(names), bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                                 start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.communicate()
+                raise RuntimeError("timed out: bamqualcheck " + " ".join(extra))
+            dt = time.perf_counter() - t1
+            if p.returncode != 0:
+                raise RuntimeError("bamqualcheck %s failed (%d): %s" % (" ".join(extra), p.returncode, err[-600:]))
+            return dt, err
+
+        multi = []
+        for k in range(3):
+            time.sleep(1.0)
+            dt, err = run(["--gpus", str(world)], os.path.join(tmp, "m%d.bamqc" % k))
+            multi.append(dt)
+        loops = [float(x) for x in __import__("re").findall(r"record loop ([0-9.]+) s", err)]
+        time.sleep(1.0)
+        one, _ = run([], os.path.join(tmp, "one.bamqc"))
+        lanes = bamqc_text.parse(os.path.join(tmp, "m0.bamqc"))
+        bamqc_text.check_invariants(lanes["L1"], n_records=reads, read_len=args.read_len)
+        wall = statistics.median(multi)
+        return {"what": "bin/bamqualcheck --gpus %d (one worker per GPU on its byte range of the file, one RCCL reduce from C++) on a BAM file of %d reads (BGZF level 1, %.1f GB), "
+                        "default options; median of three runs; beside ONE run of the single-GPU program on the same file%s" %
+                        (world, reads, os.path.getsize(bam) / 1e9, "; REHEARSAL: all workers on one card" if one_gpu_rehearsal else ""),
+                "gpus": world, "reads": reads, "wall_s": wall, "runs_s": multi, "reads_per_s": reads / wall, "record_loops_s_last_run": loops,
+                "one_gpu_wall_s": one, "one_gpu_reads_per_s": reads / one, "speedup_vs_one_gpu": one / wall,
+                "identical_to_one_gpu": all(filecmp.cmp(os.path.join(tmp, "one.bamqc"), os.path.join(tmp, "m%d.bamqc" % k), shallow=False) for k in range(3)),
+                "invariants": "ok", "write_input_s": t_write}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def config3_line(args):
