@@ -87,6 +87,7 @@ _SIGNATURES = {
     "bqc_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "bqc_main_shard": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, _abi.SHARD_HOOK, C.c_void_p]),
     "bqc_main_multi": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int]),
+    "bqc_program_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_uint64]),
     "bqc_calib_read4": (C.c_int, [C.c_uint64, C.c_int]),
     "bqc_inflate_raw": (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]),
     "bqc_crc32": (C.c_uint32, [C.c_char_p, C.c_uint64]),

@@ -32,17 +32,14 @@ struct MT {
         st[0] = seed;
         for (int i = 1; i < 624; ++i) st[i] = 1812433253u * (st[i - 1] ^ (st[i - 1] >> 30)) + (uint32_t)i;
     }
-    static uint32_t twist(uint32_t m, uint32_t s0, uint32_t s1)
-    {
-        return m ^ (((s0 & 0x80000000u) | (s1 & 0x7fffffffu)) >> 1) ^ ((uint32_t)(-(int32_t)(s1 & 1u)) & 0x9908b0dfu);
-    }
+    // one generation of the recurrence x[i+624] = x[i+397] ^ A((x[i] & upper bit) | (x[i+1] & lower 31 bits)), all indices mod 624,
+    // computed in place in index order (entries behind i are already the new generation, as the recurrence wants)
     void reload()
     {
-        uint32_t* p = st;
-        int i;
-        for (i = 624 - 397; i--; ++p) *p = twist(p[397], p[0], p[1]);
-        for (i = 397; --i; ++p) *p = twist(p[397 - 624], p[0], p[1]);
-        *p = twist(p[397 - 624], p[0], st[0]);
+        for (int i = 0; i < 624; ++i) {
+            const uint32_t y = (st[i] & 0x80000000u) | (st[(i + 1) % 624] & 0x7fffffffu);
+            st[i] = st[(i + 397) % 624] ^ (y >> 1) ^ ((st[(i + 1) % 624] & 1u) ? 0x9908b0dfu : 0u);
+        }
         left = 624; next = 0;
     }
     uint32_t rand_int()
@@ -57,11 +54,11 @@ struct MT {
     }
 };
 
-size_t round_up_pow2(size_t size)
+size_t round_up_pow2(size_t size) // smallest power of two >= size (size >= 1)
 {
-    size--;
-    size |= size >> 1; size |= size >> 2; size |= size >> 4; size |= size >> 8; size |= size >> 16; size |= size >> 32;
-    return size + 1;
+    size_t p = 1;
+    while (p < size) p <<= 1;
+    return p;
 }
 
 const unsigned char kTwin[32] = {0, 20, 2, 7, 4, 5, 6, 3, 8, 9, 10, 11, 12, 13, 14, 15,

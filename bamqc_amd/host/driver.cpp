@@ -1232,6 +1232,18 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
 
 extern "C" int bqc_main(int argc, const char** argv) { return run_program(argc, argv, nullptr); }
 
+// The front end of `--gpus N` checks the command line ONCE, before it forks (a usage error is then printed once, and no worker
+// starts RCCL for it), and learns the input path the workers will use from the same parser they use.
+extern "C" int bqc_program_args(int argc, const char** argv, char* input_path, uint64_t cap)
+{
+    ProgramOptions opt;
+    std::string perr;
+    const int pr = parse_args(argc, argv, opt, perr);
+    if (pr == 1) fprintf(stderr, "%s\n", perr.c_str());
+    if (pr == 0 && input_path && cap) snprintf(input_path, (size_t)cap, "%s", opt.bamFile.c_str());
+    return pr;
+}
+
 extern "C" int bqc_main_shard(int argc, const char** argv, uint32_t shard_index, uint32_t shard_count, bqc_shard_hook hook, void* user)
 {
     if (!hook || shard_count == 0 || shard_index >= shard_count) return 1;

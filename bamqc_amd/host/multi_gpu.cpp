@@ -101,6 +101,7 @@ struct WorkerInfo {
 // bamqc_amd/distributed.py: split_is_consistent / fasta_order_is_consistent, restated
 bool split_is_consistent(const std::vector<WorkerInfo>& w, uint64_t file_size)
 {
+    if (file_size == 0) return false; // (a size that is not known verifies nothing: one process takes the file)
     const WorkerInfo* prev = nullptr;
     for (const WorkerInfo& e : w) {
         if (!(e.b0 < std::min(e.b1, file_size))) continue; // (a shard without blocks: its neighbours meet directly)
@@ -157,6 +158,15 @@ struct Worker {
     std::vector<std::string> names;
     std::vector<const char*> name_ptrs;
     std::vector<uint32_t> index;
+
+    // BQC_TEST_WORKER_FAULT="<rank>:<what>" (tests/test_gpu_sharded.py): worker <rank> fails the way <what> names
+    bool test_fault(const char* what) const
+    {
+        const char* e = getenv("BQC_TEST_WORKER_FAULT");
+        if (!e) return false;
+        const char* colon = strchr(e, ':');
+        return colon && (uint32_t)atoi(e) == rank && strcmp(colon + 1, what) == 0;
+    }
 
     void start_rccl()
     {
@@ -238,14 +248,20 @@ struct Worker {
         // ---- ONE sum of the flat state vectors onto worker 0
         const uint64_t words = bqc_state_words(ctx);
         rc = 0;
+        if (test_fault("wedge")) for (;;) pause(); // (test: a worker that never gets to the sum — the front end's deadline ends the run)
         if (use_rccl) {
             void* dvec = nullptr;
             hipStream_t s = nullptr;
-            if (hipSetDevice(device) != hipSuccess || hipMalloc(&dvec, words * 8) != hipSuccess || hipMemset(dvec, 0, words * 8) != hipSuccess ||
-                hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { fprintf(stderr, "ERROR: no device memory for the state vector\n"); rc = 1; }
-            if (!rc && (rc = bqc_state_export(ctx, dvec))) fprintf(stderr, "%s\n", bqc_last_error(ctx));
-            // (every worker enters the collective, also after a failure of its own: the others are in it)
-            if (dvec && s) {
+            if (test_fault("nomem") || hipSetDevice(device) != hipSuccess || hipMalloc(&dvec, words * 8) != hipSuccess || hipMemset(dvec, 0, words * 8) != hipSuccess ||
+                hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+                // A worker that cannot enter the collective ends at once, as in start_rccl: its peers are inside ncclReduce, where no
+                // message reaches them — the front end sees this process go (SIGCHLD) and ends them.
+                fprintf(stderr, "ERROR: worker %u: no device memory for the state vector\n", rank); fflush(stderr);
+                _exit(1);
+            }
+            if ((rc = bqc_state_export(ctx, dvec))) fprintf(stderr, "%s\n", bqc_last_error(ctx));
+            // (every worker that got here enters the collective, also after a failed export: the others are in it)
+            {
                 const ncclResult_t r = rccl.Reduce(dvec, dvec, (size_t)words, ncclUint64, ncclSum, 0, comm, s);
                 if (r != ncclSuccess) { fprintf(stderr, "ERROR: ncclReduce: %s\n", rccl.GetErrorString(r)); rc = 1; }
                 if (hipStreamSynchronize(s) != hipSuccess) { fprintf(stderr, "ERROR: the RCCL reduce failed on the device\n"); rc = 1; }
@@ -314,11 +330,19 @@ void reap(int)
             }
     }
 }
-// a message from a worker — or false as soon as any worker has failed (one that waits inside an RCCL call cannot be told)
-bool recv_watching(int fd, std::vector<uint8_t>& m)
+double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+// a message from a worker — or false as soon as any worker has failed (one that waits inside an RCCL call cannot be told), or when
+// `deadline` (CLOCK_MONOTONIC seconds; 0: none) has passed: a worker wedged on its card never exits and never answers
+bool recv_watching(int fd, std::vector<uint8_t>& m, double deadline)
 {
     for (;;) {
         if (g_worker_failed) return false;
+        if (deadline > 0 && now_s() > deadline) { fprintf(stderr, "bamqualcheck: a worker did not answer in time (BQC_GPUS_TIMEOUT / BQC_GPUS_LOOP_TIMEOUT); ending the run\n"); return false; }
         struct pollfd pf{fd, POLLIN, 0};
         const int k = poll(&pf, 1, 200);
         if (k < 0 && errno != EINTR) return false;
@@ -331,6 +355,10 @@ struct Coordinator {
     uint32_t world;
     bool use_rccl;
     uint64_t file_size;
+    // Deadlines per phase: the record loops (phase 1) are as long as the file is — no limit unless BQC_GPUS_LOOP_TIMEOUT (seconds) sets
+    // one; every later phase moves kilobytes and one reduce: BQC_GPUS_TIMEOUT seconds (default 300) from the end of the phase before.
+    double loop_timeout = 0, phase_timeout = 300;
+    double until(double secs) const { return secs > 0 ? now_s() + secs : 0; }
     bool tell_all(int32_t v)
     {
         bool ok = true;
@@ -343,14 +371,15 @@ struct Coordinator {
     {
         std::vector<uint8_t> m;
         if (use_rccl) { // the communicator's id: from worker 0 to all of them
-            if (!recv_watching(fds[0], m)) return false;
+            if (!recv_watching(fds[0], m, until(phase_timeout))) return false;
             for (uint32_t i = 0; i < world; ++i) if (!send_msg(fds[i], m)) return false;
         }
         // ---- phase 1: status, ranges, lane names
         std::vector<WorkerInfo> info(world);
         bool any_gone = false;
+        double dl = until(loop_timeout);
         for (uint32_t i = 0; i < world; ++i) {
-            if (!recv_watching(fds[i], m)) { any_gone = true; continue; }
+            if (!recv_watching(fds[i], m, dl)) { any_gone = true; continue; }
             Reader r{m};
             WorkerInfo& e = info[i];
             e.status = r.get<int32_t>(); e.has_ctx = r.get<int32_t>();
@@ -382,8 +411,9 @@ struct Coordinator {
         if (!tell_all(V_GO)) return false;
         // ---- phase 2: the coverage state down the chain
         bad = false;
+        dl = until(phase_timeout);
         for (uint32_t i = 0; i < world; ++i) {
-            if (!recv_watching(fds[i], m)) return false;
+            if (!recv_watching(fds[i], m, dl)) return false;
             Reader r{m};
             bad = r.get<int32_t>() || bad;
             std::vector<uint8_t> state = r.bytes();
@@ -394,9 +424,10 @@ struct Coordinator {
         if (!tell_all(V_GO)) return false;
         // ---- phase 3: the sum
         bad = false;
+        dl = until(phase_timeout);
         std::vector<uint64_t> sum;
         for (uint32_t i = 0; i < world; ++i) {
-            if (!recv_watching(fds[i], m)) return false;
+            if (!recv_watching(fds[i], m, dl)) return false;
             Reader r{m};
             bad = r.get<int32_t>() || bad;
             if (use_rccl) continue;
@@ -415,8 +446,9 @@ struct Coordinator {
         }
         // ---- phase 4: import on worker 0; the merged lane names go to the worker that writes
         bad = false;
+        dl = until(phase_timeout);
         for (uint32_t i = 0; i < world; ++i) {
-            if (!recv_watching(fds[i], m)) return false;
+            if (!recv_watching(fds[i], m, dl)) return false;
             Reader r{m};
             bad = r.get<int32_t>() || bad;
         }
@@ -446,8 +478,16 @@ extern "C" int bqc_main_multi(int argc, const char** argv, int n_gpus)
     std::vector<std::string> args(argv, argv + argc);
     for (size_t k = 1; k + 1 < args.size(); ++k)
         if ((args[k] == "-s" || args[k] == "--seed") && atoi(args[k + 1].c_str()) == 0) args[k + 1] = std::to_string((long long)std::max<time_t>(1, time(nullptr)));
+    // the command line is checked ONCE, here: a usage error is printed once and no worker starts (RCCL included) for it; the input
+    // path is the one the workers' own parser finds, not a guess from the file extension
     std::string bam;
-    for (size_t k = 1; k < args.size(); ++k) if (args[k].size() > 4 && args[k].compare(args[k].size() - 4, 4, ".bam") == 0) bam = args[k];
+    {
+        char path[4096] = "";
+        const int pr = bqc_program_args(argc, argv, path, sizeof path);
+        if (pr == 2) return 0;
+        if (pr != 0) return 1;
+        bam = path;
+    }
     fflush(stdout); fflush(stderr);
     std::vector<int> fds;
     g_children.assign((size_t)n_gpus, 0);
@@ -496,7 +536,9 @@ extern "C" int bqc_main_multi(int argc, const char** argv, int n_gpus)
         g_children[(size_t)i] = pid;
         sigprocmask(SIG_SETMASK, &old_mask, nullptr);
     }
-    Coordinator C{fds, (uint32_t)n_gpus, use_rccl, bam.empty() ? 0 : bqc_file_size(bam.c_str())};
+    Coordinator C{fds, (uint32_t)n_gpus, use_rccl, bam == "-" ? 0 : bqc_file_size(bam.c_str())};
+    if (const char* e = getenv("BQC_GPUS_TIMEOUT")) C.phase_timeout = atof(e);
+    if (const char* e = getenv("BQC_GPUS_LOOP_TIMEOUT")) C.loop_timeout = atof(e);
     const bool ok = C.run();
     if (!ok) { // a worker that waits for a message ends when its socket closes; one that waits inside an RCCL call is ended
         for (int fd : fds) shutdown(fd, SHUT_RDWR);

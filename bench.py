@@ -45,6 +45,8 @@ def main():
     if args.read_len is None:
         args.read_len = 10_000 if long_reads else 150
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -59,10 +61,8 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if world != args.gpus:  # (never re-exec: a process that has touched the GPU must not be replaced)
-        sys.exit("bench.py --gpus %d needs one process per GPU; launch it as\n  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                 "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d --steps %d --warmup %d"
-                 % (args.gpus, args.gpus, args.gpus, args.steps, args.warmup))
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     dev = torch.device("cuda", local)
     sharded_flag = os.path.join(tempfile_dir(), "bqc_bench_sharded_%s.done" % os.environ.get("MASTER_PORT", "0"))
     if world > 1 and rank == 0 and os.path.exists(sharded_flag):
@@ -212,6 +212,19 @@ def main():
         agg.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started like `--gpus 1`: this process has touched no GPU (torch is not even imported), so it starts the N ranks as
+    CHILD processes through torch.distributed.run (never an exec), relays their output — rank 0's JSON line — and leaves with their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def tempfile_dir():

@@ -148,6 +148,11 @@ int bqc_main_shard(int argc, const char** argv, uint32_t shard_index, uint32_t s
  * one card, BQC_GPUS_SHARE_DEVICE=1).  argv: the program's arguments (without --gpus).  Returns the exit status. */
 int bqc_main_multi(int argc, const char** argv, int n_gpus);
 
+/* The program's command line, parsed as bqc_main parses it (CommandLineParser.hpp:43-149) without running anything: 0 = valid
+ * (the input path — a file name or "-" — is copied to input_path), 1 = usage error (message printed on stderr), 2 = -h /
+ * --version answered on stdout.  bqc_main_multi calls it once before it forks its workers. */
+int bqc_program_args(int argc, const char** argv, char* input_path, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

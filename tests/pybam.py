@@ -155,10 +155,7 @@ def _bgzf_block(payload, level=6):
             struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
 
 
-def write_bam(path, header_text, refs, records, block=40000, rng=None):
-    """Independent BAM writer for tests.  records: dicts with rid pos mapq flag rnext pnext tlen name (str), cigar (uint32
-    words), seq (packed nibbles), qual (bytes), l_seq, tags (bytes, already encoded).  BGZF blocks are cut at arbitrary
-    byte offsets (records straddle them), with varying block sizes when `rng` is given."""
+def _bam_bytes(header_text, refs, records):
     out = bytearray(b"BAM\x01" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs)))
     for name, ln in refs:
         out += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
@@ -169,6 +166,14 @@ def write_bam(path, header_text, refs, records, block=40000, rng=None):
                            r["rnext"], r.get("pnext", -1), r["tlen"])
         body += name + cig + bytes(r["seq"]) + bytes(r["qual"]) + r["tags"]
         out += struct.pack("<i", len(body)) + body
+    return out
+
+
+def write_bam(path, header_text, refs, records, block=40000, rng=None):
+    """Independent BAM writer for tests.  records: dicts with rid pos mapq flag rnext pnext tlen name (str), cigar (uint32
+    words), seq (packed nibbles), qual (bytes), l_seq, tags (bytes, already encoded).  BGZF blocks are cut at arbitrary
+    byte offsets (records straddle them), with varying block sizes when `rng` is given."""
+    out = _bam_bytes(header_text, refs, records)
     with open(path, "wb") as f:
         p = 0
         while p < len(out):
@@ -176,3 +181,71 @@ def write_bam(path, header_text, refs, records, block=40000, rng=None):
             f.write(_bgzf_block(bytes(out[p:p + n]), level=6 if rng is None else int(rng.integers(0, 10))))
             p += n
         f.write(_bgzf_block(b""))
+
+
+MEMBER_KINDS = ("stored", "fixed", "level9", "flush_split", "level1", "empty")
+
+
+def _bgzf_member(payload, kind, rng):
+    """One BGZF member whose DEFLATE stream is of the given kind: `stored` (level 0: stored blocks only), `fixed` (Z_FIXED: fixed
+    Huffman codes), `level9` / `level1` (dynamic codes), `flush_split` (the payload compressed in 2-5 pieces with Z_FULL_FLUSH
+    between them: several deflate blocks, an empty stored block after each, no match reaches back over a flush point).
+    Returns None when the member would not fit BGZF's 64 KiB."""
+    import zlib
+    if kind == "stored":
+        c = zlib.compressobj(0, zlib.DEFLATED, -15)
+        comp = c.compress(payload) + c.flush()
+    elif kind == "fixed":
+        c = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        comp = c.compress(payload) + c.flush()
+    elif kind == "flush_split":
+        c = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15)
+        cuts = sorted(int(x) for x in rng.integers(0, len(payload) + 1, size=int(rng.integers(1, 5))))
+        comp, last = b"", 0
+        for cut in cuts:
+            comp += c.compress(payload[last:cut]) + c.flush(zlib.Z_FULL_FLUSH)
+            last = cut
+        comp += c.compress(payload[last:]) + c.flush()
+    else:
+        c = zlib.compressobj(9 if kind == "level9" else 1, zlib.DEFLATED, -15)
+        comp = c.compress(payload) + c.flush()
+    bsize = 18 + len(comp) + 8
+    if bsize > 65536:
+        return None
+    return (bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", bsize - 1) + comp +
+            struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def write_bam_adversarial(path, header_text, refs, records, rng, tiny_until=0.5):
+    """The same records as a BGZF file no writer in the field produces but every reader must take: members alternate between the kinds
+    of MEMBER_KINDS (empty members in the middle of the file included); the first `tiny_until` of the stream is cut into payloads of
+    1..200 bytes (every record of that part straddles at least one member boundary, most straddle several), the rest into payloads
+    of 1..65 280 bytes with the extremes (1, 65 280) forced in.  Returns the list of (kind, payload bytes) written."""
+    out = _bam_bytes(header_text, refs, records)
+    members = []
+    forced = [65280, 1, 65280, 2, 1]
+    with open(path, "wb") as f:
+        p, k = 0, 0
+        while p < len(out):
+            kind = MEMBER_KINDS[k % len(MEMBER_KINDS)]
+            k += 1
+            if kind == "empty":
+                f.write(_bgzf_member(b"", "level1", rng))
+                members.append((kind, 0))
+                continue
+            if p < tiny_until * len(out):
+                n = int(rng.integers(1, 201))
+            elif forced:
+                n = forced.pop()
+            else:
+                n = int(rng.integers(1, 65281))
+            while True:
+                m = _bgzf_member(bytes(out[p:p + n]), kind, rng)
+                if m is not None:
+                    break
+                n = n * 3 // 4  # (fixed codes on poorly compressible bytes: the member must stay within 64 KiB)
+            f.write(m)
+            members.append((kind, min(n, len(out) - p)))
+            p += n
+        f.write(_bgzf_block(b""))
+    return members

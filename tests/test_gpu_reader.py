@@ -217,3 +217,25 @@ def test_gpu_reader_against_an_independent_decoder(tmp_path):
         got = [dict((k, np.array(v, copy=True)) for k, v in x.items() if isinstance(v, np.ndarray)) for x in b.batches(1777)]
         b.close()
         same(want, {k: np.concatenate([c[k] for c in got]) for k in got[0]})
+
+
+def test_gpu_reader_on_adversarial_bgzf_members(tmp_path, monkeypatch):
+    """The reader on the card against tests/pybam.columns on a file no writer in the field produces but every reader must take
+    (tests/pybam.py: write_bam_adversarial): BGZF members alternating stored / fixed-Huffman / level-9 / Z_FULL_FLUSH-split (several
+    deflate blocks per member) / level-1 / EMPTY, payloads from 1 to 65 280 bytes, every record of the file's first half across at
+    least one member boundary, a header of 150 KB that spans many members.  Whole, in runs of 1 MB (records and members across run
+    boundaries), and with every inflate kernel variant."""
+    from tests import pybam
+    from tests.test_host_io import _wild_bam
+    path = str(tmp_path / "adv.bam")
+    _wild_bam(path, 37, 5000, extra_nm=False, adversarial=True, pad_header=4000)
+    want, refs, _, _ = pybam.columns(path, [1, 1, 1])
+    for env in ({}, {"BQC_GB_RUN_MB": "1"}, {"BQC_GI_WAVE": "0"}, {"BQC_GI_WAVE": "0", "BQC_GI_TWO_PHASE": "0"}, {"BQC_GI_TWO_PHASE": "0", "BQC_GI_LEAN": "32"}):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            b = hostio.BamFile(path, gpu=0)
+            b.set_main_chrom(np.ones(3, np.uint8))
+            got = [dict((k, np.array(v, copy=True)) for k, v in x.items() if isinstance(v, np.ndarray)) for x in b.batches(1234)]
+            b.close()
+        same(want, {k: np.concatenate([c[k] for c in got]) for k in got[0]})

@@ -139,3 +139,51 @@ def test_rccl_set_up_and_reduce_run_on_one_card(inputs, launcher):
         r = subprocess.run([sys.executable, "-m", "bamqc_amd.dist_cli"] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert same(single, out)
+
+
+def test_a_worker_that_cannot_enter_the_reduce_ends_the_run(inputs):
+    """BQC_REDUCE unset: the RCCL path (`--gpus 1` forced through it — RCCL refuses two ranks on the one card of the test box).  A worker
+    whose device allocation for the state vector fails must not leave its peers inside ncclReduce for ever: it exits at once
+    (multi_gpu.cpp, as start_rccl's die()), the front end sees it go and reports failure — exit status 1, well inside the time limit."""
+    bam, fa, single, d = inputs
+    out = str(d / "fault_nomem.bamqc")
+    env = dict(os.environ, BQC_GPUS_FORCE="1", BQC_TEST_WORKER_FAULT="0:nomem")
+    env.pop("BQC_REDUCE", None)
+    r = subprocess.run([EXE, "--gpus", "1", "-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "no device memory for the state vector" in r.stderr
+
+
+@pytest.mark.parametrize("reduce", ["rccl", "pipe"])
+def test_a_wedged_worker_meets_the_front_ends_deadline(inputs, reduce):
+    """A worker that never answers (wedged on its card) and never exits: the front end's per-phase deadline (BQC_GPUS_TIMEOUT) ends the
+    run with status 1 and kills the workers."""
+    import time
+    bam, fa, single, d = inputs
+    out = str(d / ("fault_wedge_%s.bamqc" % reduce))
+    if reduce == "rccl":
+        env = dict(os.environ, BQC_GPUS_FORCE="1", BQC_TEST_WORKER_FAULT="0:wedge", BQC_GPUS_TIMEOUT="3")
+        env.pop("BQC_REDUCE", None)
+        world = 1
+    else:
+        env = dict(os.environ, BQC_GPUS_SHARE_DEVICE="1", BQC_TEST_WORKER_FAULT="1:wedge", BQC_GPUS_TIMEOUT="3")
+        world = 2
+    t0 = time.time()
+    r = subprocess.run([EXE, "--gpus", str(world), "-r", fa, "-o", out, "-c", "chr1,chr2", "-i", "800", bam], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "did not answer in time" in r.stderr
+    assert time.time() - t0 < 60
+
+
+def test_usage_errors_are_reported_once_by_the_front_end(inputs):
+    """`--gpus N` checks the command line before it forks: one message, no worker started; `-o x.bam` behind the input does not
+    confuse the front end about which file is the input (it asks the program's own parser)."""
+    bam, fa, single, d = inputs
+    r = subprocess.run([EXE, "--gpus", "3", "-r", fa, "-o", str(d / "u.bamqc"), "--no-such-option", bam], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, BQC_GPUS_SHARE_DEVICE="1"))
+    assert r.returncode == 1
+    assert r.stderr.count("illegal option") == 1, r.stderr
+    out = str(d / "looks_like_input.bam")
+    rcs, outs = run_ranks(2, ["-r", fa, "-c", "chr1,chr2", "-i", "800", bam, "-o", out], launcher="cxx")
+    assert rcs == [0, 0], outs
+    assert same(single, out)

@@ -193,7 +193,7 @@ def test_sam_text_decodes_to_the_same_batches(synth_files, tmp_path):
         assert np.array_equal(gb[k], gs[k]), k
 
 
-def _wild_bam(path, seed, n_reads, extra_nm=True):
+def _wild_bam(path, seed, n_reads, extra_nm=True, adversarial=False, pad_header=0):
     """Wild records (tests/test_gpu_fuzz.py) as a BAM with every tag type around the three tags the decoder looks for."""
     from tests.test_gpu_fuzz import wild_batch
     from tests import pybam
@@ -238,7 +238,11 @@ def _wild_bam(path, seed, n_reads, extra_nm=True):
                          cigar=cols["cigar"][co:co + nc], seq=cols["seq"][so:so + (L + 1) // 2], qual=cols["qual"][qo:qo + L], l_seq=L,
                          tags=b"".join(tags)))
         so += (L + 1) // 2; qo += L; co += nc
-    pybam.write_bam(path, text, [("chr%d" % (i + 1), len(r)) for i, r in enumerate(refs)], recs, rng=rng)
+    text += "".join("@CO\tpadding line %d of a long header\n" % i for i in range(pad_header))
+    if adversarial:  # members of every DEFLATE kind, payloads of 1 .. 65 280 bytes, every record of the first half across member boundaries
+        pybam.write_bam_adversarial(path, text, [("chr%d" % (i + 1), len(r)) for i, r in enumerate(refs)], recs, rng)
+    else:
+        pybam.write_bam(path, text, [("chr%d" % (i + 1), len(r)) for i, r in enumerate(refs)], recs, rng=rng)
     return cols, exp_extra
 
 
@@ -266,6 +270,26 @@ def test_wild_records_and_tags_decode(tmp_path):
             extra += [(int(r) + base, int(v)) for r, v in zip(b["nm_extra_read"], b["nm_extra_val"])]
         base += len(b["flag"])
     assert extra == exp_extra
+
+
+def test_adversarial_bgzf_members_through_the_host_reader(tmp_path):
+    """A BGZF file of stored / fixed-Huffman / level-9 / flush-split / empty members with payloads of 1 .. 65 280 bytes, records across
+    member boundaries everywhere in its first half, a 150 KB header across several members: the host reader's columns against the
+    independent decoder's (tests/pybam.py: gzip + struct)."""
+    from tests import pybam
+    p = str(tmp_path / "adv.bam")
+    _wild_bam(p, 31, 4000, extra_nm=False, adversarial=True, pad_header=4000)
+    want, refs, _, _ = pybam.columns(p, [1, 1, 1])
+    for threads in ("1", "4"):
+        os.environ["BQC_IO_THREADS"] = threads
+        try:
+            f = hostio.BamFile(p)
+            f.set_main_chrom(np.ones(3, np.uint8))
+            got = list(f.batches(max_reads=999))
+        finally:
+            del os.environ["BQC_IO_THREADS"]
+        for k in ("flag", "mapq", "lane", "rid", "pos", "tlen", "nm", "as_", "l_seq", "n_cigar", "seq", "qual", "cigar"):
+            assert np.array_equal(np.concatenate([b[k] for b in got]), want[k]), (k, threads)
 
 
 def test_parallel_record_walk_equals_the_serial_walk(tmp_path):
