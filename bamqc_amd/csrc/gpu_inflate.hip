@@ -635,6 +635,90 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 #include "gpu_inflate_wave.inc"
 
 // ---------------------------------------------------------------------------------------------------
+// CRC-32 of the inflated blocks on the card (for readers that keep the inflated bytes there: csrc/gpu_bam.hip)
+// ---------------------------------------------------------------------------------------------------
+// A wave per block: lane 0 takes the first usize - 63 L bytes, every other lane L = usize / 64 bytes; each computes the standard
+// CRC-32 of its piece (table in LDS), then the pieces are joined pairwise — crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)
+// (the identity behind zlib's crc32_combine; reflected polynomial arithmetic) — where every right-hand piece has the length
+// L * 2^level, so one squaring per level gives the multiplier.
+namespace {
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+    }
+    return p;
+}
+// the same at compile time: the constants of k_inflate_resolve's CRC
+constexpr uint32_t gi_cx_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+    }
+    return p;
+}
+constexpr uint32_t gi_cx_xpow8(uint32_t n) // x^(8 n) mod P
+{
+    uint32_t p = 0x80000000u, base = 0x00800000u;
+    while (n) {
+        if (n & 1u) p = gi_cx_mulmod(p, base);
+        base = gi_cx_mulmod(base, base);
+        n >>= 1;
+    }
+    return p;
+}
+struct GiCrcK {
+    static constexpr uint32_t x4096 = gi_cx_xpow8(4096u); // a row of the resolve kernel's gather pass further left
+    // x^(32 * 2^lv): level lv of the tree that joins the 1024 columns (a column = 4 bytes)
+    __device__ static constexpr uint32_t word_level(int lv)
+    {
+        constexpr uint32_t t[10] = {gi_cx_xpow8(4u), gi_cx_xpow8(8u), gi_cx_xpow8(16u), gi_cx_xpow8(32u), gi_cx_xpow8(64u), gi_cx_xpow8(128u), gi_cx_xpow8(256u), gi_cx_xpow8(512u),
+                                    gi_cx_xpow8(1024u), gi_cx_xpow8(2048u)};
+        return t[lv];
+    }
+    // x^(8 * 2^b), b < 12
+    __device__ static uint32_t byte_pow2(uint32_t b)
+    {
+        constexpr uint32_t t[12] = {gi_cx_xpow8(1u), gi_cx_xpow8(2u), gi_cx_xpow8(4u), gi_cx_xpow8(8u), gi_cx_xpow8(16u), gi_cx_xpow8(32u), gi_cx_xpow8(64u), gi_cx_xpow8(128u),
+                                    gi_cx_xpow8(256u), gi_cx_xpow8(512u), gi_cx_xpow8(1024u), gi_cx_xpow8(2048u)};
+        uint32_t v = t[0];
+#pragma unroll
+        for (int k = 1; k < 12; ++k) v = b == (uint32_t)k ? t[k] : v; // (selects: no table in memory)
+        return v;
+    }
+    // 0xFFFFFFFF * x^(8 * 4096 * rows), rows 1 .. 16: what the CRC's start value has become behind 4096 * rows bytes
+    __device__ static uint32_t start_times_rows(uint32_t rows)
+    {
+        constexpr uint32_t t[16] = {gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 1)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 2)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 3)),
+                                    gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 4)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 5)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 6)),
+                                    gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 7)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 8)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 9)),
+                                    gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 10)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 11)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 12)),
+                                    gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 13)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 14)), gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 15)),
+                                    gi_cx_mulmod(0xFFFFFFFFu, gi_cx_xpow8(4096u * 16))};
+        uint32_t v = t[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v = rows == (uint32_t)(k + 1) ? t[k] : v;
+        return v;
+    }
+};
+__device__ uint32_t crc_xpow8(uint32_t n) // x^(8 n) mod P
+{
+    uint32_t p = 0x80000000u, base = 0x00800000u;
+    while (n) { // (n is the same for the whole wave)
+        if (n & 1u) p = crc_mulmod(p, base);
+        base = crc_mulmod(base, base);
+        n >>= 1;
+    }
+    return p;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
 // phase 2: the matches of a block, resolved by pointer jumping
 // ---------------------------------------------------------------------------------------------------
 // A match says "byte p is byte p - distance"; following that from byte to byte ends at a literal, which phase 1 has written.  Phase 1
@@ -648,22 +732,49 @@ template <int NL> __global__ __launch_bounds__(NL) void k_inflate_lean(const uin
 // per link, between workgroup barriers or through a bitmap of final bytes — took 65 and 83 ms for 45 K blocks).  Reading an index
 // that another thread is just replacing is harmless: old and new value are both ancestors.  Last, every match byte is fetched from
 // its literal (a gather inside the block's 64 KiB, which the workgroup has just touched) and stored, four bytes per thread.
+// The block's CRC-32 is checked HERE (round 4; k_gi_crc below stays for the one-phase kernels): every final byte passes through this
+// workgroup's registers in the last pass, four bytes per thread and step at p = 4 tid + 4096 j — a layout a CRC does not like (a
+// thread's words lie 4096 bytes apart), taken care of by linearity.  With raw(M) = the CRC register after M from a ZERO start (no
+// final inversion): raw(A || B) = raw(A) x^(8|B|) + raw(B) (mod P, reflected arithmetic: crc_mulmod), leading zeros change nothing,
+// and the message is the sum of its 1024 "columns" (column t: the words at 4t + 4096j, zeros elsewhere).  So thread t runs a Horner
+// scheme down its column — acc = acc * x^(8*4096) + raw(word): the word's raw CRC by slicing-by-4 (four LDS look-ups), the
+// multiplication by the constant through four more 256-entry tables — then the columns are joined, acc_t * x^(32 (1023 - t)), in a
+// tree: six levels by shuffles, four through LDS, each level's multiplier the square of the one before.  That is raw(M || zeros up to
+// the next multiple of 4096), = raw(M) x^(8 pad); and the block's CRC-32 is ~(raw(M) + 0xFFFFFFFF x^(8 |M|)) (the standard start value
+// is linear too).  Both sides times x^(8 pad): no division is needed, two powers of x per block by a single lane.  8 KB of tables
+// beside the 128 KB of indices; the separate kernel read the 2.9 GB of a 45 K-block launch once more (and fetched every line 4-8 times:
+// a lane per kilobyte, profiles/r3_pmc_e2e_gpu_reader.json) for 1.7-3.3 ms.
 #define GI_RESOLVE_LDS (131072 + 64)
+#define GI_RESOLVE_LDS_CRC (131072 + 64 + 8192 + 128)
 __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, const uint32_t* __restrict__ bitmap,
-                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) counters */)
+                                                           const uint32_t* __restrict__ ntok, unsigned long long* __restrict__ stats /* nullptr, or (BQC_GI_STATS) counters */,
+                                                           const uint32_t* __restrict__ expect /* nullptr: no CRC check here */, uint32_t* __restrict__ status)
 {
-    extern __shared__ uint16_t ridx[]; // [65536]
+    extern __shared__ uint16_t ridx[]; // [65536], then (expect) the CRC tables
     const uint32_t bi = blockIdx.x, tid = threadIdx.x;
     if (bi >= n_blocks) return;
     const uint32_t n = ntok[bi];
-    if (n == 0u) return; // no match in this block (or it failed): phase 1 has written all of it
+    if (n == 0u && !expect) return; // no match in this block (or it failed): phase 1 has written all of it
     const GiBlock blk = blocks[bi];
     uint8_t* const o0 = out + blk.uoff;
     const uint32_t usize = blk.usize, upad = (usize + 7u) & ~7u;
+    if (usize == 0u) { if (tid == 0u && expect && expect[bi] != 0u) atomicOr(status, (uint32_t)GI_ERR_CRC); return; }
     const uint32_t* const bm = bitmap + gi_bm_base(blocks, bi);
     uint32_t* const pair = (uint32_t*)ridx;
+    uint32_t* const ctab = (uint32_t*)(ridx + 65536 + 32);   // [4][256] slicing by 4: ctab[k][b] = raw CRC of byte b followed by k zero bytes
+    uint32_t* const mtab = ctab + 1024;                       // [4][256] mtab[k][b] = (b << 8k) * x^(8*4096)
+    uint32_t* const wsum = mtab + 1024;                       // [16] the waves' partial results
     long long tc[5] = {stats ? clock64() : 0, 0, 0, 0, 0}; // (BQC_GI_STATS: where the workgroup's clocks go)
     const long long wc0 = stats ? wall_clock64() : 0;
+    if (expect) { // the tables (before the first barrier below)
+        const uint32_t b = tid & 255u, k = tid >> 8;
+        uint32_t c = b;
+        for (int i = 0; i < 8; ++i) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+        for (uint32_t z = 0; z < k; ++z) { uint32_t c2 = c; for (int i = 0; i < 8; ++i) c2 = (c2 >> 1) ^ ((c2 & 1u) ? 0xEDB88320u : 0u); c = c2; } // k zero bytes behind it
+        ctab[k * 256u + b] = c;
+        mtab[k * 256u + b] = crc_mulmod(b << (8u * k), GiCrcK::x4096);
+    }
+    if (n != 0u) {
     for (uint32_t q = tid; q < upad / 2u; q += 1024u) pair[q] = (2u * q) | ((2u * q + 1u) << 16); // every byte its own root
     __syncthreads();
     if (stats) tc[1] = clock64();
@@ -697,63 +808,80 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
         }
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
-    if (stats) tc[3] = clock64();
+    if (stats) { tc[3] = clock64(); if (tid == 0u) atomicAdd(&stats[2], (unsigned long long)rounds); }
+    } else __syncthreads(); // (a block without matches: only its CRC is looked at; the tables are complete behind this barrier)
     // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte).  (All loads in front of all
     // stores — the compiler has to take a store for a possible source of the next load — measured no faster.)
+    uint32_t acc = 0;
+#define GI_CRC_COL(x) do { if (expect) { const uint32_t w_ = (x); \
+        acc = mtab[acc & 255u] ^ mtab[256u + ((acc >> 8) & 255u)] ^ mtab[512u + ((acc >> 16) & 255u)] ^ mtab[768u + (acc >> 24)] ^ \
+              ctab[768u + (w_ & 255u)] ^ ctab[512u + ((w_ >> 8) & 255u)] ^ ctab[256u + ((w_ >> 16) & 255u)] ^ ctab[w_ >> 24]; } } while (0)
     for (uint32_t p = 4u * tid; p < usize; p += 4096u) {
-        const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
-        const uint32_t i0 = v0 & 0xFFFFu, i1 = v0 >> 16, i2 = v1 & 0xFFFFu, i3 = v1 >> 16;
-        if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) continue; // four literals
+        uint32_t i0 = p, i1 = p + 1u, i2 = p + 2u, i3 = p + 3u;
+        if (n != 0u) {
+            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
+            i0 = v0 & 0xFFFFu; i1 = v0 >> 16; i2 = v1 & 0xFFFFu; i3 = v1 >> 16;
+        }
         if (p + 4u <= usize) {
+            if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) { // four literals: in place already
+                if (expect) GI_CRC_COL(*(const gi_u32_u*)(o0 + p));
+                continue;
+            }
             const uint32_t w = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24);
             *(gi_u32_u*)(o0 + p) = w;
+            GI_CRC_COL(w);
         } else {
             const uint32_t ii[4] = {i0, i1, i2, i3};
-            uint8_t vv[4];
+            uint8_t vv[4] = {0, 0, 0, 0};
             for (uint32_t j = 0; p + j < usize; ++j) vv[j] = o0[ii[j]];
             for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = vv[j];
+            GI_CRC_COL((uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24)); // (zeros behind the block's end)
         }
     }
-    if (stats) {
+#undef GI_CRC_COL
+    if (expect) {
+        // rows this thread has not met (its column lies behind the block's end in the last row): the zero word of that row
+        const uint32_t rows = (usize + 4095u) >> 12;
+        if (4u * tid + 4096u * (rows - 1u) >= usize) acc = mtab[acc & 255u] ^ mtab[256u + ((acc >> 8) & 255u)] ^ mtab[512u + ((acc >> 16) & 255u)] ^ mtab[768u + (acc >> 24)];
+        // the columns joined: c = c_left * x^(32 * 2^level) + c_right
+        uint32_t c = acc;
+#pragma unroll
+        for (int lv = 0; lv < 6; ++lv) {
+            const uint32_t right = __shfl_down(c, 1u << lv, 64);
+            c = crc_mulmod(c, GiCrcK::word_level(lv)) ^ right; // (only the lanes whose index is a multiple of 2 << lv hold a joined piece; the others' values are not used)
+        }
+        if ((tid & 63u) == 0u) wsum[tid >> 6] = c;
+        __syncthreads();
+        if (tid < 64u) {
+            c = tid < 16u ? wsum[tid] : 0u;
+#pragma unroll
+            for (int lv = 6; lv < 10; ++lv) {
+                const uint32_t right = __shfl_down(c, 1u << (lv - 6), 64);
+                c = crc_mulmod(c, GiCrcK::word_level(lv)) ^ right;
+            }
+            // c (lane 0) = raw(M || zeros up to 4096 * rows) = raw(M) x^(8 pad).  x^(8 pad), pad < 4096: the product of x^(8 * 2^b) over
+            // the bits b of pad — twelve factors in twelve lanes, multiplied in a tree
+            const uint32_t pad = 4096u * rows - usize;
+            uint32_t f = tid < 12u && ((pad >> tid) & 1u) ? GiCrcK::byte_pow2(tid) : 0x80000000u; // (0x80000000 = 1)
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) f = crc_mulmod(f, __shfl_down(f, d, 64));
+            if (tid == 0u) {
+                const uint32_t lhs = c ^ GiCrcK::start_times_rows(rows);   // + 0xFFFFFFFF x^(8 * 4096 * rows)
+                const uint32_t rhs = crc_mulmod(~expect[bi], f);
+                if (lhs != rhs) atomicOr(status, (uint32_t)GI_ERR_CRC);
+            }
+        }
+    }
+    if (stats && n != 0u) {
         __syncthreads();
         if (tid == 0u) {
             tc[4] = clock64();
-            atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n); atomicAdd(&stats[2], (unsigned long long)rounds);
+            atomicAdd(&stats[0], 1ull); atomicAdd(&stats[7], (unsigned long long)n);
             for (int k = 0; k < 4; ++k) atomicAdd(&stats[8 + k], (unsigned long long)(tc[k + 1] - tc[k]));
             atomicAdd(&stats[12], (unsigned long long)(wall_clock64() - wc0));
         }
     }
 }
-
-// ---------------------------------------------------------------------------------------------------
-// CRC-32 of the inflated blocks on the card (for readers that keep the inflated bytes there: csrc/gpu_bam.hip)
-// ---------------------------------------------------------------------------------------------------
-// A wave per block: lane 0 takes the first usize - 63 L bytes, every other lane L = usize / 64 bytes; each computes the standard
-// CRC-32 of its piece (table in LDS), then the pieces are joined pairwise — crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)
-// (the identity behind zlib's crc32_combine; reflected polynomial arithmetic) — where every right-hand piece has the length
-// L * 2^level, so one squaring per level gives the multiplier.
-namespace {
-__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
-{
-    uint32_t p = 0;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        p ^= (a & (0x80000000u >> i)) ? b : 0u;
-        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
-    }
-    return p;
-}
-__device__ uint32_t crc_xpow8(uint32_t n) // x^(8 n) mod P
-{
-    uint32_t p = 0x80000000u, base = 0x00800000u;
-    while (n) { // (n is the same for the whole wave)
-        if (n & 1u) p = crc_mulmod(p, base);
-        base = crc_mulmod(base, base);
-        n >>= 1;
-    }
-    return p;
-}
-} // namespace
 
 __global__ __launch_bounds__(256) void k_gi_crc(const uint8_t* __restrict__ out, const GiBlock* __restrict__ blocks, const uint32_t* __restrict__ expect,
                                                   uint32_t n_blocks, uint32_t* __restrict__ status)
@@ -811,7 +939,7 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     // more blocks than the kernel with root tables holds at once (72 per CU): the lean kernel takes them in one go; for fewer blocks the
     // root tables are faster.  BQC_GI_LEAN: 0 never, N always with N blocks per workgroup
     const int lean_env = getenv("BQC_GI_LEAN") ? atoi(getenv("BQC_GI_LEAN")) : -1;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, GI_RESOLVE_LDS);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inflate_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, GI_RESOLVE_LDS_CRC);
     (void)attr;
     const bool two_phase = bqc_gpu_inflate_two_phase() != 0; // (see the comment at struct Out)
     if (!two_phase || !d_ntok) d_tok = nullptr;
@@ -845,8 +973,11 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     else if (lean) { if (lean == 8) GI_LAUNCH_L(8); else if (lean == 32) GI_LAUNCH_L(32); else if (lean == 16) GI_LAUNCH_L(16); else GI_LAUNCH_L(64); }
     else if (lanes == 2) GI_LAUNCH_D(2); else if (lanes == 4) GI_LAUNCH_D(4); else if (lanes == 16) GI_LAUNCH_D(16); else GI_LAUNCH_D(8);
     const bool no_resolve = getenv("BQC_GI_NO_RESOLVE") != nullptr; // (timing experiments: phase 1 alone; the output then lacks its matches)
-    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), GI_RESOLVE_LDS, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64, d_ntok, d_stats);
-    if (d_crc) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
+    // the CRC-32s are checked by the resolve kernel, which has every final byte in its hands (BQC_GI_CRC_KERNEL=1, or one phase: k_gi_crc)
+    const bool crc_in_resolve = d_crc && d_tok && !no_resolve && !(getenv("BQC_GI_CRC_KERNEL") && atoi(getenv("BQC_GI_CRC_KERNEL")) == 1);
+    if (d_tok && !no_resolve) hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(1024), crc_in_resolve ? GI_RESOLVE_LDS_CRC : GI_RESOLVE_LDS, (hipStream_t)stream, d_blocks, n_blocks, d_out, d_tok64,
+                                                 d_ntok, d_stats, crc_in_resolve ? d_crc : nullptr, d_status);
+    if (d_crc && !crc_in_resolve) hipLaunchKernelGGL(k_gi_crc, dim3((n_blocks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_out, d_blocks, d_crc, n_blocks, d_status);
 }
 
 // ---------------------------------------------------------------------------------------------------

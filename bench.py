@@ -36,9 +36,15 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the BAM file -> bin/bamqualcheck -> .bamqc leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra device timings (default options with sketch; long reads)")
     ap.add_argument("--e2e-prefix", type=int, default=1_000_000, help="reads of the e2e input checked against the oracle")
+    ap.add_argument("--no-large", action="store_true", help="skip e2e_large (100 M reads over 24 GRCh38-length contigs as a 10 GB file) and e2e_shard_proxy (one worker's eighth of config 3)")
+    ap.add_argument("--large-reads", type=int, default=100_000_000)
+    ap.add_argument("--only-large", action="store_true", help="(development) only e2e_large and e2e_shard_proxy, printed as one JSON object")
     args = ap.parse_args()
     if args.workload == "config3":
         return config3_line(args)
+    if args.only_large:
+        print(json.dumps(large_legs(args)), flush=True)
+        return
     long_reads = args.workload == "config5"
     if args.reads is None:
         args.reads = 100_000 if long_reads else 10_000_000
@@ -76,11 +82,16 @@ def main():
     if args.sketch:
         opts.update(klist=(32,), qlist=(17,))
     refs = [synth.reference(seed, i, n) for i, n in enumerate(lens)]
-    e2e = None
+    e2e, e2e_big = None, None
     if world == 1 and rank == 0 and not args.no_e2e and not long_reads:
         # first, while this process has not touched the GPU: the program's start-up (HIP initialisation, context creation) was
         # measured to take 0.25-0.7 s instead of 0.1 s next to another process that holds a context on the card or is handing one back
         e2e = e2e_leg(args, refs, None)
+        if not args.no_large:
+            try:
+                e2e_big = large_legs(args)
+            except BaseException as e:  # noqa: BLE001 - the line is printed whatever happens in this leg
+                e2e_big = {"e2e_large": {"error": repr(e)[:600]}}
     t0 = time.time()
     cols = synth.batch(seed, args.reads, lens, refs, read_len=args.read_len, first_read_index=rank * args.reads, isize=opts["isize"], long_reads=long_reads)
     t_gen = time.time() - t0
@@ -193,13 +204,22 @@ def main():
             out["extra"] = extra_timings(refs)
         try:  # the headline WGS configuration as a FILE: measured by tools/run_config_file.py under gpurun (generating its 54 GB input takes 3 minutes;
             # `--workload config3` measures it live), copied here with its source named
-            c3 = json.load(open(os.path.join(ROOT, "profiles", "r3_config3_file.json")))
-            out["e2e_config3"] = {"source": "profiles/r3_config3_file.json (tools/run_config_file.py --config 3; not re-measured in this run)", "reads": c3["reads"],
+            c3name = next(f for f in ("r4_config3_file.json", "r3_config3_file.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            c3 = json.load(open(os.path.join(ROOT, "profiles", c3name)))
+            out["e2e_config3"] = {"source": "profiles/%s (tools/run_config_file.py --config 3; not re-measured in this run)" % c3name, "reads": c3["reads"],
                                   "bam_GB": c3["bam_bytes"] / 1e9, "wall_s": c3["program_wall_s"], "reads_per_s": c3["reads_per_s"], "compressed_GB_per_s": c3["compressed_GB_per_s"],
                                   "reader": c3["reader"], "which": c3["which"], "host_reader_reads_per_s": c3["host_reader"]["reads_per_s"],
                                   "prefix_matches_oracle": c3.get("prefix_matches_oracle")}
         except Exception:
             pass
+        if e2e_big:
+            out.update(e2e_big)
+            px, c3 = e2e_big.get("e2e_shard_proxy"), out.get("e2e_config3")
+            if px and c3 and "wall_s" in px:  # the 1 -> 8 projection: config 3 on one card over one worker's eighth of it
+                px["projected_speedup_8"] = c3["wall_s"] / px["wall_s"]
+                px["projection"] = ("config 3 on ONE card (%.2f s, %s) / this leg's wall time: what `bamqualcheck --gpus 8` gains when its slowest worker takes as long as this run "
+                                    "(not in it: the hook's hand-over and one RCCL reduce of ~3 MB, a middle shard's search for its first record, eight workers sharing the host's cores and page cache)"
+                                    % (c3["wall_s"], c3["source"]))
         if e2e_sharded is not None:
             out["e2e_sharded"] = e2e_sharded
         if e2e is not None:
@@ -365,6 +385,86 @@ def extra_timings(refs):
     return out
 
 
+GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+
+
+def program_runs(exe, cli, reads, n_runs, tmp, tag):
+    """bin/bamqualcheck `cli` n_runs times, a second apart: (median run, all runs); outputs tmp/<tag><k>.bamqc must be identical"""
+    import filecmp
+    import re
+    import subprocess
+    runs = []
+    for k in range(n_runs):
+        out = os.path.join(tmp, "%s%d.bamqc" % (tag, k))
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-o", out] + cli, capture_output=True, text=True, env=dict(os.environ, BQC_TIMING="1", BQC_GB_TIMING="1", BQC_T0="%.6f" % time.monotonic()))
+        dt = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"record loop ([0-9.]+) s", r.stderr)
+        ls = re.search(r"record loop starts: ([0-9.]+) s after launch", r.stderr)
+        runs.append({"wall_s": dt, "reads_per_s": reads / dt, "record_loop_s": float(m.group(1)) if m else None, "loop_start_s": float(ls.group(1)) if ls else None,
+                     "reader": "gpu" if "records decoded on the GPU" in r.stderr else "host", "timing": [ln for ln in r.stderr.splitlines() if ln.startswith(("[timing]", "[gpu reader] open"))]})
+    assert all(filecmp.cmp(os.path.join(tmp, tag + "0.bamqc"), os.path.join(tmp, "%s%d.bamqc" % (tag, k)), shallow=False) for k in range(1, n_runs))
+    return sorted(runs, key=lambda x: x["wall_s"])[n_runs // 2], runs
+
+
+def large_legs(args):
+    """Two BAM files through bin/bamqualcheck with default options, both driver-timed (inside this benchmark's own run):
+    e2e_large — 100 M reads over the 24 GRCh38-length contigs (~10 GB at BGZF level 1): a start-up-amortised BAM throughput, median of three runs, the whole
+    output through the invariants of tests/bamqc_text.py, the first million reads of the same plan byte for byte against the oracle;
+    e2e_shard_proxy — what ONE of the eight workers of `bamqualcheck --gpus 8` has to do on config 3 (618 M reads): 77.25 M reads over the contigs the third
+    eighth of the genome touches (chr4, chr5, chr6), as a file of their own through the single-GPU program: wall time and the time the record loop starts."""
+    import shutil
+    import tempfile
+    from bamqc_amd import hostio
+    from bamqc_amd.synth import GRCH38
+    from tests import bamqc_text
+    from tests.test_gpu_stream import prefix_parity
+    exe = os.path.join(ROOT, "bin", "bamqualcheck")
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="bqc_e2e_large_")
+    try:
+        bam, fa = os.path.join(tmp, "l.bam"), os.path.join(tmp, "l.fa")
+        t0 = time.time()
+        hostio.synth_stream(bam, fa, 1003, args.large_reads, GRCH38_NAMES, GRCH38, level=1)
+        t_write = time.time() - t0
+        size = os.path.getsize(bam)
+        med, runs = program_runs(exe, ["-r", fa, bam], args.large_reads, 3, tmp, "l")
+        lanes = bamqc_text.parse(os.path.join(tmp, "l0.bamqc"))
+        bamqc_text.check_invariants(lanes["L1"], n_records=args.large_reads, read_len=150)
+        npre = min(args.large_reads, 1_000_000)
+        prefix_parity(tmp, 1003, args.large_reads, npre, GRCH38_NAMES, GRCH38, ["-c", "chr1"], dict(chroms="chr1"))
+        res["e2e_large"] = {"what": "BAM file of %d reads x 150 bp PE over 24 GRCh38-length contigs (BGZF level 1, %.1f GB) -> bin/bamqualcheck, default options -> .bamqc; wall time of "
+                                    "the whole process, median of 3 runs, timed live in this run" % (args.large_reads, size / 1e9),
+                            "reads": args.large_reads, "bam_GB": size / 1e9, "wall_s": med["wall_s"], "reads_per_s": med["reads_per_s"], "compressed_GB_per_s": size / med["wall_s"] / 1e9,
+                            "frac_of_hbm": med["reads_per_s"] * 277.0 / 8e12, "frac_of_hbm_what": "reads/s x 277 algorithmic bytes per read / 8 TB/s",
+                            "record_loop_s": med["record_loop_s"], "loop_start_s": med["loop_start_s"], "reader": med["reader"], "runs": runs, "invariants": "ok",
+                            "prefix_matches_oracle": {"reads": npre, "identical": True}, "write_input_s": t_write}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    tmp = tempfile.mkdtemp(prefix="bqc_e2e_proxy_")
+    try:
+        which = [3, 4, 5]  # chr4, chr5, chr6: where the third of eight equal parts of the genome (772 - 1158 Mb) lies
+        names, lens = [GRCH38_NAMES[k] for k in which], [GRCH38[k] for k in which]
+        reads = 618_000_000 // 8
+        bam, fa = os.path.join(tmp, "p.bam"), os.path.join(tmp, "p.fa")
+        t0 = time.time()
+        hostio.synth_stream(bam, fa, 1013, reads, names, lens, level=1)
+        t_write = time.time() - t0
+        size = os.path.getsize(bam)
+        med, runs = program_runs(exe, ["-r", fa, "-c", ",".join(names), bam], reads, 3, tmp, "p")
+        lanes = bamqc_text.parse(os.path.join(tmp, "p0.bamqc"))
+        bamqc_text.check_invariants(lanes["L1"], n_records=reads, read_len=150)
+        res["e2e_shard_proxy"] = {"what": "one worker's eighth of config 3 as a file of its own: %d reads x 150 bp PE over %s (BGZF level 1, %.1f GB) -> bin/bamqualcheck, default sketch; "
+                                          "median of 3 runs, timed live in this run" % (reads, "+".join(names), size / 1e9),
+                                  "reads": reads, "bam_GB": size / 1e9, "wall_s": med["wall_s"], "loop_start_s": med["loop_start_s"], "record_loop_s": med["record_loop_s"],
+                                  "reads_per_s": med["reads_per_s"], "reader": med["reader"], "runs": runs, "invariants": "ok", "write_input_s": t_write}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def cpu_baseline(cols, refs, args, agg, db):
     """Oracle (single-thread CPU restatement of the reference; the reference itself cannot be compiled
     here: SeqAn 1.4.2 is absent) timed on a bounded prefix of the same workload, and used to check the
@@ -462,7 +562,8 @@ def e2e_leg(args, refs, cpu_kernel_value):
             assert r.returncode == 0, r.stderr[-2000:]
         t_b2b = time.perf_counter() - t0
         assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "b%d.bamqc" % k), shallow=False) for k in range(n_b2b))
-        return {"what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process "
+        return {"frac_of_hbm": best["reads_per_s"] * 277.0 / 8e12,
+                "what": "BAM file (BGZF level 1, %.0f MB) -> bin/bamqualcheck (default options, sketch k32 q17) -> .bamqc; wall time of the whole process "
                         "(median of 5 runs; the front end leaves when the output is complete, its worker's teardown of 0.2-0.5 s is outside a single "
                         "run's wall time and inside back_to_back's)" % (os.path.getsize(bam) / 1e6),
                 "reads": args.reads, "wall_s": best["wall_s"], "reads_per_s": best["reads_per_s"], "wall_s_min": timed[0]["wall_s"], "wall_s_max": timed[-1]["wall_s"],

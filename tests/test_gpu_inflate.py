@@ -275,3 +275,103 @@ def test_reader_on_the_gpu_matches_the_cpu_decoder(tmp_path, level):
         assert a.keys() == b.keys()
         for k in a:
             assert np.array_equal(a[k], b[k]), k
+
+
+class _Hip:
+    """Device memory through the HIP runtime the library itself is linked against (ctypes; torch brings a runtime of its own, and a
+    second one in a process that has used the card already finds no GPU)."""
+    def __init__(self):
+        _lib.load()
+        self.rt = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def put(self, arr, extra=0):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), arr.nbytes + extra + 256) == 0
+        assert self.rt.hipMemset(p, 0, arr.nbytes + extra + 256) == 0
+        if arr.nbytes:
+            assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        self.bufs.append(p)
+        return p
+
+    def get(self, p, nbytes, dtype=np.uint8):
+        out = np.zeros(nbytes, np.uint8)
+        if nbytes:
+            assert self.rt.hipMemcpy(out.ctypes.data, p, nbytes, 2) == 0
+        return out.view(dtype)
+
+    def free(self):
+        assert self.rt.hipDeviceSynchronize() == 0
+        for p in self.bufs:
+            self.rt.hipFree(p)
+        self.bufs = []
+
+
+def _launch_on_card(streams, want, crcs):
+    """bqc_gpu_inflate_launch on device-resident operands (what csrc/gpu_bam.hip calls), with the blocks' expected CRC-32s: returns
+    (status bits, output bytes)."""
+    fn = C.CDLL(_lib.LIB_PATH).bqc_gpu_inflate_launch
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = len(streams)
+    tab = np.zeros(n, dtype=[("coff", "<u8"), ("uoff", "<u8"), ("csize", "<u4"), ("usize", "<u4")])
+    co = uo = 0
+    for i, s in enumerate(streams):
+        tab[i] = (co, uo, len(s), len(want[i]))
+        co += len(s)
+        uo += len(want[i])
+    hip = _Hip()
+    try:
+        d_comp = hip.put(np.frombuffer(b"".join(streams), np.uint8), extra=256)
+        d_tab = hip.put(tab.view(np.uint8))
+        d_crc = hip.put(np.array(crcs, np.uint32))
+        d_out = hip.put(np.zeros(uo, np.uint8), extra=4096)
+        d_st = hip.put(np.zeros(16, np.uint32))
+        d_tok = hip.put(np.zeros(uo // 32 + n + 64, np.uint32))
+        d_ntok = hip.put(np.zeros(n + 16, np.uint32))
+        fn(d_comp, d_tab, n, uo, d_out, d_crc, d_st, d_tok, d_ntok, None)
+        assert hip.rt.hipDeviceSynchronize() == 0
+        return int(hip.get(d_st, 4, np.uint32)[0]), hip.get(d_out, uo).tobytes()
+    finally:
+        hip.free()
+
+
+def test_crc_checked_on_the_card():
+    """The blocks' CRC-32s on the card — inside k_inflate_resolve (two phases: every final byte passes through that kernel; the CRC of
+    1024 interleaved columns joined by polynomial arithmetic) or by k_gi_crc (one phase) — for every size class: empty, 1-9 bytes, around
+    the 4096-byte rows of the resolve kernel's gather pass, maximal; blocks without any match (stored, incompressible) and blocks that
+    are all matches; then ONE wrong CRC / ONE flipped output-relevant bit among many blocks must be noticed, wherever it sits."""
+    rng = np.random.default_rng(17)
+    datas = [b"", b"a", b"ab", b"abc", b"abcd", b"abcde", b"abcdefg", b"abcdefgh", b"abcdefghi"]
+    for n in (63, 64, 65, 4093, 4094, 4095, 4096, 4097, 4099, 8191, 8192, 8193, 12288, 40001, 65533, 65534, 65535, 65536):
+        datas.append(bytes(rng.integers(0, 5, n, dtype=np.uint8)))           # short codes, many matches
+        datas.append(bytes(rng.integers(0, 256, n, dtype=np.uint8)))         # no matches at all
+    datas += [p for p in payloads()]
+    streams, want = [], []
+    for d in datas:
+        for level in (0, 1, 9):
+            s = raw_deflate(d, level)
+            if len(s) <= 65536 + 64:
+                streams.append(s)
+                want.append(d)
+    crcs = [zlib.crc32(w) & 0xFFFFFFFF for w in want]
+    st, got = _launch_on_card(streams, want, crcs)
+    assert st == 0
+    assert got == b"".join(want)
+    for k in (0, 1, 5, len(crcs) // 2, len(crcs) - 1):      # a wrong expectation: the CRC bit, nothing else
+        bad = list(crcs)
+        bad[k] ^= 1 << int(rng.integers(0, 32))
+        st, _ = _launch_on_card(streams, want, bad)
+        assert st == 8, (k, st)
+    for k in range(0, len(streams), 7):                       # a literal byte of a stored block changed: the block inflates, its CRC is wrong
+        if len(want[k]) == 0 or raw_deflate(want[k], 0) != streams[k]:
+            continue
+        s = bytearray(streams[k])
+        s[5 + len(want[k]) // 2] ^= 0x20
+        st, _ = _launch_on_card(streams[:k] + [bytes(s)] + streams[k + 1:], want, crcs)
+        assert st == 8, (k, st)

@@ -78,7 +78,7 @@ def main():
             m = re.search(r"record loop ([0-9.]+) s", err)
             runs.append({"wall_s": dt, "reads_per_s": a.reads / dt, "compressed_GB_per_s": size / dt / 1e9, "record_loop_s": float(m.group(1)) if m else None,
                          "reader": "gpu (inflate, CRC, record walk and column decode on the card)" if "records decoded on the GPU" in err else "host",
-                         "timing": [ln for ln in err.splitlines() if ln.startswith("[timing]")]})
+                         "timing": [ln for ln in err.splitlines() if ln.startswith(("[timing]", "[gpu reader]"))]})
             print("run %d: %.2f s = %.1f M reads/s, %.2f GB/s of compressed input" % (k, dt, a.reads / dt / 1e6, size / dt / 1e9), flush=True)
         assert all(filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "o%d.bamqc" % k), shallow=False) for k in range(1, a.runs))
         lanes = bamqc_text.parse(os.path.join(tmp, "o0.bamqc"))
