@@ -10,7 +10,7 @@ import os
 from . import _abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbamqc_gpu.so")
+LIB_PATH = os.environ.get("BQC_LIB_PATH") or os.path.join(HERE, "libbamqc_gpu.so")  # (BQC_LIB_PATH: experiment builds, tools/build_inflate_variant.sh)
 
 # every symbol include/bamqc.h declares (checked by tests/test_abi.py against the header)
 _SIGNATURES = {
@@ -25,6 +25,11 @@ _SIGNATURES = {
     "bqc_submit": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch)]),
     "bqc_submit_async": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.POINTER(C.c_uint64)]),
     "bqc_batch_uploaded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    "bqc_anchor_enqueue": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bqc_anchor_complete": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bqc_submit_anchored": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bqc_anchor_discard": (None, [C.c_void_p, C.c_void_p]),
+    "bqc_anchor_error": (C.c_char_p, [C.c_void_p]),
     "bqc_host_register": (C.c_int, [C.c_void_p, C.c_uint64]),
     "bqc_host_unregister": (C.c_int, [C.c_void_p]),
     "bqc_upload": (C.c_int, [C.c_void_p, C.POINTER(_abi.Batch), C.POINTER(C.c_void_p)]),

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "bqc_ctx.h"
@@ -105,14 +107,20 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
             return BQC_ERR_DEVICE;                                                                            \
         }                                                                                                     \
     } while (0)
+    const bool ctiming = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
+    const auto ct0 = std::chrono::steady_clock::now();
+    double cts[6] = {0, 0, 0, 0, 0, 0};
+    auto cstamp = [&](int k) { cts[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - ct0).count() * 1e3; };
     CCHK(hipSetDevice(c->device));
     hipDeviceProp_t prop;
     CCHK(hipGetDeviceProperties(&prop, c->device));
     c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
-    CCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    c->stream = bqc_pool_stream(c->device, 0); // (made ahead by bqc_warmup, or now; the copy stream: at the first submit, bqc_copy_stream)
+    if (!c->stream) { fail(nullptr, BQC_ERR_DEVICE, "bqc_create: hipStreamCreate failed"); bqc_destroy(c); return BQC_ERR_DEVICE; }
+    cstamp(0);
     CCHK(bqc_long_init());
     CCHK(bqc_short_init());
+    cstamp(1);
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err0, sizeof(ErrRec)));
     CCHK(hipMalloc(&c->d_cursor, 8));
@@ -131,6 +139,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMalloc(&c->d_refn_ptrs, sizeof(uint32_t*) * nr));
     CCHK(hipMalloc(&c->d_main, nr));
     CCHK(hipMemcpy(c->d_main, c->main_chrom.data(), nr, hipMemcpyHostToDevice));
+    cstamp(2);
     CCHK(hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
     if (reset_stream_records(c)) { snprintf(g_create_err, sizeof g_create_err, "%s", c->err.c_str()); bqc_destroy(c); return BQC_ERR_DEVICE; }
     CCHK(hipMemsetAsync(c->d_carry, 0, (size_t)opt->n_lanes * 2 * 2000 * 4, c->stream));
@@ -138,24 +147,76 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMemsetAsync(c->d_started, 0, opt->n_lanes, c->stream));
     CCHK(hipStreamSynchronize(c->stream));
     if (upload_ref_tables(c)) { snprintf(g_create_err, sizeof g_create_err, "%s", c->err.c_str()); bqc_destroy(c); return BQC_ERR_DEVICE; }
+    cstamp(3);
     if (opt->sketch.n_k && opt->sketch.n_q) {
         std::string e;
         c->sketch = sketch_create(opt->sketch, opt->n_lanes, c->stream, e);
         if (!c->sketch) { fail(nullptr, BQC_ERR_ARG, "bqc_create: sketch: %s", e.c_str()); bqc_destroy(c); return BQC_ERR_ARG; }
     }
+    cstamp(4);
     for (int i = 0; i < 16; ++i) {
         hipEvent_t e;
         CCHK(hipEventCreate(&e));
         c->ev.push_back(e);
     }
+    cstamp(5);
+    if (ctiming) fprintf(stderr, "[timing] bqc_create: streams at %.1f ms, kernel attributes (code object load) %.1f, allocations %.1f, memsets + tables %.1f, sketch %.1f, events %.1f\n", cts[0], cts[1], cts[2], cts[3], cts[4], cts[5]);
     *out = c;
     return 0;
 }
 
+// Streams made ahead.  On this card a process's first stream costs 20-25 ms and each of the next three 8-10 (a hardware queue each:
+// tools/micro/startup_probe.cpp, profiles/r4_startup_probe.txt), one after the other whichever threads ask — 45-50 ms that the program's
+// reader (two streams) and the context (two) used to pay in turn, between the runtime's start and the first kernel.  bqc_warmup makes
+// them in ITS thread right behind the runtime's start, while the caller's other threads allocate, page-lock and parse; whoever needs
+// a stream takes one from here (waiting for the warm-up if it is still at it), or creates it when there is none.
+namespace {
+struct StreamPool {
+    std::mutex m;
+    std::condition_variable cv;
+    static const int kAhead = 4;
+    hipStream_t made[kAhead] = {nullptr, nullptr, nullptr, nullptr};
+    bool taken[kAhead] = {false, false, false, false};
+    int device = -1;
+    int n_made = 0;
+    bool making = false; // the warm-up thread is still at it
+};
+StreamPool g_streams;
+}
+// `rank`: the order in which the program needs its streams — 0 the context's compute stream (its creation, the references), 1 the
+// reader's producer (first copy, first inflate), 2 the reader's consumer (first walk), 3 the context's copy stream (first submit):
+// a caller waits for the stream of ITS rank, not for whichever comes next.
+hipStream_t bqc_pool_stream(int device, int rank)
+{
+    {
+        std::unique_lock<std::mutex> lk(g_streams.m);
+        if (g_streams.device == device && rank >= 0 && rank < StreamPool::kAhead) {
+            g_streams.cv.wait(lk, [&] { return g_streams.n_made > rank || !g_streams.making; });
+            if (g_streams.n_made > rank && !g_streams.taken[rank]) { g_streams.taken[rank] = true; return g_streams.made[rank]; }
+        }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+
 extern "C" int bqc_warmup(int32_t device)
 {
-    if (hipSetDevice(device) != hipSuccess) return BQC_ERR_DEVICE;
-    return hipFree(nullptr) == hipSuccess ? 0 : BQC_ERR_DEVICE;
+    {
+        std::lock_guard<std::mutex> lk(g_streams.m);
+        if (g_streams.device != -1) return g_streams.device == device ? 0 : BQC_ERR_ARG; // (once per process)
+        g_streams.device = device;
+        g_streams.making = true;
+    }
+    auto done = [](int rc) { { std::lock_guard<std::mutex> lk(g_streams.m); g_streams.making = false; } g_streams.cv.notify_all(); return rc; };
+    if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) return done(BQC_ERR_DEVICE);
+    for (int k = 0; k < StreamPool::kAhead; ++k) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return done(BQC_ERR_DEVICE); }
+        { std::lock_guard<std::mutex> lk(g_streams.m); g_streams.made[k] = s; g_streams.n_made = k + 1; }
+        g_streams.cv.notify_all();
+    }
+    return done(0);
 }
 
 extern "C" int bqc_set_fasta_index(bqc_ctx* c, const int32_t* idx)
@@ -179,6 +240,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     bqc_pipeline_destroy(c);
+    bqc_anchor_destroy(c);
     auto in_arena = [&](const void* p) { return c->ref_arena && (const uint8_t*)p >= c->ref_arena && (const uint8_t*)p < c->ref_arena + c->ref_arena_cap; };
     for (auto p : c->d_ref) if (p && !in_arena(p)) (void)hipFree(p);
     for (auto p : c->d_refn) if (p && !in_arena(p)) (void)hipFree(p);
@@ -273,6 +335,12 @@ extern "C" int bqc_reset(bqc_ctx* c)
     if (c->sketch) sketch_reset(c->sketch, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cov.assign(c->opt.n_lanes, LaneCov());
+    if (c->anchor.d_state) { // (anchors made on the card: the read group's state starts over as well)
+        AnchorState s0{};
+        s0.first = 1;
+        HIPCHK(c, hipMemcpy(c->anchor.d_state, &s0, sizeof s0, hipMemcpyHostToDevice));
+    }
+    c->anchor.mode = 0;
     c->state_seq = 0;
     c->flushed = false;
     c->poisoned = false;

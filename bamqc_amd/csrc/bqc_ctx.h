@@ -3,15 +3,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/bamqc.h"
 #include "device_types.h"
 #include "prep.h"
+#include "anchor.h"
 #include "sketch.h"
 #include "../host/raw_vector.h"
 
@@ -102,6 +105,29 @@ struct Slot { // one batch in flight through bqc_submit / bqc_submit_async
     uint64_t ticket = 0;
 };
 
+// Anchors made on the card (anchor.h, k_anchor.hip) for batches whose columns live in device memory: bqc_anchor_enqueue /
+// bqc_anchor_complete run in the thread that decodes the batches, bqc_submit_anchored in the one that submits them.
+struct bqc_anchored {
+    AnchorSummary* h_sum = nullptr;   // page-locked: the batch's summary ...
+    AnchorBound* h_bound = nullptr;   // ... and the first kInline entries of its boundary list
+    std::vector<AnchorBound> rest;    // the entries behind them (sparse data), fetched by bqc_anchor_complete
+    const CovEntry* d_cov = nullptr;  // the caller's device buffer with the anchors of the batch's reads
+    uint32_t n = 0;
+    bool completed = false;
+    static const uint32_t kInline = 1u << 16;
+};
+struct AnchorEngine {
+    std::atomic<int> mode{0};         // 0: not used yet, 1: the card keeps the state, 2: off for the rest of the stream (the host keeps it)
+    AnchorState* d_state = nullptr;
+    AnchorSummary* d_sum = nullptr;
+    AnchorBound* d_bound = nullptr;
+    void* d_scratch = nullptr;
+    size_t cap_n = 0;                 // reads the scratch buffers are sized for
+    std::mutex m;                     // the free list (handles come back from the submitting thread)
+    std::vector<bqc_anchored*> free_list, all;
+    std::string err;
+};
+
 struct bqc_ctx {
     bqc_options opt{};
     std::vector<uint8_t> main_chrom;
@@ -154,6 +180,7 @@ struct bqc_ctx {
     Slot slots[kSlots];
     uint64_t next_ticket = 1;    // ticket of the next submitted batch; slot = ticket % kSlots
     uint64_t checked_ticket = 0; // every batch up to here has been waited for and its error record read
+    AnchorEngine anchor;
     // sketch (N1)
     SketchDevice* sketch = nullptr;
     // timing
@@ -178,9 +205,14 @@ int bqc_fail(bqc_ctx* c, int code, const char* fmt, ...);
         if (e_ != hipSuccess) return bqc_fail(c, BQC_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// bqc_api.cpp: a non-blocking stream on `device` — one of those bqc_warmup has made ahead, or a new one (nullptr: creation failed)
+hipStream_t bqc_pool_stream(int device, int rank);
+// the context's copy stream, taken when the first batch needs it (0: ok)
+int bqc_copy_stream(bqc_ctx* c);
 // bqc_pipeline.cpp
 int bqc_report_errors(bqc_ctx* c, const ErrRec& e); // what the device found wrong with a batch -> error code + message (0: nothing)
 int bqc_drain(bqc_ctx* c);                 // wait for every batch in flight; returns the first error of the stream (context poisoned)
 void bqc_pipeline_destroy(bqc_ctx* c);     // frees slots and pooled buffers
+void bqc_anchor_destroy(bqc_ctx* c);       // frees the anchor engine's buffers and handles
 // Every reader of d_state goes through this: the packed 8-mer rows of k_short are summed into the state vector first.
 void bqc_state_ready(bqc_ctx* c);

@@ -42,6 +42,13 @@ static int timing_level()
     return lv;
 }
 
+int bqc_copy_stream(bqc_ctx* c)
+{
+    if (c->copy_stream) return 0;
+    c->copy_stream = bqc_pool_stream(c->device, 3);
+    return c->copy_stream ? 0 : bqc_fail(c, BQC_ERR_DEVICE, "hipStreamCreate failed");
+}
+
 void bqc_state_ready(bqc_ctx* c)
 {
     if (!c->t8_slots_used) return;
@@ -286,6 +293,45 @@ static int host_pass(bqc_ctx* c, const bqc_batch* b, HostPass& H)
     return 0;
 }
 
+// The same for a batch that was anchored on the card (k_anchor.hip): no pass over the reads — the batch's sizes, the read group's
+// state before and behind it and the reads at which the window index changes come with the summary; the tiles follow from those.
+static int host_pass_anchored(bqc_ctx* c, uint32_t n, const bqc_anchored* a, HostPass& H)
+{
+    const AnchorSummary& S = *a->h_sum;
+    H.n = n;
+    H.seq_bytes = S.seq_bytes; H.qual_bytes = S.qual_bytes; H.cigar_words = S.cigar_words;
+    H.n_slow = S.n_slow; H.max_len_slow = S.max_len_slow;
+    H.lane_count.assign(1, n);
+    H.t8_lane = 0;
+    H.multi_lane = false;
+    H.order.clear();
+    H.stretches.clear(); H.sws.clear();
+    {
+        Stretch St{0, 0, 0, 0};
+        for (uint32_t p = 0; p < n; p += BQC_SW_READS) H.sws.push_back(SuperWindow{0, p, std::min<uint32_t>(BQC_SW_READS, n - p), 0});
+        St.sw_end = (uint32_t)H.sws.size();
+        H.stretches.push_back(St);
+    }
+    H.n_pending = 0;
+    // the read group's state in front of the batch, as the planner wants to find it
+    LaneCov& lc = c->cov[0];
+    lc.first = S.before.first != 0; lc.id = S.before.id; lc.shift = S.before.shift; lc.win = S.before.win;
+    CovPlanner plan(c, H, n);
+    if (S.n_cand) {
+        // first[k] = the first read whose window is >= k: from the boundary list (any order on the card: sorted here)
+        std::vector<AnchorBound> bl(a->h_bound, a->h_bound + std::min<uint32_t>(S.n_bound, bqc_anchored::kInline));
+        bl.insert(bl.end(), a->rest.begin(), a->rest.end());
+        std::sort(bl.begin(), bl.end(), [](const AnchorBound& x, const AnchorBound& y) { return x.rel < y.rel; });
+        std::vector<uint32_t>& first = H.lane_first[0];
+        for (const AnchorBound& e : bl) if (first.size() <= e.rel) first.resize((size_t)e.rel + 1, e.idx);
+        plan.last_rel[0] = S.last_rel;
+        if (first.size() != (size_t)S.last_rel + 1) return bqc_fail(c, BQC_ERR_DEVICE, "internal error: the anchors' boundary list does not end at the last window");
+    }
+    lc.first = S.after.first != 0; lc.id = S.after.id; lc.shift = S.after.shift; lc.win = S.after.win; // (batch_base: set by the planner, advanced by finish())
+    plan.finish();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // device image of a batch
 // ---------------------------------------------------------------------------------------------------
@@ -394,11 +440,11 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
 }
 
 // the tables of the host pass into the image (host memory laid out like the device buffer from h2d_begin on)
-static void fill_tables(const BatchMem& m, const bqc_batch* b, const HostPass& H, char* img, size_t img_begin /* device offset of img[0]: <= o_xr */)
+static void fill_tables(const BatchMem& m, const bqc_batch* b, const HostPass& H, char* img, size_t img_begin /* device offset of img[0]: <= o_xr */, bool anchors_on_device = false)
 {
     auto at = [&](size_t off) { return img + (off - img_begin); };
     if (b->n_nm_extra) { memcpy(at(m.o_xr), b->nm_extra_read, 4ull * b->n_nm_extra); memcpy(at(m.o_xv), b->nm_extra_val, 4ull * b->n_nm_extra); }
-    memcpy(at(m.o_cov_in), H.cov.data(), sizeof(CovEntry) * (size_t)H.n);
+    if (!anchors_on_device) memcpy(at(m.o_cov_in), H.cov.data(), sizeof(CovEntry) * (size_t)H.n);
     if (H.multi_lane) memcpy(at(m.o_order), H.order.data(), 4ull * H.n);
     memcpy(at(m.o_sws), H.sws.data(), sizeof(SuperWindow) * H.sws.size());
     memcpy(at(m.o_stretch), H.stretches.data(), sizeof(Stretch) * H.stretches.size());
@@ -522,6 +568,7 @@ extern "C" int bqc_upload(bqc_ctx* c, const bqc_batch* b, bqc_dbatch** out)
     if (rc) return rc;
     if (c->shard.tail && !c->shard.resolved) return bqc_fail(c, BQC_ERR_STATE, "bqc_upload: resident batches are not available to a shard_tail context (use bqc_submit)");
     HIPCHK(c, hipSetDevice(c->device));
+    c->anchor.mode = 2; // (the host keeps the window state)
     const auto t0 = clk::now();
     HostPass& H = c->hp;
     if ((rc = host_pass(c, b, H))) return poison(c, rc);
@@ -604,13 +651,15 @@ void bqc_pipeline_destroy(bqc_ctx* c)
     c->shard.batches.clear();
 }
 
-static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint64_t* ticket_out)
+static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint64_t* ticket_out, const bqc_anchored* anchored = nullptr)
 {
     int rc = check_batch_args(c, b, "bqc_submit");
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if (ticket_out) *ticket_out = 0;
+    if (!anchored) c->anchor.mode = 2; // (the host keeps the window state from here on: bqc_anchor_enqueue refuses)
     if (b->n_reads == 0) return 0;
+    if ((rc = bqc_copy_stream(c))) return rc;
     const uint64_t ticket = c->next_ticket;
     Slot& s = c->slots[ticket % bqc_ctx::kSlots];
     const auto t0 = clk::now();
@@ -622,7 +671,7 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
         HIPCHK(c, hipHostMalloc((void**)&s.h_err, sizeof(ErrRec), hipHostMallocDefault));
     }
     HostPass& H = c->hp;
-    if ((rc = host_pass(c, b, H))) return poison(c, rc);
+    if ((rc = anchored ? host_pass_anchored(c, b->n_reads, anchored, H) : host_pass(c, b, H))) return poison(c, rc);
     const double t_pass = secs_since(t0) - t_wait;
     if ((rc = layout_batch(c, s.m, b, H, false))) return poison(c, rc);
     BatchMem& m = s.m;
@@ -647,7 +696,7 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
         if (he != hipSuccess) { poison(c, BQC_ERR_DEVICE); return bqc_fail(c, BQC_ERR_DEVICE, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(he)); }
         s.hcap = cap;
     }
-    fill_tables(m, b, H, s.hmem, img_begin);
+    fill_tables(m, b, H, s.hmem, img_begin, anchored != nullptr);
     char* base = (char*)m.dmem;
     hipError_t he = hipSuccess;
     if (pinned_columns) {
@@ -667,6 +716,12 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
             }
         });
     }
+    if (anchored) { // the anchors are on the card already (the caller's buffer): the image's tables in front of and behind their place
+        const size_t n_cov = sizeof(CovEntry) * (size_t)b->n_reads, o_behind = m.o_cov_in + ((n_cov + 255) & ~(size_t)255);
+        if (he == hipSuccess && m.o_cov_in > img_begin) he = hipMemcpyAsync(base + img_begin, s.hmem, m.o_cov_in - img_begin, hipMemcpyHostToDevice, c->copy_stream);
+        if (he == hipSuccess && n_cov) he = hipMemcpyAsync(base + m.o_cov_in, anchored->d_cov, n_cov, hipMemcpyDeviceToDevice, c->copy_stream);
+        if (he == hipSuccess && m.h2d_end > o_behind) he = hipMemcpyAsync(base + o_behind, s.hmem + (o_behind - img_begin), m.h2d_end - o_behind, hipMemcpyHostToDevice, c->copy_stream);
+    } else
     if (he == hipSuccess) he = hipMemcpyAsync(base + img_begin, s.hmem, img_bytes, hipMemcpyHostToDevice, c->copy_stream);
     if (he == hipSuccess) he = hipEventRecord(s.ev_h2d, c->copy_stream);
     if (he == hipSuccess) he = hipStreamWaitEvent(c->stream, s.ev_h2d, 0);
@@ -700,6 +755,129 @@ extern "C" int bqc_submit(bqc_ctx* c, const bqc_batch* b)
     return submit_impl(c, b, false, nullptr);
 }
 extern "C" int bqc_submit_async(bqc_ctx* c, const bqc_batch* b, uint64_t* ticket) { return submit_impl(c, b, true, ticket); }
+
+// ---------------------------------------------------------------------------------------------------
+// anchors made on the card (include/bamqc.h: bqc_anchor_*; anchor.h, k_anchor.hip)
+// ---------------------------------------------------------------------------------------------------
+static int anchor_fail(bqc_ctx* c, const char* what) { c->anchor.err = what; return -BQC_ERR_DEVICE; }
+extern "C" const char* bqc_anchor_error(const bqc_ctx* c) { return c ? c->anchor.err.c_str() : ""; }
+
+extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, void* stream, bqc_anchored** out)
+{
+    if (!c || !b || !out || (b->n_reads && !d_cov)) return -BQC_ERR_ARG;
+    *out = nullptr;
+    AnchorEngine& E = c->anchor;
+    // one read group, the whole stream from its first batch on, and not a shard that starts inside the stream (its first reads are set aside
+    // by the host's pass until the predecessor's state is known)
+    if (c->opt.n_lanes != 1 || c->shard.tail || E.mode.load() == 2) return 1;
+    if (hipSetDevice(c->device) != hipSuccess) return anchor_fail(c, "hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = b->n_reads;
+    if (!E.d_state) {
+        if (hipMalloc((void**)&E.d_state, sizeof(AnchorState)) != hipSuccess || hipMalloc((void**)&E.d_sum, sizeof(AnchorSummary)) != hipSuccess) return anchor_fail(c, "out of device memory");
+        AnchorState s0{};
+        s0.first = 1;
+        if (hipMemcpy(E.d_state, &s0, sizeof s0, hipMemcpyHostToDevice) != hipSuccess) return anchor_fail(c, "copy failed");
+    }
+    if (E.cap_n < n) { // scratch: [cpos crid cidx crun](4 B x n) [bound](8 B x n) [bj][runs][blk_a][blk_b]
+        if (hipStreamSynchronize(st) != hipSuccess) return anchor_fail(c, "stream failed");
+        if (E.d_scratch) (void)hipFree(E.d_scratch);
+        E.d_scratch = nullptr; E.cap_n = 0;
+        const size_t cap = std::max<size_t>(n + n / 8, 1u << 20);
+        const size_t bytes = cap * 24 + AN_MAX_BREAKS * (4 + sizeof(AnchorRun)) + 2 * (cap / 1024 + 4) * 4 + 4096;
+        if (hipMalloc(&E.d_scratch, bytes) != hipSuccess) return anchor_fail(c, "out of device memory");
+        E.cap_n = cap;
+    }
+    bqc_anchored* a = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(E.m);
+        if (!E.free_list.empty()) { a = E.free_list.back(); E.free_list.pop_back(); }
+    }
+    if (!a) {
+        a = new bqc_anchored();
+        if (hipHostMalloc((void**)&a->h_sum, sizeof(AnchorSummary), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&a->h_bound, sizeof(AnchorBound) * bqc_anchored::kInline, hipHostMallocDefault) != hipSuccess) {
+            if (a->h_sum) (void)hipHostFree(a->h_sum);
+            delete a;
+            return anchor_fail(c, "out of page-locked memory");
+        }
+        std::lock_guard<std::mutex> lk(E.m);
+        E.all.push_back(a);
+    }
+    a->rest.clear(); a->completed = false; a->n = (uint32_t)n; a->d_cov = (const CovEntry*)d_cov;
+    AnchorArgs A{};
+    A.n = (uint32_t)n; A.n_refs = c->opt.n_refs; A.n_lanes = 1; A.no_fast = c->no_fast ? 1u : 0u;
+    A.flag = b->flag; A.lane = b->lane; A.rid = b->rid; A.pos = b->pos; A.l_seq = b->l_seq; A.n_cigar = b->n_cigar;
+    A.main_chrom = c->d_main;
+    A.cov_out = (CovEntry*)d_cov; A.state = E.d_state; A.sum = E.d_sum;
+    char* q = (char*)E.d_scratch;
+    const size_t cap = E.cap_n;
+    A.cpos = (uint32_t*)q; q += 4 * cap; A.crid = (int32_t*)q; q += 4 * cap; A.cidx = (uint32_t*)q; q += 4 * cap; A.crun = (uint32_t*)q; q += 4 * cap;
+    A.bound = (AnchorBound*)q; q += 8 * cap; A.bound_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    A.bj = (uint32_t*)q; q += 4 * AN_MAX_BREAKS; A.runs = (AnchorRun*)q; q += sizeof(AnchorRun) * AN_MAX_BREAKS;
+    q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
+    A.blk_a = (uint32_t*)q; q += 4 * (cap / 1024 + 4); A.blk_b = (uint32_t*)q;
+    E.d_bound = A.bound;
+    bqc_launch_anchor(A, st);
+    if (hipMemcpyAsync(a->h_sum, E.d_sum, sizeof(AnchorSummary), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(a->h_bound, A.bound, sizeof(AnchorBound) * std::min<size_t>(bqc_anchored::kInline, std::max<size_t>(n, 1)), hipMemcpyDeviceToHost, st) != hipSuccess) {
+        std::lock_guard<std::mutex> lk(E.m);
+        E.free_list.push_back(a);
+        return anchor_fail(c, "copy failed");
+    }
+    E.mode = 1;
+    *out = a;
+    return 0;
+}
+
+extern "C" int bqc_anchor_complete(bqc_ctx* c, bqc_anchored* a, bqc_anchor_info* info)
+{
+    if (!c || !a) return -BQC_ERR_ARG;
+    AnchorEngine& E = c->anchor;
+    const AnchorSummary& S = *a->h_sum;
+    if (info) { info->n_noqual = S.n_noqual; info->rid_min = S.rid_min; info->rid_max = S.rid_max; }
+    if (S.flags & AN_FLAG_BOUND_OVERFLOW) return anchor_fail(c, "internal error: boundary list overflow");
+    if (S.flags & AN_FLAG_TOO_MANY_BREAKS) { // the card has left its state alone: this batch and what follows are the host's
+        E.mode = 2;
+        std::lock_guard<std::mutex> lk(E.m);
+        E.free_list.push_back(a);
+        return 1;
+    }
+    if (S.n_bound > bqc_anchored::kInline) { // (sparse data: the rest of the list, before the next batch's kernels reuse the buffer)
+        a->rest.resize(S.n_bound - bqc_anchored::kInline);
+        if (hipSetDevice(c->device) != hipSuccess ||
+            hipMemcpy(a->rest.data(), E.d_bound + bqc_anchored::kInline, sizeof(AnchorBound) * a->rest.size(), hipMemcpyDeviceToHost) != hipSuccess) return anchor_fail(c, "copy failed");
+    }
+    a->completed = true;
+    return 0;
+}
+
+extern "C" void bqc_anchor_discard(bqc_ctx* c, bqc_anchored* a)
+{
+    if (!c || !a) return;
+    std::lock_guard<std::mutex> lk(c->anchor.m);
+    c->anchor.free_list.push_back(a);
+}
+
+extern "C" int bqc_submit_anchored(bqc_ctx* c, const bqc_batch* b, bqc_anchored* a, uint64_t* ticket)
+{
+    if (!c || !b || !a || !a->completed || a->n != b->n_reads) return bqc_fail(c, BQC_ERR_ARG, "bqc_submit_anchored: bad argument");
+    if (b->n_nm_extra) return bqc_fail(c, BQC_ERR_ARG, "bqc_submit_anchored: further NM values belong to batches decoded on the host");
+    const int rc = submit_impl(c, b, true, ticket, a);
+    bqc_anchor_discard(c, a);
+    return rc;
+}
+
+void bqc_anchor_destroy(bqc_ctx* c)
+{
+    AnchorEngine& E = c->anchor;
+    for (bqc_anchored* a : E.all) { if (a->h_sum) (void)hipHostFree(a->h_sum); if (a->h_bound) (void)hipHostFree(a->h_bound); delete a; }
+    E.all.clear(); E.free_list.clear();
+    if (E.d_state) (void)hipFree(E.d_state);
+    if (E.d_sum) (void)hipFree(E.d_sum);
+    if (E.d_scratch) (void)hipFree(E.d_scratch);
+    E.d_state = nullptr; E.d_sum = nullptr; E.d_scratch = nullptr; E.cap_n = 0;
+}
 
 extern "C" int bqc_batch_uploaded(bqc_ctx* c, uint64_t ticket, int wait)
 {

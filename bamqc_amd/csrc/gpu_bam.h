@@ -40,6 +40,11 @@ public:
     int next_batch(HostBatch& out, size_t max_reads, size_t max_bases, std::string& err, int& err_code) override;
     uint64_t records() const { return nrec_; }
     uint64_t batches_handed_over() const { return n_handed_over_; } // batches decoded by the host reader's rules (see next_batch)
+    // The program's context, once it exists: from then on the batches' coverage anchors are made on the card (include/bamqc.h:
+    // bqc_anchor_*) and their fixed columns stay there — HostBatch::anchored — as long as the stream allows it (one read group, not a
+    // shard in the middle of a stream, no batch handed over to the host decoder so far).  Without it: columns on the host, as ever.
+    void set_anchor_context(bqc_ctx* ctx) { anchor_ctx_ = ctx; }
+    uint64_t batches_anchored() const { return n_anchored_; }
     double seconds_reading() const { return t_read_; } // time spent in fread
     // set by open() once its device buffers are allocated (also when it fails before that): a caller that creates its own device
     // context in another thread starts doing so from here on
@@ -50,7 +55,9 @@ private:
     Impl* p_ = nullptr;
     BamHeader hdr_;
     std::vector<uint8_t> main_;
-    uint64_t nrec_ = 0, n_handed_over_ = 0;
+    uint64_t nrec_ = 0, n_handed_over_ = 0, n_anchored_ = 0;
+    std::atomic<bqc_ctx*> anchor_ctx_{nullptr};
+    bool anchors_ok_ = true; // (decode thread)
     double t_read_ = 0;
     bool ranged_ = false;
     uint64_t range_b0_ = 0, range_b1_ = UINT64_MAX, range_first_ = 0, range_over_ = 0;

@@ -44,6 +44,8 @@
 #include "gpu_inflate.h"
 #include "../host/parallel.h"
 
+hipStream_t bqc_pool_stream(int device, int rank); // bqc_api.cpp: a stream bqc_warmup has made ahead (rank: the order of need), or a new one
+
 #define GB_SEG 16384u // (4 KiB segments measured slower: 28 walk launches of 0.20 ms per 10 M reads instead of 18 of 0.27 — more segments whose guess has to be redone — and k_gb_decode 0.18 instead of 0.14 ms per batch)
 #define GB_MAXR (GB_SEG / 36u + 1u)
 
@@ -113,8 +115,15 @@ __global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base
     S.first = (uint32_t)p;
     GbRec* out = recs + (size_t)s * GB_MAXR;
     uint32_t so = 0, qo = 0, co = 0, n = 0;
+    // The chain is one dependent load per record, and every record of a lane's own 16 KiB lies in a line nobody has touched: a miss
+    // each (~2.5 us; 60 records per segment: what the kernel's 0.26 ms per launch were, with a quarter of the card's SIMDs holding a
+    // wave).  So every step also asks for the line 1.5 KB further on — a load nothing waits for — and finds its own line on its way
+    // or there when it gets to it.  (`ahead` only keeps the loads alive.)
+    uint32_t ahead = 0;
+    const uint64_t last_line = avail >= 4 ? avail - 4 : 0;
     while (p < b && p < limit) {
         if (p + 36 > avail) { S.flags |= GB_INCOMPLETE; break; }
+        ahead ^= ld32(base + min(p + 1536u, last_line));
         const uint32_t bs = ld32(base + p);
         if (bs < 32u) { S.flags |= GB_CORRUPT; break; }
         const uint8_t* r = base + p + 4;
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base
     }
     S.exit = (uint32_t)min(p, (uint64_t)0xFFFFFFFEu);
     S.count = n; S.seq_bytes = so; S.qual_bytes = qo; S.cigar_words = co;
+    if (n == 0xFFFFFFFFu) S.pad = ahead; // (never: a segment holds at most GB_MAXR records)
     segs[s] = S;
 }
 
@@ -435,7 +445,8 @@ struct GpuBamReader::Impl {
         for (std::thread& t : readers) if (t.joinable()) t.join();
         (void)hipSetDevice(device);
         if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
-        for (Slot& C : slots) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) (void)hipHostFree(C.p); }
+        if (ring_alloc.joinable()) ring_alloc.join();
+        for (Slot& C : slots) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) { if (C.registered) (void)hipHostUnregister(C.p); free(C.p); } }
         for (GbRun& R : runs) {
             if (R.ready) (void)hipEventDestroy(R.ready);
             if (R.copied) (void)hipEventDestroy(R.copied);
@@ -471,7 +482,8 @@ struct GpuBamReader::Impl {
     // is the file's bytes [ring_base + i * chunk_bytes, + chunk_bytes); the producer parses them in order, copies the whole
     // blocks to the card and gives the chunk back.  A block cut by a chunk's end is completed in the HEADROOM in front of the next
     // chunk's bytes, so that a block is always contiguous.
-    struct Slot { uint8_t* p = nullptr; size_t len = 0; uint64_t index = UINT64_MAX; bool filled = false, used = false; hipEvent_t done = nullptr; };
+    struct Slot { uint8_t* p = nullptr; size_t len = 0; uint64_t index = UINT64_MAX; bool filled = false, used = false, registered = false; hipEvent_t done = nullptr; };
+    std::thread ring_alloc; // allocates and touches the ring's chunks while the runtime starts (they are page-locked afterwards: hipHostRegister)
     static const int kSlots = 6, kReaders = 3;
     static constexpr size_t kHeadroom = 1u << 17;
     Slot slots[kSlots];
@@ -541,6 +553,16 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         I.out_cap = I.head + I.run_bytes / 5 * 18 + 64;
     }
     I.producer = std::thread([&I] { I.produce(); }); // reads the first run of the file while the device is set up below
+    // the ring's chunks: allocated and touched here, by a thread of their own, while the runtime starts; page-locked below (measured,
+    // tools/micro/startup_probe.cpp: hipHostMalloc of 6 x 16 MB 17-26 ms; touching them 18 ms — hidden behind the runtime's start — and
+    // hipHostRegister 3-4 ms)
+    I.ring_alloc = std::thread([&I] {
+        for (Impl::Slot& C : I.slots) {
+            const size_t bytes = (Impl::kHeadroom + I.chunk_bytes + 64 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            C.p = (uint8_t*)aligned_alloc((size_t)2 << 20, bytes);
+            if (C.p) memset(C.p, 0, bytes);
+        }
+    });
     hipError_t he = hipSetDevice(device);
     const double t_open1 = now_s();
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
@@ -563,7 +585,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         const size_t reads = std::min<size_t>(std::max<size_t>(batch_reads, 1), 1u << 22);
         ok = ok && I.d_cols.need(((reads + 63 + GB_MAXR) & ~(size_t)63) * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256);
         if (!ok) { err = "GPU reader: out of device memory"; return false; }
-        const size_t typical = std::min<size_t>(reads * 360, batch_bases / 2 * 3 + (64u << 20)) + (1u << 20);
+        const size_t typical = std::min<size_t>(reads * 400, batch_bases / 2 * 3 + reads * 40 + (64u << 20)) + (1u << 20);
         const double t_c = now_s();
         g_pool.fill(typical, 6);
         buffers_allocated = true; // (the caller creates its context from here on: side by side with these allocations the two were measured to hold each other up)
@@ -571,15 +593,14 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     }
 
     const double t_s0 = now_s();
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.s, hipStreamNonBlocking);
+    if (he == hipSuccess) { I.ps = bqc_pool_stream(device, 1); if (!I.ps) he = hipErrorOutOfMemory; } // (made ahead by bqc_warmup when the program runs; the consumer's stream: at the first batch)
     const double t_s1 = now_s();
     if (he == hipSuccess) he = hipEventCreateWithFlags(&I.ev, hipEventBlockingSync | hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc((void**)&I.d_status, 64);
     if (he == hipSuccess) he = hipHostMalloc((void**)&I.h_status, 64, hipHostMallocDefault);
-    if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.s);
+    if (he == hipSuccess) he = hipMemsetAsync(I.d_status, 0, 64, I.ps);
     // ONE stream for all runs: a process gets a handful of hardware queues, streams beyond them share one, and a 30 ms inflate
     // kernel in a shared queue holds up whatever else is in it
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&I.ps, hipStreamNonBlocking);
     for (GbRun& R : I.runs) {
         R.s = I.ps;
         if (he == hipSuccess) he = hipEventCreateWithFlags(&R.ready, hipEventBlockingSync | hipEventDisableTiming);
@@ -587,8 +608,10 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
     }
     const double t_s2 = now_s();
+    I.ring_alloc.join();
     for (Impl::Slot& C : I.slots) {
-        if (he == hipSuccess) he = hipHostMalloc((void**)&C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostMallocDefault);
+        if (he == hipSuccess && !C.p) he = hipErrorOutOfMemory;
+        if (he == hipSuccess) { he = hipHostRegister(C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostRegisterDefault); C.registered = he == hipSuccess; }
         if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
     }
     for (int t = 0; t < Impl::kReaders; ++t) I.readers.emplace_back([&I] { I.reader_loop(); }); // (they wait for the first run to be parsed)
@@ -596,7 +619,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     if (!I.upload_lanes(hdr)) { err = "GPU reader: out of device memory"; return false; }
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
     I.cv.notify_all();
-    if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms: first stream %.1f, second stream + events + status words %.1f, page-locked chunks + tables %.1f)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3, (t_s1 - t_s0) * 1e3, (t_s2 - t_s1) * 1e3, (now_s() - t_s2) * 1e3);
+    if (I.timing) fprintf(stderr, "[gpu reader] open: %.1f ms (of which device set-up and buffers %.1f ms: the two streams %.1f, events + status words %.1f, page-locking the chunks + tables %.1f)\n", (now_s() - t_open0) * 1e3, (now_s() - t_open1) * 1e3, (t_s1 - t_s0) * 1e3, (t_s2 - t_s1) * 1e3, (now_s() - t_s2) * 1e3);
     return true;
 }
 
@@ -912,6 +935,10 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
     err_code = 0;
     Impl& I = *p_;
     if (hipSetDevice(I.device) != hipSuccess) { err = "GPU reader: device lost"; err_code = BQC_ERR_DEVICE; return -1; }
+    if (!I.s) { // the consumer's stream (the third one the program needs: bqc_pool_stream)
+        I.s = bqc_pool_stream(I.device, 2);
+        if (!I.s || hipStreamSynchronize(I.ps) != hipSuccess) { err = "GPU reader: no stream"; err_code = BQC_ERR_DEVICE; return -1; } // (the status word's memset is on the producer's)
+    }
     auto fail_dev = [&](const char* what) { err = std::string("GPU reader: ") + what; err_code = BQC_ERR_DEVICE; return -1; };
     auto unsupported = [&](const char* why) { err = std::string("GPU reader hands over to the host reader: ") + why; err_code = kUnsupported; return -1; };
     if (!I.main_set) {
@@ -1033,22 +1060,14 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         const double td = now_s();
         // columns
         const size_t N = (size_t)n;
-        o.flag.resize(N); o.mapq.resize(N); o.lane.resize(N); o.rid.resize(N); o.pos.resize(N); o.tlen.resize(N);
-        o.nm.resize(N); o.as.resize(N); o.l_seq.resize(N); o.n_cigar.resize(N);
-        // device columns: [so qo co](8 B) [rid pos tlen nm as l_seq rec_off](4 B) [flag n_cigar](2 B) [mapq lane](1 B)
+        // scratch columns of the copy kernel: [so qo co](8 B) [rec_off](4 B) per record
         const size_t Np = (N + 63) & ~(size_t)63, Np_cap = std::max(Np, (std::min<size_t>(max_reads, 1u << 22) + 63 + GB_MAXR) & ~(size_t)63);
-        if (!I.d_cols.need(Np_cap * (7 * 4 + 3 * 8 + 2 * 2 + 2) + 256)) return fail_dev("out of device memory");
-        GbCols C;
-        {
-            uint8_t* q = I.d_cols.p;
-            C.so = (uint64_t*)q; q += Np * 8; C.qo = (uint64_t*)q; q += Np * 8; C.co = (uint64_t*)q; q += Np * 8;
-            C.rid = (int32_t*)q; q += Np * 4; C.pos = (int32_t*)q; q += Np * 4; C.tlen = (int32_t*)q; q += Np * 4; C.nm = (int32_t*)q; q += Np * 4;
-            C.as = (int32_t*)q; q += Np * 4; C.l_seq = (uint32_t*)q; q += Np * 4; C.rec_off = (uint32_t*)q; q += Np * 4;
-            C.flag = (uint16_t*)q; q += Np * 2; C.n_cigar = (uint16_t*)q; q += Np * 2;
-            C.mapq = q; q += Np; C.lane = q;
-        }
-        // the batch's payload buffer on the device: [seq][qual][cigar], 512 spare bytes behind each (the kernels' vector loads)
-        const size_t o_seq = 0, o_qual = (so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255), total = o_cig + 4 * co + 512;
+        if (!I.d_cols.need(Np_cap * (3 * 8 + 4) + 256)) return fail_dev("out of device memory");
+        // the batch's own buffer on the device: [seq][qual][cigar] (512 spare bytes behind each: the kernels' vector loads), then the fixed
+        // columns [rid pos tlen nm as l_seq](4 B) [flag n_cigar](2 B) [mapq lane](1 B) and 8 bytes per read for the coverage anchors — a
+        // batch that is anchored on the card (bqc_anchor_*) is submitted from here without its columns ever visiting the host
+        const size_t o_seq = 0, o_qual = (so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255),
+                     o_fix = (o_cig + 4 * co + 512 + 255) & ~(size_t)255, o_cov = o_fix + Np * (6 * 4 + 2 * 2 + 2), total = o_cov + 8 * Np + 256;
         if (o.dev_cap < total) {
             if (o.dev_mem) dev_free_hook(o.dev_mem);
             o.dev_mem = g_pool.take(total);
@@ -1061,23 +1080,64 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             o.dev_free = dev_free_hook;
         }
         uint8_t* pay = (uint8_t*)o.dev_mem;
+        GbCols C;
+        {
+            uint8_t* q = I.d_cols.p;
+            C.so = (uint64_t*)q; q += Np * 8; C.qo = (uint64_t*)q; q += Np * 8; C.co = (uint64_t*)q; q += Np * 8; C.rec_off = (uint32_t*)q;
+            q = pay + o_fix;
+            C.rid = (int32_t*)q; q += Np * 4; C.pos = (int32_t*)q; q += Np * 4; C.tlen = (int32_t*)q; q += Np * 4; C.nm = (int32_t*)q; q += Np * 4;
+            C.as = (int32_t*)q; q += Np * 4; C.l_seq = (uint32_t*)q; q += Np * 4;
+            C.flag = (uint16_t*)q; q += Np * 2; C.n_cigar = (uint16_t*)q; q += Np * 2;
+            C.mapq = q; q += Np; C.lane = q;
+        }
         GbLanes LN{I.d_lane_blob.p, I.d_lane_tab.p, I.d_lane_tab.p + I.n_lane_ids, I.d_lane_tab.p + 2 * (size_t)I.n_lane_ids, I.n_lane_ids, I.lane_count};
         hipError_t he = hipMemcpyAsync(I.d_base.p, I.h_base.p, (size_t)last_taken * sizeof(GbBase), hipMemcpyHostToDevice, I.s);
         if (he != hipSuccess) return fail_dev("copy failed");
         hipLaunchKernelGGL(k_gb_decode, dim3(last_taken), dim3(64), 0, I.s, base, I.d_seg.p, I.d_rec.p, I.d_base.p, C, LN, I.d_main.p, I.n_main, I.d_status);
         hipLaunchKernelGGL(k_gb_copy, dim3((uint32_t)((N + 15) / 16)), dim3(256), 0, I.s, base, C, (uint32_t)N, pay + o_seq, pay + o_qual, pay + o_cig);
-        he = hipMemcpyAsync(o.flag.data(), C.flag, N * 2, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.n_cigar.data(), C.n_cigar, N * 2, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.mapq.data(), C.mapq, N, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.lane.data(), C.lane, N, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.rid.data(), C.rid, N * 4, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.pos.data(), C.pos, N * 4, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.tlen.data(), C.tlen, N * 4, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.nm.data(), C.nm, N * 4, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.as.data(), C.as, N * 4, hipMemcpyDeviceToHost, I.s);
-        if (he == hipSuccess) he = hipMemcpyAsync(o.l_seq.data(), C.l_seq, N * 4, hipMemcpyDeviceToHost, I.s);
+        // The anchors of the coverage statistic on the card (k_anchor.hip), when the program has handed its context over and the stream
+        // allows it: the fixed columns then stay here, and a summary comes back instead of 26 bytes per read
+        bqc_batch dv;
+        memset(&dv, 0, sizeof dv);
+        dv.n_reads = (uint32_t)N; dv.flag = C.flag; dv.mapq = C.mapq; dv.lane = C.lane; dv.rid = C.rid; dv.pos = C.pos; dv.tlen = C.tlen; dv.nm = C.nm; dv.as = C.as;
+        dv.l_seq = C.l_seq; dv.n_cigar = C.n_cigar; dv.seq = pay + o_seq; dv.qual = pay + o_qual; dv.cigar = (const uint32_t*)(pay + o_cig);
+        bqc_anchored* ah = nullptr;
+        bqc_ctx* const actx = anchor_ctx_.load();
+        if (actx && anchors_ok_) {
+            const int arc = bqc_anchor_enqueue(actx, &dv, pay + o_cov, I.s, &ah);
+            if (arc < 0) return fail_dev(bqc_anchor_error(actx));
+            if (arc > 0) { anchors_ok_ = false; ah = nullptr; } // (several read groups, a shard in the middle of the stream, or the host has kept the state so far)
+        }
+        auto columns_to_host = [&]() -> hipError_t {
+            o.flag.resize(N); o.mapq.resize(N); o.lane.resize(N); o.rid.resize(N); o.pos.resize(N); o.tlen.resize(N);
+            o.nm.resize(N); o.as.resize(N); o.l_seq.resize(N); o.n_cigar.resize(N);
+            hipError_t e = hipMemcpyAsync(o.flag.data(), C.flag, N * 2, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.n_cigar.data(), C.n_cigar, N * 2, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.mapq.data(), C.mapq, N, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.lane.data(), C.lane, N, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.rid.data(), C.rid, N * 4, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.pos.data(), C.pos, N * 4, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.tlen.data(), C.tlen, N * 4, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.nm.data(), C.nm, N * 4, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.as.data(), C.as, N * 4, hipMemcpyDeviceToHost, I.s);
+            if (e == hipSuccess) e = hipMemcpyAsync(o.l_seq.data(), C.l_seq, N * 4, hipMemcpyDeviceToHost, I.s);
+            return e;
+        };
+        he = ah ? hipSuccess : columns_to_host();
         if (he == hipSuccess) he = hipMemcpyAsync(I.h_status, I.d_status, 4, hipMemcpyDeviceToHost, I.s);
         if (he != hipSuccess || !I.sync()) return fail_dev("decode failed");
+        if (ah) {
+            bqc_anchor_info info{};
+            // a batch the host decoder takes (below), or one with more breaks than the card's chain walks: the host keeps the window
+            // state from this batch on (it is current there: every anchored batch before this one is submitted before it)
+            const int arc = *I.h_status ? 1 : bqc_anchor_complete(actx, ah, &info);
+            if (*I.h_status) bqc_anchor_discard(actx, ah);
+            if (arc < 0) return fail_dev(bqc_anchor_error(actx));
+            if (arc > 0) {
+                anchors_ok_ = false; ah = nullptr;
+                if (!*I.h_status && (columns_to_host() != hipSuccess || !I.sync())) return fail_dev("decode failed");
+            } else { o.anchored = ah; o.dev = dv; o.n_noqual = info.n_noqual; o.rid_min = info.rid_min; o.rid_max = info.rid_max; ++n_anchored_; }
+        }
         if (*I.h_status) {
             // A record the card does not decode (a read group that is not in the header, a second NM tag, no RG tag, ...): THIS
             // batch is decoded by the host reader's rules — its bytes come back from the window, its records are listed by a serial

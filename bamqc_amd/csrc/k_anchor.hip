@@ -1,0 +1,285 @@
+// k_anchor.hip — the order-dependent part of OverallNumbers::coverage (OverallNumbers.hpp:84-110) on the card, for ONE read group.
+//
+// The reference keeps, per read group, two live windows of 1000 positions: `shift` (where the first one starts), the chromosome
+// `id`, and — in this library's virtual coordinates — `win`, the number of windows flushed so far.  A read that enters coverage()
+// at beginPos b (bamqualcheck.cpp:318-327,392,430-433 decide which do) moves the state:
+//     first read:                         id = rid, shift = b
+//     id != rid or b - shift > 2000:      reset   -> id = rid, shift = b, win += 2          (unsigned arithmetic: b < shift resets too)
+//     1000 < b - shift < 2000:            slide   -> shift += 1000, win += 1
+// and gets {win, b - shift}.  A recurrence over 600 M reads — but almost all of it is arithmetic: behind any read, b - shift lies in
+// [0, 1000] (or is 2000 exactly: neither slide nor reset, "stuck"); so a read that is less than 1000 positions behind the read before
+// it (same chromosome) can only stay or slide ONCE, and a whole RUN of such reads follows from the state at the run's first read in
+// closed form: with x = b - shift_entry, b - shift = x if x <= 1000, else ((x - 1) mod 1000) + 1, and the slides are what was taken
+// off, in thousands.  What really is sequential are the BREAKS — a read 1000 or more behind its predecessor, out of order, or on
+// another chromosome: a handful per million reads of a 30x genome (chromosome ends, gaps in the assembly), every other read in sparse
+// data.  So:
+//   k_an_count / k_an_scan / k_an_scatter   the reads that enter coverage(), compacted in stream order (position, chromosome, index);
+//                                           the batch's other per-read facts the host used to gather (generic-path reads, records
+//                                           without qualities, range of chromosomes) on the way
+//   k_an_bcount / k_an_scan / k_an_bscatter the breaks among them, listed; every candidate learns the number of its run
+//   k_an_chain                              ONE thread walks the breaks (their operands loaded into LDS by the workgroup, 256 at a
+//                                           time): state at the end of the run before, transition of the recurrence, state the new run
+//                                           starts with.  More than AN_MAX_BREAKS breaks: the batch is left to the host's recurrence
+//                                           (flag in the summary; the state is not touched)
+//   k_an_apply                              every candidate: closed form from its run's entry -> {window, offset}; the candidates at
+//                                           which the window changes go to the boundary list the host builds the coverage tiles from
+// Checked against the host's recurrence (bqc_pipeline.cpp: CovPlanner) read by read on sorted, sparse, unsorted and wild inputs
+// (tests/test_gpu_anchor.py), and through every test that runs the program with the reader on the card.
+#include "kernels_common.h"
+#include "anchor.h"
+
+namespace {
+__device__ __forceinline__ bool an_candidate(const AnchorArgs& a, uint32_t i)
+{
+    const uint32_t flag = a.flag[i];
+    const int32_t rid = a.rid[i];
+    // primary record with a first / last flag, on a main chromosome, mapped, not a duplicate (bamqualcheck.cpp:318-327,392,430-433)
+    return !((flag & 0xD04u) || !(flag & 0xC0u) || (uint32_t)rid >= a.n_refs || !a.main_chrom[rid] || a.lane[i] >= a.n_lanes);
+}
+
+// exclusive prefix of `v` over the workgroup's 256 threads, and the workgroup's total
+__device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t* wsum /* [4] */, uint32_t& total)
+{
+    const uint32_t inc = wave_scan_incl(v);
+    block_sync();
+    if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
+    block_sync();
+    uint32_t off = inc - v;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return off;
+}
+
+// a read's state inside its run: x = beginPos - shift at the run's entry (for a stuck run: - beginPos of the read that reset)
+__device__ __forceinline__ void an_closed(uint32_t x, uint32_t& delta, uint32_t& slides)
+{
+    if (x <= BQC_VSIZE) { delta = x; slides = 0; return; }
+    delta = (x - 1u) % BQC_VSIZE + 1u;
+    slides = (x - delta) / BQC_VSIZE;
+}
+__device__ __forceinline__ void an_in_run(const AnchorRun& r, uint32_t b, uint32_t& rel, uint32_t& delta)
+{
+    uint32_t slides;
+    if (!r.stuck) { an_closed(b - r.s_e, delta, slides); rel = r.rel_e + slides; return; }
+    if (b == r.b_e) { delta = 2u * BQC_VSIZE; rel = r.rel_e; return; }
+    an_closed(b - r.b_star, delta, slides); // the first read further right reset the windows
+    rel = r.rel_e + 2u + slides;
+}
+} // namespace
+
+// ---- candidates ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_an_count(AnchorArgs a)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t c = 0, n_slow = 0, max_slow = 0, n_noqual = 0, s1 = 0, s2 = 0, s3 = 0;
+    int32_t rmin = INT32_MAX, rmax = -1;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t i = i0 + k;
+        if (i >= a.n) break;
+        c += an_candidate(a, i) ? 1u : 0u;
+        const uint32_t L = a.l_seq[i], f = a.flag[i];
+        s1 += (L + 1u) / 2u; s2 += L; s3 += a.n_cigar[i]; // (four reads per thread: far below 2^32; summed in 64 bits from the wave on)
+        if (a.no_fast || L > BQC_FAST_MAXLEN) { ++n_slow; max_slow = max(max_slow, L); }
+        n_noqual += ((f & BQC_FLAG_NO_QUAL) && !(f & 0x900u) && (f & 0xC0u)) ? 1u : 0u;
+        const int32_t rid = a.rid[i];
+        if ((uint32_t)rid < a.n_refs) { rmin = min(rmin, rid); rmax = max(rmax, rid); }
+    }
+    uint32_t total;
+    (void)block_excl(c, wsum, total);
+    if (threadIdx.x == 0) a.blk_a[blockIdx.x] = total;
+    // the batch's other facts: one atomic per wave
+    n_slow = wave_sum(n_slow); n_noqual = wave_sum(n_noqual);
+    unsigned long long t1 = s1, t2 = s2, t3 = s3;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); t3 += __shfl_xor(t3, o); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        max_slow = max(max_slow, (uint32_t)__shfl_xor((int)max_slow, o));
+        rmin = min(rmin, __shfl_xor(rmin, o));
+        rmax = max(rmax, __shfl_xor(rmax, o));
+    }
+    if (lane_id() == 0) {
+        if (n_slow) { atomicAdd(&a.sum->n_slow, n_slow); atomicMax(&a.sum->max_len_slow, max_slow); }
+        if (n_noqual) atomicAdd(&a.sum->n_noqual, n_noqual);
+        if (rmax >= 0) { atomicMin(&a.sum->rid_min, rmin); atomicMax(&a.sum->rid_max, rmax); }
+        atomicAdd(&a.sum->seq_bytes, t1); atomicAdd(&a.sum->qual_bytes, t2); atomicAdd(&a.sum->cigar_words, t3);
+    }
+}
+
+// exclusive scan of up to 4096 block counts by one workgroup of 1024 threads; the total goes to *total_out
+__global__ __launch_bounds__(1024) void k_an_scan(uint32_t* __restrict__ blk, uint32_t nblk, uint32_t* __restrict__ total_out)
+{
+    __shared__ uint32_t wsum[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += 1024u) { // (one round for batches of up to 4 M reads)
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? blk[i] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        block_sync();
+        if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
+        block_sync();
+        uint32_t off = inc - v, tot = 0;
+        for (uint32_t w = 0; w < 16u; ++w) { if (w < (threadIdx.x >> 6)) off += wsum[w]; tot += wsum[w]; }
+        if (i < nblk) blk[i] = carry + off;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_an_scatter(AnchorArgs a)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    bool cand[4];
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < 4u; ++k) { cand[k] = i0 + k < a.n && an_candidate(a, i0 + k); c += cand[k] ? 1u : 0u; }
+    uint32_t total;
+    uint32_t j = a.blk_a[blockIdx.x] + block_excl(c, wsum, total);
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t i = i0 + k;
+        if (i >= a.n) break;
+        if (cand[k]) { a.cpos[j] = (uint32_t)a.pos[i]; a.crid[j] = a.rid[i]; a.cidx[j] = i; ++j; }
+        else a.cov_out[i] = CovEntry{BQC_COV_NONE, 0u};
+    }
+}
+
+// ---- breaks ------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ bool an_break(const AnchorArgs& a, uint32_t j)
+{
+    if (j == 0) return true; // the batch's first candidate: its state comes from the batch before
+    return a.crid[j] != a.crid[j - 1] || a.cpos[j] - a.cpos[j - 1] >= BQC_VSIZE; // (unsigned: a read in front of its predecessor is a break)
+}
+}
+__global__ __launch_bounds__(256) void k_an_bcount(AnchorArgs a)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t nc = a.sum->n_cand, j0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < 4u; ++k) c += (j0 + k < nc && an_break(a, j0 + k)) ? 1u : 0u;
+    uint32_t total;
+    (void)block_excl(c, wsum, total);
+    if (threadIdx.x == 0) a.blk_b[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_an_bscatter(AnchorArgs a)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t nc = a.sum->n_cand, j0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    bool br[4];
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < 4u; ++k) { br[k] = j0 + k < nc && an_break(a, j0 + k); c += br[k] ? 1u : 0u; }
+    uint32_t total;
+    uint32_t r = a.blk_b[blockIdx.x] + block_excl(c, wsum, total); // breaks in front of this thread's first candidate
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t j = j0 + k;
+        if (j >= nc) break;
+        if (br[k]) { if (r < AN_MAX_BREAKS) a.bj[r] = j; ++r; }
+        a.crun[j] = r - 1u; // (candidate 0 is a break: r >= 1)
+    }
+}
+
+// ---- the chain over the breaks -----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_an_chain(AnchorArgs a)
+{
+    __shared__ uint32_t s_j[256], s_b[256], s_bl[256], s_jn[256];
+    __shared__ int32_t s_rid[256];
+    const uint32_t nc = a.sum->n_cand, nb = a.sum->n_breaks;
+    AnchorState st = *a.state;
+    if (threadIdx.x == 0) { a.sum->before = st; a.sum->after = st; a.sum->last_rel = 0; }
+    if (nb > AN_MAX_BREAKS) { if (threadIdx.x == 0) atomicOr(&a.sum->flags, AN_FLAG_TOO_MANY_BREAKS); return; }
+    if (nc == 0) return;
+    // the state between two reads: first / id / absolute shift / windows flushed in this batch, and the run it belongs to
+    uint32_t first = st.first, s = (uint32_t)st.shift, rel = 0;
+    int32_t id = st.id;
+    AnchorRun run{};
+    for (uint32_t base = 0; base < nb; base += 256u) {
+        block_sync();
+        {
+            const uint32_t k = base + threadIdx.x;
+            if (k < nb) {
+                const uint32_t j = a.bj[k];
+                s_j[threadIdx.x] = j; s_b[threadIdx.x] = a.cpos[j]; s_rid[threadIdx.x] = a.crid[j];
+                s_bl[threadIdx.x] = j ? a.cpos[j - 1] : 0u;            // the last read of the run before
+                s_jn[threadIdx.x] = k + 1 < nb ? a.bj[k + 1] : nc;      // where this run ends
+            }
+        }
+        block_sync();
+        if (threadIdx.x == 0) {
+            const uint32_t m = min(256u, nb - base);
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t j = s_j[t], b = s_b[t];
+                const int32_t rid = s_rid[t];
+                if (j) { // where the run before has got to at its last read
+                    uint32_t r2, d2;
+                    an_in_run(run, s_bl[t], r2, d2);
+                    rel = r2; s = s_bl[t] - d2;
+                }
+                // the recurrence itself (OverallNumbers.hpp:84-110)
+                if (first) { first = 0; id = rid; s = b; }
+                if (id != rid || b - s > 2u * BQC_VSIZE) { id = rid; rel += 2u; s = b; }
+                uint32_t p = b - s;
+                if (p > BQC_VSIZE && p < 2u * BQC_VSIZE) { rel += 1u; s += BQC_VSIZE; p -= BQC_VSIZE; }
+                run.b_e = b; run.s_e = s; run.rel_e = rel; run.stuck = p == 2u * BQC_VSIZE ? 1u : 0u; run.b_star = b;
+                if (run.stuck) // the first read of the run further right (reads at the same position come first: the run is sorted)
+                    for (uint32_t q = j + 1; q < s_jn[t]; ++q) { const uint32_t bq = a.cpos[q]; if (bq != b) { run.b_star = bq; break; } }
+                a.runs[base + t] = run;
+            }
+        }
+    }
+    if (threadIdx.x == 0) { // behind the batch's last candidate
+        uint32_t r2, d2;
+        const uint32_t bl = a.cpos[nc - 1];
+        an_in_run(run, bl, r2, d2);
+        AnchorState out;
+        out.first = 0; out.id = id; out.shift = (int32_t)(bl - d2); out.pad = 0; out.win = st.win + r2;
+        *a.state = out;
+        a.sum->after = out;
+        a.sum->last_rel = r2;
+    }
+}
+
+// ---- every candidate's anchor ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_an_apply(AnchorArgs a)
+{
+    if (a.sum->flags & AN_FLAG_TOO_MANY_BREAKS) return;
+    const uint32_t nc = a.sum->n_cand, j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= nc) return;
+    uint32_t rel, delta;
+    an_in_run(a.runs[a.crun[j]], a.cpos[j], rel, delta);
+    const uint32_t i = a.cidx[j];
+    a.cov_out[i] = CovEntry{rel, delta};
+    bool boundary = j == 0;
+    if (j) {
+        uint32_t relp, dp;
+        an_in_run(a.runs[a.crun[j - 1]], a.cpos[j - 1], relp, dp);
+        boundary = relp != rel;
+    }
+    if (boundary) {
+        const uint32_t at = atomicAdd(&a.sum->n_bound, 1u);
+        if (at < a.bound_cap) a.bound[at] = AnchorBound{rel, i};
+        else atomicOr(&a.sum->flags, AN_FLAG_BOUND_OVERFLOW);
+    }
+}
+
+__global__ void k_an_init(AnchorSummary* sum)
+{
+    AnchorSummary z{};
+    z.rid_min = INT32_MAX; z.rid_max = -1;
+    *sum = z;
+}
+
+extern "C" void bqc_launch_anchor(const AnchorArgs& a, hipStream_t s)
+{
+    const uint32_t nblk = (a.n + 1023u) / 1024u; // (also the grid of the candidates' passes: n_cand <= n is only known on the card)
+    hipLaunchKernelGGL(k_an_init, dim3(1), dim3(1), 0, s, a.sum);
+    if (!a.n) { hipLaunchKernelGGL(k_an_chain, dim3(1), dim3(256), 0, s, a); return; }
+    hipLaunchKernelGGL(k_an_count, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_a, nblk, &a.sum->n_cand);
+    hipLaunchKernelGGL(k_an_scatter, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_bcount, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_b, nblk, &a.sum->n_breaks);
+    hipLaunchKernelGGL(k_an_bscatter, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_chain, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_apply, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
+}

@@ -12,6 +12,7 @@
 
 bqc_batch HostBatch::view() const
 {
+    if (anchored) return dev;
     bqc_batch b;
     memset(&b, 0, sizeof b);
     b.n_reads = (uint32_t)flag.size();
@@ -27,6 +28,7 @@ void HostBatch::clear()
     flag.clear(); n_cigar.clear(); mapq.clear(); lane.clear(); seq.clear(); qual.clear(); rid.clear(); pos.clear();
     tlen.clear(); nm.clear(); as.clear(); nm_extra_val.clear(); l_seq.clear(); cigar.clear(); nm_extra_read.clear();
     d_seq = d_qual = nullptr; d_cigar = nullptr; // (dev_mem stays: the next batch reuses it)
+    anchored = nullptr; memset(&dev, 0, sizeof dev); n_noqual = 0; rid_min = 0; rid_max = -1;
 }
 
 static inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }

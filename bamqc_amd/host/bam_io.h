@@ -39,13 +39,20 @@ struct HostBatch { // owning storage behind a bqc_batch
     void* dev_mem = nullptr;
     size_t dev_cap = 0;
     void (*dev_free)(void*) = nullptr;
+    // A batch that also keeps its FIXED columns on the card and was anchored there (include/bamqc.h: bqc_anchor_*): the host vectors
+    // above are empty, dev holds the device pointers (n_reads and all), `anchored` the handle bqc_submit_anchored takes; what the
+    // program wants to know about the reads without seeing them: records without qualities, range of reference ids.
+    void* anchored = nullptr;
+    bqc_batch dev{};
+    uint32_t n_noqual = 0;
+    int32_t rid_min = 0, rid_max = -1;
     HostBatch() = default;
     HostBatch(const HostBatch&) = delete;
     HostBatch& operator=(const HostBatch&) = delete;
     ~HostBatch() { if (dev_mem && dev_free) dev_free(dev_mem); }
     bqc_batch view() const;
     void clear();
-    size_t n() const { return flag.size(); }
+    size_t n() const { return anchored ? dev.n_reads : flag.size(); }
 };
 
 // what the driver needs from an input stream of alignment records

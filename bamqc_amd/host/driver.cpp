@@ -946,11 +946,13 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     double t_create_s = 0, t_c_warm = 0, t_c_reader = 0, t_c_create = 0;
     std::thread creator([&] {
         const auto c0 = clk::now();
-        if (warm.joinable()) warm.join();
+        // Who sets up when (round 4): the warm-up thread starts the runtime (~60 ms) and then makes the program's four streams one after the
+        // other (20 + 3 x 8-10 ms: hardware queues, serial whoever asks); the reader allocates its buffers as soon as the runtime is up
+        // and takes the SECOND stream; the context is created here as soon as the FIRST stream exists — a few milliseconds of allocations
+        // and memsets, behind the reader's allocations by then (side by side the two were measured to hold each other up at the runtime's
+        // locks in round 3, when each also made its own streams and the reader page-locked 96 MB with hipHostMalloc) — and the references
+        // go to the card while the reader still waits for its stream.
         const auto c1 = clk::now();
-        // the GPU reader sets itself up first (buffers, streams, page-locked chunks: ~50 ms): side by side the two were measured to hold
-        // each other up at the runtime's locks — context creation 0.4-0.65 s instead of 0.1 in one run out of three
-        while (use_gpu_reader && !gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));
         const auto c2 = clk::now();
         rc = bqc_create(&bo, &ctx);
         if (rc) create_err = bqc_last_error(nullptr);
@@ -977,7 +979,17 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         for (size_t i = 0; i < fa.size(); ++i) if (fa[i].name == H.ref_names[r]) { fasta_index[r] = (int32_t)i; break; }
     const auto t_fasta = clk::now();
     creator.join();
-    if (use_gpu_reader) { while (!gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(200)); gpu_rd.allow_kernels(); } // (the context exists: the card may get busy)
+    // The reader may launch its first inflate kernel once the context exists AND its own set-up is done (it is still waiting for its
+    // stream at this point, as a rule): a thread of its own says so, this one goes on to the references.
+    std::thread allow_thr;
+    struct AllowJoiner { std::thread& t; ~AllowJoiner() { if (t.joinable()) t.join(); } } allow_joiner{allow_thr};
+    if (use_gpu_reader) allow_thr = std::thread([&gpu_reader_opened, &gpu_rd, ctx, rc] {
+        while (!gpu_reader_opened.load()) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        // the batches' coverage anchors are made on the card from the first batch on (BQC_DEVICE_ANCHORS=0: the host's pass, columns and all)
+        const char* da = getenv("BQC_DEVICE_ANCHORS");
+        if (!rc && ctx && !(da && da[0] == '0')) gpu_rd.set_anchor_context(ctx);
+        gpu_rd.allow_kernels(); // (the context exists: the card may get busy)
+    });
     const auto t_create = clk::now();
     if (rc) { fprintf(stderr, "ERROR: %s\n", create_err.c_str()); stop_decoder(); return shard_abort(); }
     if ((rc = bqc_set_fasta_index(ctx, fasta_index.data()))) { fprintf(stderr, "ERROR: %s\n", bqc_last_error(ctx)); stop_decoder(); bqc_destroy(ctx); return shard_abort(); }
@@ -1026,10 +1038,19 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     double t_lazy_refs = 0;
     uint32_t n_lazy_refs = 0;
     double t_wait_refs = 0;
+    std::vector<int32_t> rid_range; // (a batch whose columns stayed on the card names the range of its reference ids)
     auto ensure_refs = [&](const HostBatch& hb) -> int { // the contigs this batch's reads lie on are on the card before it is submitted
+        const int32_t* rid_begin = hb.rid.data();
+        const int32_t* rid_end = hb.rid.data() + hb.rid.size();
+        if (hb.anchored) {
+            rid_range.clear();
+            for (int32_t r = hb.rid_min; r <= hb.rid_max; ++r) rid_range.push_back(r);
+            rid_begin = rid_range.data(); rid_end = rid_range.data() + rid_range.size();
+        }
         if (bg_refs) { // wait for the uploader where it has not got to yet
             int32_t last = -1;
-            for (int32_t rid : hb.rid) {
+            for (const int32_t* q = rid_begin; q != rid_end; ++q) {
+                const int32_t rid = *q;
                 if (rid == last || rid < 0 || (uint32_t)rid >= n_refs) continue;
                 last = rid;
                 if (ref_state[rid].load() == 1) continue;
@@ -1044,7 +1065,8 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         std::vector<size_t> which;
         std::vector<uint32_t> rids;
         int32_t last = -1;
-        for (int32_t rid : hb.rid) {
+        for (const int32_t* q = rid_begin; q != rid_end; ++q) {
+            const int32_t rid = *q;
             if (rid == last || rid < 0 || (uint32_t)rid >= n_refs) continue;
             last = rid;
             if (ref_loaded[rid] || fasta_index[rid] < 0) continue;
@@ -1097,7 +1119,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         if (status) continue; // drain
         { // check_read_len (QualityCheck.hpp:70-79, called at bamqualcheck.cpp:357,378; return value ignored): one line per primary
           // record with a first / last flag whose quality string is empty while its sequence is not
-            size_t n_noqual = 0;
+            size_t n_noqual = hb->anchored ? hb->n_noqual : 0; // (a batch whose columns stayed on the card: counted there)
             for (uint16_t f : hb->flag) n_noqual += (f & BQC_FLAG_NO_QUAL) && !(f & 0x900) && (f & 0xC0);
             if (use_gpu_reader) { n_noqual_deferred += n_noqual; n_noqual = 0; } // (printed once the pass is known to be the one that counts)
             if (n_noqual) {
@@ -1119,7 +1141,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
         if (pinned || hb->d_seq) { // (BQC_NO_PINNED=1 is about host columns: a payload that lives on the card can only be taken from there)
             if (!hb->d_seq) pin_batch(*hb); // (a batch decoded on the card: its payload is there already, its small fixed columns are copied staged)
             uint64_t ticket = 0;
-            if ((rc = bqc_submit_async(ctx, &v, &ticket))) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
+            if (hb->anchored) { rc = bqc_submit_anchored(ctx, &v, (bqc_anchored*)hb->anchored, &ticket); hb->anchored = nullptr; }
+            else rc = bqc_submit_async(ctx, &v, &ticket);
+            if (rc) { fprintf(stderr, "%s\n", bqc_last_error(ctx)); status = 1; }
             inflight.push_back(InFlight{ticket, std::move(hb)});
             recycle(false);
         } else {
@@ -1143,6 +1167,7 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     }
     if (timing && refs_beside_loop) fprintf(stderr, "[timing] references uploaded beside the record loop; the submitting thread waited %.3f s for them\n", t_wait_refs);
     if (timing && lazy_refs) fprintf(stderr, "[timing] %u of %u contigs loaded, when their first reads arrived: %.3f s\n", n_lazy_refs, n_refs, t_lazy_refs);
+    if (timing && use_gpu_reader) fprintf(stderr, "[timing] %llu batches anchored on the card (fixed columns never on the host)\n", (unsigned long long)gpu_rd.batches_anchored());
     if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",

@@ -184,7 +184,9 @@ typedef struct bqc_dbatch bqc_dbatch; /* a batch resident in device memory */
 /* ---- aggregation (replaces bamqualcheck.cpp:303-453) ----------------------- */
 int bqc_abi_version(void);
 int bqc_create(const bqc_options* opt, bqc_ctx** out);
-/* Starts the HIP runtime on `device` (~0.1 s on a cold process): callable from any thread, e.g. while the inputs are opened. */
+/* Starts the HIP runtime on `device` (~0.06 s on a cold process) and makes the streams ahead that a context (and the program's reader)
+ * will ask for (~0.05 s more, which then overlap with the caller's other set-up): callable from any thread, once per process, e.g.
+ * while the inputs are opened. */
 int bqc_warmup(int32_t device);
 /* The FASTA order of the contigs (bqc_options.fasta_index) may also be given after creation, before the first batch: a
  * program can then create the context while it still reads the FASTA file. */
@@ -213,6 +215,33 @@ int bqc_submit(bqc_ctx* ctx, const bqc_batch* batch);
  * bqc_batch_uploaded(ctx, ticket, ...) returns 1.  The payload columns (seq, qual, cigar) may also live in the device's own
  * memory (a caller that inflates and decodes there); the fixed columns are read by the host as well and stay host pointers. */
 int bqc_submit_async(bqc_ctx* ctx, const bqc_batch* batch, uint64_t* ticket);
+
+/* ---- batches that live on the card entirely (a caller that decodes the records there: the program's reader, csrc/gpu_bam.hip) ----
+ * With the FIXED columns in device memory too, the one order-dependent step of the reference's loop — the window state machine of
+ * OverallNumbers::coverage, OverallNumbers.hpp:84-110, which bqc_submit* runs on the host over the fixed columns — runs on the card
+ * as well (csrc/k_anchor.hip), and the columns never come to the host: it sees a summary of a few hundred bytes per batch.
+ *   bqc_anchor_enqueue   queues the anchor kernels and the copy of their summary on `stream` (a hipStream_t on the context's device, on
+ *                        which the columns are complete); d_cov: 8 bytes per read of device memory for the anchors, valid — like the
+ *                        columns — until the batch's ticket is reported uploaded.  Returns 0 and a handle; 1: not available — the
+ *                        context has several read groups, is a shard_tail context, or a batch has gone through bqc_submit* /
+ *                        bqc_upload before (the host then keeps the state for the rest of the stream); < 0: -BQC_ERR_*.
+ *   bqc_anchor_complete  after the caller has synchronised `stream`: 0 = anchored; 1 = not anchored (more position breaks in the batch
+ *                        than the card's serial chain takes: the card has left its state untouched; this batch and every later one
+ *                        go through bqc_submit* with host columns); < 0: -BQC_ERR_* (bqc_anchor_error).  `info` (optional): what a
+ *                        program wants to know about a batch whose columns it does not have.
+ *   bqc_submit_anchored  the batch into the pipeline as bqc_submit_async does (every column of `batch` a device pointer); consumes the handle.
+ * Batches must be anchored in stream order and submitted in the same order; the anchor calls may be made by another thread than the
+ * submit calls (the program's decode thread and its submitting thread). */
+typedef struct bqc_anchored bqc_anchored;
+typedef struct bqc_anchor_info {
+    uint32_t n_noqual;        /* primary first / last records without qualities (check_read_len's message, QualityCheck.hpp:70-79) */
+    int32_t rid_min, rid_max; /* range of the reference ids in [0, n_refs) the batch holds; rid_min > rid_max: none */
+} bqc_anchor_info;
+int bqc_anchor_enqueue(bqc_ctx* ctx, const bqc_batch* batch, void* d_cov, void* stream, bqc_anchored** out);
+int bqc_anchor_complete(bqc_ctx* ctx, bqc_anchored* a, bqc_anchor_info* info);
+int bqc_submit_anchored(bqc_ctx* ctx, const bqc_batch* batch, bqc_anchored* a, uint64_t* ticket);
+void bqc_anchor_discard(bqc_ctx* ctx, bqc_anchored* a);
+const char* bqc_anchor_error(const bqc_ctx* ctx);
 /* 1: the batch's columns have been copied to the device (or the ticket is older than every batch in flight), 0: not yet
  * (only with wait == 0), < 0: -(BQC_ERR_*). */
 int bqc_batch_uploaded(bqc_ctx* ctx, uint64_t ticket, int wait);

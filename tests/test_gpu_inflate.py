@@ -277,39 +277,7 @@ def test_reader_on_the_gpu_matches_the_cpu_decoder(tmp_path, level):
             assert np.array_equal(a[k], b[k]), k
 
 
-class _Hip:
-    """Device memory through the HIP runtime the library itself is linked against (ctypes; torch brings a runtime of its own, and a
-    second one in a process that has used the card already finds no GPU)."""
-    def __init__(self):
-        _lib.load()
-        self.rt = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
-        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-        self.rt.hipFree.argtypes = [C.c_void_p]
-        self.bufs = []
-
-    def put(self, arr, extra=0):
-        arr = np.ascontiguousarray(arr)
-        p = C.c_void_p()
-        assert self.rt.hipMalloc(C.byref(p), arr.nbytes + extra + 256) == 0
-        assert self.rt.hipMemset(p, 0, arr.nbytes + extra + 256) == 0
-        if arr.nbytes:
-            assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
-        self.bufs.append(p)
-        return p
-
-    def get(self, p, nbytes, dtype=np.uint8):
-        out = np.zeros(nbytes, np.uint8)
-        if nbytes:
-            assert self.rt.hipMemcpy(out.ctypes.data, p, nbytes, 2) == 0
-        return out.view(dtype)
-
-    def free(self):
-        assert self.rt.hipDeviceSynchronize() == 0
-        for p in self.bufs:
-            self.rt.hipFree(p)
-        self.bufs = []
+from tests.hipmem import Hip as _Hip  # noqa: E402
 
 
 def _launch_on_card(streams, want, crcs):

@@ -32,7 +32,7 @@ def main():
                 assert r.returncode == 0, r.stderr[-3000:]
                 print("%s run %d: %.3f s = %.1f M reads/s" % (v or "default", rep, dt, reads / dt / 1e6), flush=True)
                 if rep == 2:
-                    print("\n".join(ln for ln in r.stderr.splitlines() if ln.startswith("[timing]")), flush=True)
+                    print("\n".join(ln for ln in r.stderr.splitlines() if ln.startswith(("[timing]", "[gpu reader] open"))), flush=True)
                 outs.append(out)
         ref = open(outs[0], "rb").read()
         for o in outs[1:]:
