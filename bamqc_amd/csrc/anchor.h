@@ -13,6 +13,13 @@ struct AnchorState {
     int32_t shift;    // position of the first live window's first base
     uint32_t pad;
     uint64_t win;     // absolute index (flush order) of the first live window
+    // A shard that starts inside the stream (bqc_options.shard_tail): its reads are SET ASIDE (BQC_COV_PENDING) up to the first one
+    // that resets the windows whatever their state — another chromosome, or more than 2000 positions from the read before
+    // (bqc_pipeline.cpp: host_pass) —, from which on the shard runs as a stream of its own.
+    uint32_t pending;  // still setting aside
+    uint32_t has_prev; // a read has been seen (prev_rid / prev_bp are the last one's)
+    int32_t prev_rid;
+    uint32_t prev_bp;
 };
 
 // what the host needs from a batch besides the anchors themselves
@@ -26,7 +33,8 @@ struct AnchorSummary {
     uint32_t n_noqual;      // primary first / last records without qualities (check_read_len's message, QualityCheck.hpp:70-79)
     uint32_t last_rel;      // window (relative to before.win) of the last candidate
     int32_t rid_min, rid_max; // range of the reference ids in [0, n_refs) the batch holds (rid_min > rid_max: none)
-    uint32_t pad0, pad1;
+    uint32_t n_pending;     // candidates set aside (the first n_pending of the batch's candidates: a shard_tail context)
+    uint32_t first_certain; // candidate index of the first read that resets whatever the state (0xFFFFFFFF: none; only looked for while setting aside)
     unsigned long long seq_bytes, qual_bytes, cigar_words; // payload sizes: sums of ceil(l_seq / 2), l_seq, n_cigar
     AnchorState before, after;
 };
@@ -48,6 +56,12 @@ struct AnchorRun {
 
 #define AN_MAX_BREAKS 65536u
 
+struct AnchorPart { // what a workgroup of k_an_count (1024 reads) knows; summed by k_an_scan
+    uint32_t n_slow, max_slow, n_noqual, first_certain;
+    int32_t rid_min, rid_max;
+    unsigned long long s1, s2, s3;
+};
+
 struct AnchorArgs {
     uint32_t n, n_refs, n_lanes, no_fast;
     const uint16_t* flag; const uint8_t* lane; const int32_t* rid; const int32_t* pos; const uint32_t* l_seq; const uint16_t* n_cigar;
@@ -61,6 +75,7 @@ struct AnchorArgs {
     uint32_t* bj;               // [AN_MAX_BREAKS] candidate index of every break
     AnchorRun* runs;            // [AN_MAX_BREAKS]
     uint32_t* blk_a; uint32_t* blk_b; // [n / 1024 + 2] block counts / offsets of the two compactions
+    AnchorPart* parts;          // [n / 1024 + 2]
 };
 
 extern "C" void bqc_launch_anchor(const AnchorArgs& a, hipStream_t s);

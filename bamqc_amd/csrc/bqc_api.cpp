@@ -338,6 +338,7 @@ extern "C" int bqc_reset(bqc_ctx* c)
     if (c->anchor.d_state) { // (anchors made on the card: the read group's state starts over as well)
         AnchorState s0{};
         s0.first = 1;
+        s0.pending = c->shard.tail && !c->shard.resolved ? 1u : 0u;
         HIPCHK(c, hipMemcpy(c->anchor.d_state, &s0, sizeof s0, hipMemcpyHostToDevice));
     }
     c->anchor.mode = 0;

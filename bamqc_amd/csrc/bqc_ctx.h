@@ -111,6 +111,8 @@ struct bqc_anchored {
     AnchorSummary* h_sum = nullptr;   // page-locked: the batch's summary ...
     AnchorBound* h_bound = nullptr;   // ... and the first kInline entries of its boundary list
     std::vector<AnchorBound> rest;    // the entries behind them (sparse data), fetched by bqc_anchor_complete
+    std::vector<int32_t> pend_rid;    // a shard_tail context: the reads set aside (the batch's first n_pending candidates) ...
+    std::vector<uint32_t> pend_bp;    // ... chromosome and beginPos, for the pending log (bqc_shard_resolve)
     const CovEntry* d_cov = nullptr;  // the caller's device buffer with the anchors of the batch's reads
     uint32_t n = 0;
     bool completed = false;

@@ -313,11 +313,21 @@ static int host_pass_anchored(bqc_ctx* c, uint32_t n, const bqc_anchored* a, Hos
         H.stretches.push_back(St);
     }
     H.n_pending = 0;
+    if (S.n_pending) { // a shard in the middle of the stream: the reads set aside go to the pending log, as host_pass would have put them there
+        ShardCtx& sh = c->shard;
+        sh.batches.emplace_back();
+        PendBatch& pb = sh.batches.back();
+        pb.lane.assign(S.n_pending, 0);
+        pb.rid = a->pend_rid;
+        pb.bp = a->pend_bp;
+        H.n_pending = S.n_pending;
+    }
+    if (c->shard.tail) { c->shard.pending[0] = S.after.pending ? 1 : 0; c->shard.has_prev[0] = S.after.has_prev ? 1 : 0; c->shard.prev_rid[0] = S.after.prev_rid; c->shard.prev_bp[0] = S.after.prev_bp; }
     // the read group's state in front of the batch, as the planner wants to find it
     LaneCov& lc = c->cov[0];
     lc.first = S.before.first != 0; lc.id = S.before.id; lc.shift = S.before.shift; lc.win = S.before.win;
     CovPlanner plan(c, H, n);
-    if (S.n_cand) {
+    if (S.n_cand > S.n_pending) {
         // first[k] = the first read whose window is >= k: from the boundary list (any order on the card: sorted here)
         std::vector<AnchorBound> bl(a->h_bound, a->h_bound + std::min<uint32_t>(S.n_bound, bqc_anchored::kInline));
         bl.insert(bl.end(), a->rest.begin(), a->rest.end());
@@ -767,9 +777,9 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
     if (!c || !b || !out || (b->n_reads && !d_cov)) return -BQC_ERR_ARG;
     *out = nullptr;
     AnchorEngine& E = c->anchor;
-    // one read group, the whole stream from its first batch on, and not a shard that starts inside the stream (its first reads are set aside
-    // by the host's pass until the predecessor's state is known)
-    if (c->opt.n_lanes != 1 || c->shard.tail || E.mode.load() == 2) return 1;
+    // one read group, and the whole stream from its first batch on (a shard that starts inside the stream sets its first reads aside on
+    // the card as the host's pass would: AnchorState::pending)
+    if (c->opt.n_lanes != 1 || (c->shard.tail && c->shard.resolved) || E.mode.load() == 2) return 1;
     if (hipSetDevice(c->device) != hipSuccess) return anchor_fail(c, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     const size_t n = b->n_reads;
@@ -777,6 +787,7 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
         if (hipMalloc((void**)&E.d_state, sizeof(AnchorState)) != hipSuccess || hipMalloc((void**)&E.d_sum, sizeof(AnchorSummary)) != hipSuccess) return anchor_fail(c, "out of device memory");
         AnchorState s0{};
         s0.first = 1;
+        s0.pending = c->shard.tail ? 1u : 0u;
         if (hipMemcpy(E.d_state, &s0, sizeof s0, hipMemcpyHostToDevice) != hipSuccess) return anchor_fail(c, "copy failed");
     }
     if (E.cap_n < n) { // scratch: [cpos crid cidx crun](4 B x n) [bound](8 B x n) [bj][runs][blk_a][blk_b]
@@ -784,7 +795,7 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
         if (E.d_scratch) (void)hipFree(E.d_scratch);
         E.d_scratch = nullptr; E.cap_n = 0;
         const size_t cap = std::max<size_t>(n + n / 8, 1u << 20);
-        const size_t bytes = cap * 24 + AN_MAX_BREAKS * (4 + sizeof(AnchorRun)) + 2 * (cap / 1024 + 4) * 4 + 4096;
+        const size_t bytes = cap * 24 + AN_MAX_BREAKS * (4 + sizeof(AnchorRun)) + (cap / 1024 + 4) * (2 * 4 + sizeof(AnchorPart)) + 4096;
         if (hipMalloc(&E.d_scratch, bytes) != hipSuccess) return anchor_fail(c, "out of device memory");
         E.cap_n = cap;
     }
@@ -804,7 +815,7 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
         std::lock_guard<std::mutex> lk(E.m);
         E.all.push_back(a);
     }
-    a->rest.clear(); a->completed = false; a->n = (uint32_t)n; a->d_cov = (const CovEntry*)d_cov;
+    a->rest.clear(); a->pend_rid.clear(); a->pend_bp.clear(); a->completed = false; a->n = (uint32_t)n; a->d_cov = (const CovEntry*)d_cov;
     AnchorArgs A{};
     A.n = (uint32_t)n; A.n_refs = c->opt.n_refs; A.n_lanes = 1; A.no_fast = c->no_fast ? 1u : 0u;
     A.flag = b->flag; A.lane = b->lane; A.rid = b->rid; A.pos = b->pos; A.l_seq = b->l_seq; A.n_cigar = b->n_cigar;
@@ -816,7 +827,9 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
     A.bound = (AnchorBound*)q; q += 8 * cap; A.bound_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
     A.bj = (uint32_t*)q; q += 4 * AN_MAX_BREAKS; A.runs = (AnchorRun*)q; q += sizeof(AnchorRun) * AN_MAX_BREAKS;
     q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
-    A.blk_a = (uint32_t*)q; q += 4 * (cap / 1024 + 4); A.blk_b = (uint32_t*)q;
+    A.blk_a = (uint32_t*)q; q += 4 * (cap / 1024 + 4); A.blk_b = (uint32_t*)q; q += 4 * (cap / 1024 + 4);
+    q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
+    A.parts = (AnchorPart*)q;
     E.d_bound = A.bound;
     bqc_launch_anchor(A, st);
     if (hipMemcpyAsync(a->h_sum, E.d_sum, sizeof(AnchorSummary), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -847,6 +860,12 @@ extern "C" int bqc_anchor_complete(bqc_ctx* c, bqc_anchored* a, bqc_anchor_info*
         a->rest.resize(S.n_bound - bqc_anchored::kInline);
         if (hipSetDevice(c->device) != hipSuccess ||
             hipMemcpy(a->rest.data(), E.d_bound + bqc_anchored::kInline, sizeof(AnchorBound) * a->rest.size(), hipMemcpyDeviceToHost) != hipSuccess) return anchor_fail(c, "copy failed");
+    }
+    if (S.n_pending) { // the reads set aside: chromosome and position of the batch's first n_pending candidates (the scratch's crid / cpos)
+        a->pend_rid.resize(S.n_pending); a->pend_bp.resize(S.n_pending);
+        const char* q = (const char*)E.d_scratch;
+        if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(a->pend_bp.data(), q, 4ull * S.n_pending, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(a->pend_rid.data(), q + 4 * E.cap_n, 4ull * S.n_pending, hipMemcpyDeviceToHost) != hipSuccess) return anchor_fail(c, "copy failed");
     }
     a->completed = true;
     return 0;

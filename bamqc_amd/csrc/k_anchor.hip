@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void k_an_count(AnchorArgs a)
     uint32_t total;
     (void)block_excl(c, wsum, total);
     if (threadIdx.x == 0) a.blk_a[blockIdx.x] = total;
-    // the batch's other facts: one atomic per wave
+    // the batch's other facts: the workgroup's partial results (thousands of waves adding to the same few words took longer than the
+    // rest of the kernel; k_an_scan sums the workgroups')
+    __shared__ unsigned long long part[4][8];
     n_slow = wave_sum(n_slow); n_noqual = wave_sum(n_noqual);
     unsigned long long t1 = s1, t2 = s2, t3 = s3;
 #pragma unroll
@@ -100,17 +102,68 @@ __global__ __launch_bounds__(256) void k_an_count(AnchorArgs a)
         rmax = max(rmax, __shfl_xor(rmax, o));
     }
     if (lane_id() == 0) {
-        if (n_slow) { atomicAdd(&a.sum->n_slow, n_slow); atomicMax(&a.sum->max_len_slow, max_slow); }
-        if (n_noqual) atomicAdd(&a.sum->n_noqual, n_noqual);
-        if (rmax >= 0) { atomicMin(&a.sum->rid_min, rmin); atomicMax(&a.sum->rid_max, rmax); }
-        atomicAdd(&a.sum->seq_bytes, t1); atomicAdd(&a.sum->qual_bytes, t2); atomicAdd(&a.sum->cigar_words, t3);
+        unsigned long long* q = part[threadIdx.x >> 6];
+        q[0] = n_slow; q[1] = max_slow; q[2] = n_noqual; q[3] = (unsigned long long)(long long)rmin; q[4] = (unsigned long long)(long long)rmax; q[5] = t1; q[6] = t2; q[7] = t3;
+    }
+    block_sync();
+    if (threadIdx.x == 0) {
+        AnchorPart P;
+        P.n_slow = (uint32_t)(part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+        P.max_slow = (uint32_t)max(max(part[0][1], part[1][1]), max(part[2][1], part[3][1]));
+        P.n_noqual = (uint32_t)(part[0][2] + part[1][2] + part[2][2] + part[3][2]);
+        P.rid_min = min(min((int32_t)(long long)part[0][3], (int32_t)(long long)part[1][3]), min((int32_t)(long long)part[2][3], (int32_t)(long long)part[3][3]));
+        P.rid_max = max(max((int32_t)(long long)part[0][4], (int32_t)(long long)part[1][4]), max((int32_t)(long long)part[2][4], (int32_t)(long long)part[3][4]));
+        P.s1 = part[0][5] + part[1][5] + part[2][5] + part[3][5];
+        P.s2 = part[0][6] + part[1][6] + part[2][6] + part[3][6];
+        P.s3 = part[0][7] + part[1][7] + part[2][7] + part[3][7];
+        P.first_certain = 0xFFFFFFFFu;
+        a.parts[blockIdx.x] = P;
     }
 }
 
 // exclusive scan of up to 4096 block counts by one workgroup of 1024 threads; the total goes to *total_out
-__global__ __launch_bounds__(1024) void k_an_scan(uint32_t* __restrict__ blk, uint32_t nblk, uint32_t* __restrict__ total_out)
+// (which: 0 = the candidates' counts — it also starts the batch's summary and sums the workgroups' partial facts into it; 1 = the
+// breaks' counts — and the first certain reset, when a shard is still setting reads aside)
+__global__ __launch_bounds__(1024) void k_an_scan(uint32_t* __restrict__ blk, uint32_t nblk, AnchorSummary* __restrict__ sum, AnchorPart* __restrict__ parts, int which)
 {
     __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long red[16][8];
+    if (which == 0) {
+        unsigned long long v[8] = {0, 0, 0, (unsigned long long)(long long)INT32_MAX, (unsigned long long)(long long)-1, 0, 0, 0};
+        for (uint32_t i = threadIdx.x; i < nblk; i += 1024u) {
+            const AnchorPart P = parts[i];
+            v[0] += P.n_slow; v[1] = max(v[1], (unsigned long long)P.max_slow); v[2] += P.n_noqual;
+            v[3] = (unsigned long long)(long long)min((int32_t)(long long)v[3], P.rid_min); v[4] = (unsigned long long)(long long)max((int32_t)(long long)v[4], P.rid_max);
+            v[5] += P.s1; v[6] += P.s2; v[7] += P.s3;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v[0] += __shfl_xor(v[0], o); v[2] += __shfl_xor(v[2], o); v[5] += __shfl_xor(v[5], o); v[6] += __shfl_xor(v[6], o); v[7] += __shfl_xor(v[7], o);
+            v[1] = max(v[1], (unsigned long long)__shfl_xor(v[1], o));
+            v[3] = (unsigned long long)(long long)min((int32_t)(long long)v[3], (int32_t)(long long)__shfl_xor(v[3], o));
+            v[4] = (unsigned long long)(long long)max((int32_t)(long long)v[4], (int32_t)(long long)__shfl_xor(v[4], o));
+        }
+        if (lane_id() == 0) for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = v[k];
+        block_sync();
+        if (threadIdx.x == 0) {
+            AnchorSummary z{};
+            z.rid_min = INT32_MAX; z.rid_max = -1; z.first_certain = 0xFFFFFFFFu;
+            for (int w = 0; w < 16; ++w) {
+                z.n_slow += (uint32_t)red[w][0]; z.max_len_slow = max(z.max_len_slow, (uint32_t)red[w][1]); z.n_noqual += (uint32_t)red[w][2];
+                z.rid_min = min(z.rid_min, (int32_t)(long long)red[w][3]); z.rid_max = max(z.rid_max, (int32_t)(long long)red[w][4]);
+                z.seq_bytes += red[w][5]; z.qual_bytes += red[w][6]; z.cigar_words += red[w][7];
+            }
+            *sum = z;
+        }
+        block_sync();
+    } else {
+        uint32_t fc = 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < nblk; i += 1024u) fc = min(fc, parts[i].first_certain);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fc = min(fc, (uint32_t)__shfl_xor((int)fc, o));
+        if (lane_id() == 0 && fc != 0xFFFFFFFFu) atomicMin(&sum->first_certain, fc); // (sixteen waves)
+    }
+    uint32_t* const total_out = which == 0 ? &sum->n_cand : &sum->n_breaks;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nblk; base += 1024u) { // (one round for batches of up to 4 M reads)
         const uint32_t i = base + threadIdx.x;
@@ -161,6 +214,20 @@ __global__ __launch_bounds__(256) void k_an_bcount(AnchorArgs a)
     uint32_t total;
     (void)block_excl(c, wsum, total);
     if (threadIdx.x == 0) a.blk_b[blockIdx.x] = total;
+    if (a.state->pending) { // a shard in the middle of the stream: the first read that resets the windows whatever their state
+        uint32_t fc = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < 4u && fc == 0xFFFFFFFFu; ++k) {
+            const uint32_t j = j0 + k;
+            if (j >= nc) break;
+            const bool has_prev = j ? true : a.state->has_prev != 0;
+            const int32_t prid = j ? a.crid[j - 1] : a.state->prev_rid;
+            const uint32_t d = a.cpos[j] - (j ? a.cpos[j - 1] : a.state->prev_bp);
+            if (has_prev && (a.crid[j] != prid || (d > 2u * BQC_VSIZE && d <= 0xFFFFFFFFu - 2u * BQC_VSIZE))) fc = j;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fc = min(fc, (uint32_t)__shfl_xor((int)fc, o));
+        if (lane_id() == 0 && fc != 0xFFFFFFFFu) atomicMin(&a.parts[blockIdx.x].first_certain, fc); // (the workgroup's four waves; k_an_scan takes the minimum)
+    }
 }
 __global__ __launch_bounds__(256) void k_an_bscatter(AnchorArgs a)
 {
@@ -186,14 +253,32 @@ __global__ __launch_bounds__(256) void k_an_chain(AnchorArgs a)
     __shared__ int32_t s_rid[256];
     const uint32_t nc = a.sum->n_cand, nb = a.sum->n_breaks;
     AnchorState st = *a.state;
-    if (threadIdx.x == 0) { a.sum->before = st; a.sum->after = st; a.sum->last_rel = 0; }
+    if (threadIdx.x == 0) { a.sum->before = st; a.sum->after = st; a.sum->last_rel = 0; a.sum->n_pending = 0; }
     if (nb > AN_MAX_BREAKS) { if (threadIdx.x == 0) atomicOr(&a.sum->flags, AN_FLAG_TOO_MANY_BREAKS); return; }
     if (nc == 0) return;
+    // setting aside: the candidates in front of the first certain reset are pending; the chain starts AT that read — a break — from the
+    // context's own state (a stream that begins there)
+    uint32_t k0 = 0, j_first = 0;
+    if (st.pending) {
+        const uint32_t fc = a.sum->first_certain;
+        j_first = fc == 0xFFFFFFFFu ? nc : fc;
+        if (threadIdx.x == 0) a.sum->n_pending = j_first;
+        if (j_first == nc) { // every candidate of the batch is set aside
+            if (threadIdx.x == 0) {
+                AnchorState out = st;
+                out.has_prev = 1; out.prev_rid = a.crid[nc - 1]; out.prev_bp = a.cpos[nc - 1];
+                *a.state = out;
+                a.sum->after = out;
+            }
+            return;
+        }
+        k0 = a.crun[j_first];
+    }
     // the state between two reads: first / id / absolute shift / windows flushed in this batch, and the run it belongs to
     uint32_t first = st.first, s = (uint32_t)st.shift, rel = 0;
     int32_t id = st.id;
     AnchorRun run{};
-    for (uint32_t base = 0; base < nb; base += 256u) {
+    for (uint32_t base = k0; base < nb; base += 256u) {
         block_sync();
         {
             const uint32_t k = base + threadIdx.x;
@@ -210,7 +295,7 @@ __global__ __launch_bounds__(256) void k_an_chain(AnchorArgs a)
             for (uint32_t t = 0; t < m; ++t) {
                 const uint32_t j = s_j[t], b = s_b[t];
                 const int32_t rid = s_rid[t];
-                if (j) { // where the run before has got to at its last read
+                if (j != j_first) { // where the run before has got to at its last read (the first read of all: the state that came in)
                     uint32_t r2, d2;
                     an_in_run(run, s_bl[t], r2, d2);
                     rel = r2; s = s_bl[t] - d2;
@@ -231,8 +316,9 @@ __global__ __launch_bounds__(256) void k_an_chain(AnchorArgs a)
         uint32_t r2, d2;
         const uint32_t bl = a.cpos[nc - 1];
         an_in_run(run, bl, r2, d2);
-        AnchorState out;
+        AnchorState out = st;
         out.first = 0; out.id = id; out.shift = (int32_t)(bl - d2); out.pad = 0; out.win = st.win + r2;
+        if (st.pending) { out.pending = 0; out.has_prev = 1; out.prev_rid = a.crid[j_first]; out.prev_bp = a.cpos[j_first]; }
         *a.state = out;
         a.sum->after = out;
         a.sum->last_rel = r2;
@@ -245,12 +331,13 @@ __global__ __launch_bounds__(256) void k_an_apply(AnchorArgs a)
     if (a.sum->flags & AN_FLAG_TOO_MANY_BREAKS) return;
     const uint32_t nc = a.sum->n_cand, j = blockIdx.x * 256u + threadIdx.x;
     if (j >= nc) return;
+    const uint32_t i = a.cidx[j], np = a.sum->n_pending;
+    if (j < np) { a.cov_out[i] = CovEntry{BQC_COV_PENDING, j}; return; } // set aside: its place in the batch's pending log
     uint32_t rel, delta;
     an_in_run(a.runs[a.crun[j]], a.cpos[j], rel, delta);
-    const uint32_t i = a.cidx[j];
     a.cov_out[i] = CovEntry{rel, delta};
-    bool boundary = j == 0;
-    if (j) {
+    bool boundary = j == np;
+    if (j != np) {
         uint32_t relp, dp;
         an_in_run(a.runs[a.crun[j - 1]], a.cpos[j - 1], relp, dp);
         boundary = relp != rel;
@@ -262,23 +349,15 @@ __global__ __launch_bounds__(256) void k_an_apply(AnchorArgs a)
     }
 }
 
-__global__ void k_an_init(AnchorSummary* sum)
-{
-    AnchorSummary z{};
-    z.rid_min = INT32_MAX; z.rid_max = -1;
-    *sum = z;
-}
-
 extern "C" void bqc_launch_anchor(const AnchorArgs& a, hipStream_t s)
 {
     const uint32_t nblk = (a.n + 1023u) / 1024u; // (also the grid of the candidates' passes: n_cand <= n is only known on the card)
-    hipLaunchKernelGGL(k_an_init, dim3(1), dim3(1), 0, s, a.sum);
+    if (a.n) hipLaunchKernelGGL(k_an_count, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_a, nblk, a.sum, a.parts, 0); // (starts the summary)
     if (!a.n) { hipLaunchKernelGGL(k_an_chain, dim3(1), dim3(256), 0, s, a); return; }
-    hipLaunchKernelGGL(k_an_count, dim3(nblk), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_a, nblk, &a.sum->n_cand);
     hipLaunchKernelGGL(k_an_scatter, dim3(nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_an_bcount, dim3(nblk), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_b, nblk, &a.sum->n_breaks);
+    hipLaunchKernelGGL(k_an_scan, dim3(1), dim3(1024), 0, s, a.blk_b, nblk, a.sum, a.parts, 1);
     hipLaunchKernelGGL(k_an_bscatter, dim3(nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_an_chain, dim3(1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_an_apply, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);

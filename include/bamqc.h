@@ -223,8 +223,9 @@ int bqc_submit_async(bqc_ctx* ctx, const bqc_batch* batch, uint64_t* ticket);
  *   bqc_anchor_enqueue   queues the anchor kernels and the copy of their summary on `stream` (a hipStream_t on the context's device, on
  *                        which the columns are complete); d_cov: 8 bytes per read of device memory for the anchors, valid — like the
  *                        columns — until the batch's ticket is reported uploaded.  Returns 0 and a handle; 1: not available — the
- *                        context has several read groups, is a shard_tail context, or a batch has gone through bqc_submit* /
- *                        bqc_upload before (the host then keeps the state for the rest of the stream); < 0: -BQC_ERR_*.
+ *                        context has several read groups, or a batch has gone through bqc_submit* / bqc_upload before (the host
+ *                        then keeps the state for the rest of the stream); < 0: -BQC_ERR_*.  (A shard_tail context sets its first
+ *                        reads aside on the card exactly as bqc_submit* does on the host.)
  *   bqc_anchor_complete  after the caller has synchronised `stream`: 0 = anchored; 1 = not anchored (more position breaks in the batch
  *                        than the card's serial chain takes: the card has left its state untouched; this batch and every later one
  *                        go through bqc_submit* with host columns); < 0: -BQC_ERR_* (bqc_anchor_error).  `info` (optional): what a

@@ -187,3 +187,29 @@ def test_usage_errors_are_reported_once_by_the_front_end(inputs):
     rcs, outs = run_ranks(2, ["-r", fa, "-c", "chr1,chr2", "-i", "800", bam, "-o", out], launcher="cxx")
     assert rcs == [0, 0], outs
     assert same(single, out)
+
+
+@pytest.mark.parametrize("world,batch", [(2, "1000000"), (3, "20011")])
+def test_single_read_group_shards_set_aside_on_the_card(tmp_path, world, batch):
+    """ONE read group and the reader on the card: the workers' coverage anchors are made on the card (csrc/k_anchor.hip), also by the workers
+    that start inside the stream — their reads up to the first certain reset (here: the next chromosome, the data has no gaps) are set
+    aside there exactly as the host's pass sets them aside; small batches: the pending phase spans many of them.  Same bytes as the
+    single-process run and as the host's pass (BQC_DEVICE_ANCHORS=0)."""
+    bam, fa = str(tmp_path / "one.bam"), str(tmp_path / "one.fa")
+    hostio.synth_write(bam, fa, seed=78, n_reads=250_000, ref_names=["chr1", "chr2", "chrM"], ref_lens=[2_000_000, 400_000, 20_000], n_lanes=1)
+    single = str(tmp_path / "single.bamqc")
+    r = subprocess.run([EXE, "-r", fa, "-o", single, "-c", "chr1,chr2", bam], capture_output=True, text=True, env=dict(os.environ, BQC_GPU_DECODE="1", BQC_TIMING="1"))
+    assert r.returncode == 0, r.stderr
+    assert " batches anchored on the card" in r.stderr and "[timing] 0 batches anchored" not in r.stderr, r.stderr
+    outs_seen = []
+    for anchors in ("1", "0"):
+        out = str(tmp_path / ("sharded_%s.bamqc" % anchors))
+        rcs, outs = run_ranks(world, ["-r", fa, "-o", out, "-c", "chr1,chr2", "--batch-reads", batch, bam],
+                              env_extra={"BQC_GPU_DECODE": "1", "BQC_TIMING": "1", "BQC_DEVICE_ANCHORS": anchors}, launcher="cxx")
+        assert rcs == [0] * world, outs
+        assert same(single, out)
+        outs_seen.append(outs[0])
+    import re
+    counts = [int(x) for x in re.findall(r"\[timing\] (\d+) batches anchored on the card", outs_seen[0])]
+    assert len(counts) == world and all(c > 0 for c in counts), outs_seen[0]  # every worker, the ones in the middle of the stream too
+    assert all(int(x) == 0 for x in re.findall(r"\[timing\] (\d+) batches anchored on the card", outs_seen[1]))
