@@ -102,6 +102,7 @@ struct Slot { // one batch in flight through bqc_submit / bqc_submit_async
     ErrRec* h_err = nullptr;  // page-locked copy of the batch's error record (written by a D2H copy behind its last kernel)
     hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
     bool busy = false;
+    bool in_place = false;    // the batch's columns are read where the caller has them (bqc_submit_anchored): bqc_batch_uploaded waits for ev_done
     uint64_t ticket = 0;
 };
 

@@ -353,7 +353,9 @@ struct Carver {
 }
 
 // carve m.dmem (allocating / growing it) for a batch of the given sizes and fill in the DevBatch / PrepArgs pointers
-static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostPass& H, bool from_pool)
+// in_place (an anchored batch: every column and the anchors live in the caller's device memory until the batch's kernels are through):
+// the image holds no copy of them — the kernels read them where they are (250 MB per million reads that used to be copied once more)
+static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostPass& H, bool from_pool, const CovEntry* in_place = nullptr)
 {
     const uint64_t n = H.n;
     const uint32_t nl = c->opt.n_lanes;
@@ -361,9 +363,9 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
     cv.take(256);
     m.h2d_begin = cv.off;
     const size_t cb[13] = {2 * n, n, n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * n, 2 * n, H.seq_bytes, H.qual_bytes, 4 * H.cigar_words};
-    for (int k = 0; k < 13; ++k) { m.col_bytes[k] = cb[k]; m.o_col[k] = cv.take(cb[k] + (k >= 10 ? 512 : 0)); }
+    for (int k = 0; k < 13; ++k) { m.col_bytes[k] = in_place ? 0 : cb[k]; m.o_col[k] = cv.take(in_place ? 0 : cb[k] + (k >= 10 ? 512 : 0)); }
     m.o_xr = cv.take(4ull * b->n_nm_extra); m.o_xv = cv.take(4ull * b->n_nm_extra);
-    m.o_cov_in = cv.take(sizeof(CovEntry) * n);
+    m.o_cov_in = cv.take(in_place ? 0 : sizeof(CovEntry) * n);
     m.o_order = cv.take(H.multi_lane ? 4 * n : 0);
     m.o_sws = cv.take(sizeof(SuperWindow) * H.sws.size());
     m.o_stretch = cv.take(sizeof(Stretch) * H.stretches.size());
@@ -445,6 +447,12 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
     m.d_err = p.err;
     m.algo_bytes = 48ull * n + H.seq_bytes + H.qual_bytes + 4 * H.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
     m.n_slow = H.n_slow; m.max_len_slow = H.max_len_slow; m.n_chunks_slow_ub = (uint32_t)cs_cap; m.t8_lane = H.t8_lane;
+    if (in_place) { // the columns where the caller has them
+        d.mapq = b->mapq; d.lane = b->lane; d.rid = b->rid; d.pos = b->pos; d.tlen = b->tlen; d.nm = b->nm; d.as_ = b->as; d.l_seq = b->l_seq; d.n_cigar = b->n_cigar;
+        d.seq = b->seq; d.qual = b->qual; d.cigar = b->cigar;
+        p.flag_in = b->flag; p.mapq = d.mapq; p.lane = d.lane; p.rid = d.rid; p.pos = d.pos; p.as_ = d.as_; p.l_seq = d.l_seq; p.n_cigar = d.n_cigar; p.qual = d.qual; p.cigar = d.cigar;
+        p.cov_in = in_place;
+    }
     m.processed = false;
     return 0;
 }
@@ -683,7 +691,10 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
     HostPass& H = c->hp;
     if ((rc = anchored ? host_pass_anchored(c, b->n_reads, anchored, H) : host_pass(c, b, H))) return poison(c, rc);
     const double t_pass = secs_since(t0) - t_wait;
-    if ((rc = layout_batch(c, s.m, b, H, false))) return poison(c, rc);
+    static const bool copy_anyway = getenv("BQC_ANCHORED_COPY") && getenv("BQC_ANCHORED_COPY")[0] == '1'; // (A/B: the columns copied into the image as bqc_submit_async does)
+    const bool in_place = anchored && !copy_anyway;
+    if ((rc = layout_batch(c, s.m, b, H, false, in_place ? anchored->d_cov : nullptr))) return poison(c, rc);
+    s.in_place = in_place;
     BatchMem& m = s.m;
     if (H.n_pending) { // shard mode: the covered runs of the reads set aside stay on the device until bqc_shard_resolve
         PendBatch& pb = c->shard.batches.back();
@@ -726,7 +737,8 @@ static int submit_impl(bqc_ctx* c, const bqc_batch* b, bool pinned_columns, uint
             }
         });
     }
-    if (anchored) { // the anchors are on the card already (the caller's buffer): the image's tables in front of and behind their place
+    // (an anchored batch: columns and anchors stay where the caller has them — the image is the host pass's small tables)
+    if (anchored && !in_place) { // BQC_ANCHORED_COPY=1: the anchors into their place in the image, the tables in front of and behind it
         const size_t n_cov = sizeof(CovEntry) * (size_t)b->n_reads, o_behind = m.o_cov_in + ((n_cov + 255) & ~(size_t)255);
         if (he == hipSuccess && m.o_cov_in > img_begin) he = hipMemcpyAsync(base + img_begin, s.hmem, m.o_cov_in - img_begin, hipMemcpyHostToDevice, c->copy_stream);
         if (he == hipSuccess && n_cov) he = hipMemcpyAsync(base + m.o_cov_in, anchored->d_cov, n_cov, hipMemcpyDeviceToDevice, c->copy_stream);
@@ -904,8 +916,10 @@ extern "C" int bqc_batch_uploaded(bqc_ctx* c, uint64_t ticket, int wait)
     if (ticket == 0 || ticket >= c->next_ticket) return 1;
     Slot& s = c->slots[ticket % bqc_ctx::kSlots];
     if (!s.busy || s.ticket != ticket) return 1; // retired (or overwritten by a later batch, which waited for it)
-    if (wait) return hipEventSynchronize(s.ev_h2d) == hipSuccess ? 1 : -BQC_ERR_DEVICE;
-    const hipError_t q = hipEventQuery(s.ev_h2d);
+    // (a batch whose columns are read in place — bqc_submit_anchored — is done with them when its kernels are)
+    hipEvent_t ev = s.in_place ? s.ev_done : s.ev_h2d;
+    if (wait) return hipEventSynchronize(ev) == hipSuccess ? 1 : -BQC_ERR_DEVICE;
+    const hipError_t q = hipEventQuery(ev);
     return q == hipSuccess ? 1 : q == hipErrorNotReady ? 0 : -BQC_ERR_DEVICE;
 }
 

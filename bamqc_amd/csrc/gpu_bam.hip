@@ -142,6 +142,106 @@ __global__ __launch_bounds__(64) void k_gb_walk(const uint8_t* __restrict__ base
     segs[s] = S;
 }
 
+// The same walk by a WAVE per segment (round 4; BQC_GB_WALK=lane: the kernel above).  With a lane per segment a batch's window is 280 waves
+// on 1024 SIMDs, and a lane's 60 records are 60 dependent loads from lines nobody has touched (~2 us each under the inflate kernels'
+// traffic) behind ~135 serial plausibility tests: 0.26-0.37 ms per launch, 9 % of a run's GPU time.  Here the wave first brings its
+// segment (and 192 bytes beyond it: the header of a record that starts at its very end) into LDS with ONE round of coalesced 16-byte
+// loads; the guess tests 64 candidate starts at a time (ballot: the first one that holds), and the chain reads a record's header
+// from LDS — every lane the same addresses, a broadcast — ~150 clocks per record instead of a memory latency.  What lies beyond the
+// staged bytes (the records a plausibility test follows past the segment's end) is read from memory as before.  Same results, field
+// for field: tests/test_gpu_reader.py compares both with the host reader's walk.
+#define GBW_STAGE (GB_SEG + 192u)
+namespace {
+struct GbwView {
+    const uint32_t* buf;   // LDS copy of base[a, a + staged)
+    const uint8_t* base;
+    uint64_t a, staged;
+    // four bytes at window offset p (unaligned): from the staged copy when they lie inside it (two aligned words, v_alignbyte)
+    __device__ __forceinline__ uint32_t u32(uint64_t p) const
+    {
+        if (p >= a && p + 4 <= a + staged) {
+            const uint32_t r = (uint32_t)(p - a), w = r >> 2, sh = r & 3u;
+            const uint32_t lo = buf[w], hi = buf[w + 1]; // (buf has a spare word behind the staged bytes)
+            return sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
+        }
+        return ld32(base + p);
+    }
+    __device__ __forceinline__ uint32_t u8(uint64_t p) const { return p >= a && p < a + staged ? (buf[(uint32_t)(p - a) >> 2] >> (8u * ((uint32_t)(p - a) & 3u))) & 255u : base[p]; }
+};
+// gb_plausible over a view
+__device__ __forceinline__ bool gbw_plausible(const GbwView& V, uint64_t avail, uint64_t p, int32_t n_ref, uint64_t& next)
+{
+    if (p + 36 > avail) return false;
+    const uint32_t bs = V.u32(p);
+    if (bs < 32u || bs > (1u << 28)) return false;
+    const int32_t rid = (int32_t)V.u32(p + 4), pos = (int32_t)V.u32(p + 8), rnext = (int32_t)V.u32(p + 24), pnext = (int32_t)V.u32(p + 28);
+    if (rid < -1 || rid >= n_ref || rnext < -1 || rnext >= n_ref || pos < -1 || pnext < -1) return false;
+    const uint32_t w12 = V.u32(p + 12), l_name = w12 & 255u, n_cig = V.u32(p + 16) & 0xFFFFu, l_seq = V.u32(p + 20);
+    if (l_name == 0 || l_seq > (1u << 28)) return false;
+    const uint64_t var = 32ull + l_name + 4ull * n_cig + (l_seq + 1u) / 2u + l_seq;
+    if (var > bs) return false;
+    if (p + 4 + 32 + l_name <= avail && V.u8(p + 4 + 32 + l_name - 1) != 0) return false; // read name is NUL-terminated
+    next = p + 4 + bs;
+    return true;
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void k_gb_walk_wave(const uint8_t* __restrict__ base, uint64_t avail, uint32_t seg0, uint32_t nseg, uint64_t exact, uint64_t limit, int32_t n_ref,
+                                                      GbSeg* __restrict__ segs, GbRec* __restrict__ recs)
+{
+    __shared__ uint32_t buf[GBW_STAGE / 4 + 4];
+    const uint32_t s = seg0 + blockIdx.x, lane = threadIdx.x;
+    if (s >= seg0 + nseg) return;
+    const uint64_t a = (uint64_t)s * GB_SEG, b = min(avail, a + GB_SEG);
+    const uint64_t staged = min(avail - a, (uint64_t)GBW_STAGE) & ~(uint64_t)3; // whole words (a tail of 1-3 bytes at the window's end is read from memory)
+    for (uint32_t off = lane * 16u; off < (uint32_t)staged; off += 1024u) {
+        if (off + 16u <= (uint32_t)staged) {
+            const gb_u32x4 v = *(const gb_u32x4_u*)(base + a + off);
+            buf[off / 4] = v.x; buf[off / 4 + 1] = v.y; buf[off / 4 + 2] = v.z; buf[off / 4 + 3] = v.w;
+        } else for (uint32_t k = off; k < (uint32_t)staged; k += 4u) buf[k / 4] = ld32(base + a + k);
+    }
+    if (lane == 0) buf[staged / 4] = 0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __syncthreads();
+    const GbwView V{buf, base, a, staged};
+    GbSeg S{};
+    const bool known = s == seg0 && exact != UINT64_MAX;
+    uint64_t p = known ? exact : a;
+    if (!known) { // 64 candidate starts at a time: the first at which three records in a row look like records
+        const uint64_t stop = min(b, limit);
+        bool found = false;
+        for (uint64_t r0 = a; r0 < stop && !found; r0 += 64u) {
+            const uint64_t c = r0 + lane;
+            uint64_t q1, q2, q3;
+            const bool ok = c < stop && gbw_plausible(V, avail, c, n_ref, q1) && gbw_plausible(V, avail, q1, n_ref, q2) && gbw_plausible(V, avail, q2, n_ref, q3);
+            const uint64_t m = __ballot(ok);
+            if (m) { p = r0 + (uint64_t)(__ffsll((unsigned long long)m) - 1); found = true; }
+        }
+        if (!found) { if (lane == 0) { S.first = S.exit = 0xFFFFFFFFu; S.flags = GB_NO_START; segs[s] = S; } return; }
+    }
+    S.first = (uint32_t)p;
+    GbRec* out = recs + (size_t)s * GB_MAXR;
+    uint32_t so = 0, qo = 0, co = 0, n = 0;
+    while (p < b && p < limit) { // (every lane the same record: the header's words are broadcast reads)
+        if (p + 36 > avail) { S.flags |= GB_INCOMPLETE; break; }
+        const uint32_t bs = V.u32(p);
+        if (bs < 32u) { S.flags |= GB_CORRUPT; break; }
+        const uint32_t l_name = V.u32(p + 12) & 255u, n_cig = V.u32(p + 16) & 0xFFFFu, l_seq = V.u32(p + 20);
+        const uint64_t var = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1u) / 2u + l_seq;
+        if (var > bs) { S.flags |= GB_CORRUPT; break; }
+        if (p + 4 + bs > avail) { S.flags |= GB_INCOMPLETE; break; }
+        if (lane == 0) out[n] = GbRec{(uint32_t)p, so, qo, co};
+        so += (l_seq + 1u) / 2u; qo += l_seq; co += n_cig;
+        ++n;
+        p += 4ull + bs;
+    }
+    if (lane == 0) {
+        S.exit = (uint32_t)min(p, (uint64_t)0xFFFFFFFEu);
+        S.count = n; S.seq_bytes = so; S.qual_bytes = qo; S.cigar_words = co;
+        segs[s] = S;
+    }
+}
+
 // workgroup per taken segment, thread per record: the fixed columns and the tag scan of host/bam_io.cpp
 __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ base, const GbSeg* __restrict__ segs, const GbRec* __restrict__ recs,
                                                    const GbBase* __restrict__ bases, GbCols C, GbLanes LN, const uint8_t* __restrict__ main_chrom, uint32_t n_main,
@@ -587,7 +687,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (!ok) { err = "GPU reader: out of device memory"; return false; }
         const size_t typical = std::min<size_t>(reads * 400, batch_bases / 2 * 3 + reads * 40 + (64u << 20)) + (1u << 20);
         const double t_c = now_s();
-        g_pool.fill(typical, 6);
+        g_pool.fill(typical, 10); // (a batch's buffer comes back when its kernels are through: three in the pipeline, three queued, the decoder's, spares)
         buffers_allocated = true; // (the caller creates its context from here on: side by side with these allocations the two were measured to hold each other up)
         if (I.timing) fprintf(stderr, "[gpu reader] open: run buffers %.1f, walk buffers %.1f, batch pool %.1f ms\n", (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (now_s() - t_c) * 1e3);
     }
@@ -993,7 +1093,9 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         const uint32_t nseg = (uint32_t)((std::min<uint64_t>(avail, limit == UINT64_MAX ? avail : limit + 1) + GB_SEG - 1) / GB_SEG);
         const size_t seg_cap = nseg; // (sized in open() for a batch's worth of the window: grows only for unusual records)
         if (!I.d_seg.need(seg_cap) || !I.h_seg.need(seg_cap) || !I.d_rec.need(seg_cap * GB_MAXR) || !I.d_base.need(seg_cap) || !I.h_base.need(seg_cap)) return fail_dev("out of device memory");
-        hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, I.need_locate ? UINT64_MAX : (uint64_t)0, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
+        static const bool walk_by_lanes = getenv("BQC_GB_WALK") && !strcmp(getenv("BQC_GB_WALK"), "lane"); // (the round-3 kernel: a lane per segment)
+        if (walk_by_lanes) hipLaunchKernelGGL(k_gb_walk, dim3((nseg + 63) / 64), dim3(64), 0, I.s, base, avail, 0u, nseg, I.need_locate ? UINT64_MAX : (uint64_t)0, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
+        else hipLaunchKernelGGL(k_gb_walk_wave, dim3(nseg), dim3(64), 0, I.s, base, avail, 0u, nseg, I.need_locate ? UINT64_MAX : (uint64_t)0, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
         if (hipMemcpyAsync(I.h_seg.p, I.d_seg.p, (size_t)nseg * sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
         // the chain, segment by segment; whole segments are taken while the batch has room
         uint64_t pos = 0, n = 0, bases = 0, so = 0, qo = 0, co = 0;
@@ -1030,7 +1132,8 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
             GbSeg& S = I.h_seg.p[s];
             if ((S.flags & GB_NO_START) || S.first != pos) { // the guess is not where the chain arrives (or there was none): this segment again, from there
                 ++I.n_rewalk;
-                hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
+                if (walk_by_lanes) hipLaunchKernelGGL(k_gb_walk, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
+                else hipLaunchKernelGGL(k_gb_walk_wave, dim3(1), dim3(64), 0, I.s, base, avail, s, 1u, pos, limit, I.n_ref, I.d_seg.p, I.d_rec.p);
                 if (hipMemcpyAsync(&S, I.d_seg.p + s, sizeof(GbSeg), hipMemcpyDeviceToHost, I.s) != hipSuccess || !I.sync()) return fail_dev("walk failed");
                 if (S.first != pos) return unsupported("the record walk could not be verified");
             }
@@ -1066,7 +1169,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         // the batch's own buffer on the device: [seq][qual][cigar] (512 spare bytes behind each: the kernels' vector loads), then the fixed
         // columns [rid pos tlen nm as l_seq](4 B) [flag n_cigar](2 B) [mapq lane](1 B) and 8 bytes per read for the coverage anchors — a
         // batch that is anchored on the card (bqc_anchor_*) is submitted from here without its columns ever visiting the host
-        const size_t o_seq = 0, o_qual = (so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255),
+        const size_t o_seq = 512, o_qual = (o_seq + so + 512 + 255) & ~(size_t)255, o_cig = o_qual + ((qo + 512 + 255) & ~(size_t)255),
                      o_fix = (o_cig + 4 * co + 512 + 255) & ~(size_t)255, o_cov = o_fix + Np * (6 * 4 + 2 * 2 + 2), total = o_cov + 8 * Np + 256;
         if (o.dev_cap < total) {
             if (o.dev_mem) dev_free_hook(o.dev_mem);

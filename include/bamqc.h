@@ -231,6 +231,10 @@ int bqc_submit_async(bqc_ctx* ctx, const bqc_batch* batch, uint64_t* ticket);
  *                        go through bqc_submit* with host columns); < 0: -BQC_ERR_* (bqc_anchor_error).  `info` (optional): what a
  *                        program wants to know about a batch whose columns it does not have.
  *   bqc_submit_anchored  the batch into the pipeline as bqc_submit_async does (every column of `batch` a device pointer); consumes the handle.
+ *                        The kernels read the columns IN PLACE (no copy into the pipeline's own buffers): they and d_cov must stay
+ *                        untouched until bqc_batch_uploaded(ticket) says 1, which for such a batch means "its kernels are through";
+ *                        at least 512 bytes of the same allocation must lie in front of and behind each of seq, qual and cigar (the
+ *                        kernels' vector loads run over the ends).
  * Batches must be anchored in stream order and submitted in the same order; the anchor calls may be made by another thread than the
  * submit calls (the program's decode thread and its submitting thread). */
 typedef struct bqc_anchored bqc_anchored;

@@ -19,15 +19,17 @@ class Hip:
         self.rt.hipFree.argtypes = [C.c_void_p]
         self.bufs = []
 
-    def put(self, arr, extra=0):
+    def put(self, arr, extra=0, front=0):
+        """the array in device memory, `front` zero bytes of the same allocation before it and `extra` (+ 256) behind it"""
         arr = np.ascontiguousarray(arr)
         p = C.c_void_p()
-        assert self.rt.hipMalloc(C.byref(p), arr.nbytes + extra + 256) == 0
-        assert self.rt.hipMemset(p, 0, arr.nbytes + extra + 256) == 0
+        assert self.rt.hipMalloc(C.byref(p), front + arr.nbytes + extra + 256) == 0
+        assert self.rt.hipMemset(p, 0, front + arr.nbytes + extra + 256) == 0
+        q = C.c_void_p(p.value + front)
         if arr.nbytes:
-            assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+            assert self.rt.hipMemcpy(q, arr.ctypes.data, arr.nbytes, 1) == 0
         self.bufs.append(p)
-        return p
+        return q
 
     def get(self, p, nbytes, dtype=np.uint8):
         out = np.zeros(nbytes, np.uint8)

@@ -44,7 +44,7 @@ def device_batch(hip, cols):
     n = len(cols["flag"])
     b.n_reads = n
     for name, dt, pt in _abi._BATCH_COLS:
-        setattr(b, name, C.cast(hip.put(keep[name], extra=1024), pt))
+        setattr(b, name, C.cast(hip.put(keep[name], extra=1024, front=1024), pt))  # (read in place: the kernels' vector loads run over both ends)
     return b, hip.put(np.zeros(2 * max(n, 1), np.uint32))
 
 
