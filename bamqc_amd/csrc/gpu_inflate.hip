@@ -788,7 +788,8 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
             const uint32_t d = 32u * w + (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
             if (d + 3u > usize) continue;
-            const uint32_t tok = (uint32_t)o0[d] | ((uint32_t)o0[d + 1u] << 8) | ((uint32_t)o0[d + 2u] << 16); // phase 1 left the match's description in its first bytes
+            // phase 1 left the match's description in its first three bytes: one load of four where the block has them (three byte loads per match before)
+            const uint32_t tok = d + 4u <= usize ? *(const gi_u32_u*)(o0 + d) & 0xFFFFFFu : (uint32_t)o0[d] | ((uint32_t)o0[d + 1u] << 8) | ((uint32_t)o0[d + 2u] << 16);
             const uint32_t dist = (tok & 0x7FFFu) + 1u, len = (tok >> 16) + 3u;
             if (dist > d || d + len > usize) continue; // (phase 1 has checked it; damaged memory must not reach outside)
             for (uint32_t j = 0; j < len; ++j) ridx[d + j] = (uint16_t)(d + j - dist);
@@ -952,10 +953,12 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
     static unsigned long long* d_stats = nullptr; // (BQC_GI_STATS: blocks resolved, chunks, rounds, matches, matched bytes, distances < 8, lengths > 32, tokens — printed at exit)
     static const bool want_stats = [] {
         if (!getenv("BQC_GI_STATS")) return false;
-        if (hipMalloc((void**)&d_stats, 128) != hipSuccess || hipMemset(d_stats, 0, 128) != hipSuccess) { d_stats = nullptr; return false; }
+        if (hipMalloc((void**)&d_stats, 256) != hipSuccess || hipMemset(d_stats, 0, 256) != hipSuccess) { d_stats = nullptr; return false; }
         atexit([] {
-            unsigned long long h[16] = {};
-            if (hipMemcpy(h, d_stats, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long h[32] = {};
+            if (hipMemcpy(h, d_stats, 256, hipMemcpyDeviceToHost) == hipSuccess) {
+                if (h[4]) fprintf(stderr, "[gpu inflate] header clocks per deflate block: block header (lane 0) %.0f, code-length code built %.0f, code lengths (lane 0) %.0f, distance code built %.0f, literal/length code built %.0f\n",
+                                  (double)h[16] / h[4], (double)h[17] / h[4], (double)h[18] / h[4], (double)h[19] / h[4], (double)h[20] / h[4]);
                 fprintf(stderr, "[gpu inflate] resolve clocks per block: set-up %.0f, matches listed %.0f, pointer jumping %.0f, gather %.0f\n", (double)h[8] / (h[0] ? h[0] : 1),
                         (double)h[9] / (h[0] ? h[0] : 1), (double)h[10] / (h[0] ? h[0] : 1), (double)h[11] / (h[0] ? h[0] : 1));
                 fprintf(stderr, "[gpu inflate] clock64 ticks per wall_clock64 tick (100 MHz): %.2f\n", (double)(h[8] + h[9] + h[10] + h[11]) / (h[12] ? h[12] : 1));

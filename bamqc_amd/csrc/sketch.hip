@@ -72,7 +72,8 @@ struct PairParams { // one (q, k) sketch
     int32_t q_thr;      // (signed char)(33 + q): base valid iff (signed char)(phred + 33) >= q_thr
     uint32_t f2_mask;   // F2size - 1
     uint32_t ctr_mask;  // size*16 - 1
-    uint32_t levels;    // MAX_TABLE = 32
+    uint32_t levels;    // MAX_TABLE = 32 (k_sketch counts on it: a level index is five bits)
+    uint32_t ctr_shift; // log2(ctr_per_level)
     uint64_t ctr_per_level;
 };
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
     const uint32_t lo_r = blockIdx.x * per_block, hi_r = min(b.n_reads, lo_r + per_block); // positions of the processing order (reads grouped by read group)
     uint32_t blane = 0xFFFFFFFFu;
     uint32_t& s_lane = lm[63]; // (no static __shared__: it would mis-align the dynamic LDS base)
-    uint64_t sat_mask = 0;
+    uint32_t sat_mask = 0; // (32 levels)
     for (uint32_t base = lo_r; base < hi_r; base += blockDim.x) {
         const uint32_t kk = base + threadIdx.x;
         bool live = kk < hi_r;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                 if (threadIdx.x < 33) { const uint32_t v = lm[threadIdx.x]; if (v) { gadd(D.misc + (threadIdx.x == 32 ? 0 : 1 + threadIdx.x), v); lm[threadIdx.x] = 0; } }
             }
             blane = fl;
-            sat_mask = dsk[blane * n_pairs + pair].misc[40];
+            sat_mask = (uint32_t)dsk[blane * n_pairs + pair].misc[40];
             block_sync();
         }
         const DevSketch D = dsk[lane * n_pairs + pair];
@@ -242,10 +243,30 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                     outs = kr == 0 ? lo : (hi << (64u - 4u * kr)) | (lo >> (4u * kr));
                 }
                 const uint32_t nb = min(16u, L - cb);
+                // Which of the chunk's 16 positions restart the k-mer ('N', or (signed char)(phred + 33) below the threshold:
+                // ReadQualityHasher.hpp:61-66) — for all 16 at once (round 4; a field extract, an add, a sign extension and two compares per
+                // base before): the nibbles that are 15 by two AND-shifts, the qualities byte-wise in four dwords — v = phred + 33 mod 256
+                // without a carry between the bytes, valid iff bit 7 of v is clear and its low seven bits reach the threshold (1..127; other
+                // thresholds: the compares, below).  A step then tests one bit of each.
+                uint64_t nmask; // position jj: bit 60 - 4 jj
+                { const uint64_t y = ns & (ns >> 1); nmask = y & (y >> 2) & 0x1111111111111111ull; }
+                const bool q_swar = P.q_thr >= 1 && P.q_thr <= 127;
+                uint64_t qbad_lo = 0, qbad_hi = 0; // position jj: bit 8 (jj & 7) + 7 of the half it lies in
+                if (q_swar) {
+                    const uint64_t add = 0x0101010101010101ull * (uint64_t)(0x80u - (uint32_t)P.q_thr);
+                    auto bad8 = [&](uint64_t w) {
+                        const uint64_t v = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x2121212121212121ull) ^ (w & 0x8080808080808080ull);
+                        const uint64_t tt = (v & 0x7F7F7F7F7F7F7F7Full) + add; // bit 7 of a byte: its low seven bits reach the threshold
+                        return ~(tt & ~v) & 0x8080808080808080ull;
+                    };
+                    qbad_lo = bad8(qlo); qbad_hi = bad8(qhi);
+                }
                 auto step = [&](const uint32_t jj) __attribute__((always_inline)) {
                     const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
-                    const int32_t qc = (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u);
-                    if (nib == 15u || qc < P.q_thr) { t = 0; return; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
+                    bool restart = (nmask >> (60 - 4 * jj)) & 1ull;
+                    if (q_swar) restart |= (((jj < 8 ? qbad_lo : qbad_hi) >> (8 * (jj & 7) + 7)) & 1ull) != 0;
+                    else restart |= (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u) < P.q_thr;
+                    if (restart) { t = 0; return; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
                     if (t == 0) { hh = hl = th = tl = 0; }
                     // RepHash::init built incrementally (:85-97) and RepHash::update(out, in) (:99-113) as one step: nothing
                     // leaves the k-mer while it is still filling
@@ -262,13 +283,14 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                     ++n_hash;
                     if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
                     else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
-                    uint32_t w = hash ? (uint32_t)__ffsll((unsigned long long)hash) - 1u : 63u; // bitScanForward (lsb.cpp:26-29)
-                    if (w >= P.levels) w = P.levels - 1;
-                    if (mine && ((sat_mask >> w) & 1ull)) return; // M[w] == size*countsPerLong*maxVal: every counter is 15
-                    const uint64_t index = (hash >> (w + 1)) & (uint64_t)P.ctr_mask;
+                    // bitScanForward (lsb.cpp:26-29), clamped to the last of the 32 levels: the lowest set bit of the hash's low word, 31
+                    // when that word is zero (__ffs(0) - 1 wraps to 0xFFFFFFFF)
+                    const uint32_t w = min((uint32_t)__ffs((int)(uint32_t)hash) - 1u, 31u);
+                    if (mine && ((sat_mask >> w) & 1u)) return; // M[w] == size*countsPerLong*maxVal: every counter is 15
+                    const uint32_t index = (uint32_t)(hash >> (w + 1u)) & P.ctr_mask;
                     // fire and forget: the counter's value is min(15, raw); k_sketch_levels clamps the raw counts after every
                     // batch and finds the levels in which every counter has reached 15
-                    atomicAdd(D.counters + (uint64_t)w * P.ctr_per_level + index, 1u);
+                    atomicAdd(D.counters + ((w << P.ctr_shift) + index), 1u); // (32 levels x ctr_per_level counters: far below 2^32)
                 };
 #pragma unroll
                 for (uint32_t jj = 0; jj < 16u; ++jj) // unrolled: the nibble / quality / leaving-base extractions get constant shifts
@@ -384,6 +406,8 @@ SketchDevice* sketch_create(const bqc_sketch_options& so, uint32_t n_lanes, hipS
             P.q_thr = (int32_t)(int8_t)(uint8_t)(33u + P.q);
             P.f2_mask = (uint32_t)sk->f2size - 1; P.ctr_mask = (uint32_t)sk->ctr_per_level - 1; P.levels = 32;
             P.ctr_per_level = sk->ctr_per_level;
+            P.ctr_shift = 0;
+            while (((size_t)1 << P.ctr_shift) < sk->ctr_per_level) ++P.ctr_shift; // (a power of two: round_up_pow2 above)
             sk->pp.push_back(P);
             for (int i = 0; i < 32; ++i) {
                 hv[p * 128 + 2 * i] = base[i].hi; hv[p * 128 + 2 * i + 1] = base[i].lo;
