@@ -45,7 +45,9 @@ public:
     // shard in the middle of a stream, no batch handed over to the host decoder so far).  Without it: columns on the host, as ever.
     void set_anchor_context(bqc_ctx* ctx) { anchor_ctx_ = ctx; }
     uint64_t batches_anchored() const { return n_anchored_; }
-    double seconds_reading() const { return t_read_; } // time spent in fread
+    double seconds_reading() const { return t_read_; } // time spent in pread, summed over the reader threads
+    double seconds_waiting_for_runs() const { return t_wait_run_; } // time the consumer waited for the next inflated run (file, copy or inflate behind)
+    double seconds_producer_waiting_for_chunks() const { return t_wait_chunk_; } // time the producer waited for the ring's reader threads
     // set by open() once its device buffers are allocated (also when it fails before that): a caller that creates its own device
     // context in another thread starts doing so from here on
     std::atomic<bool> buffers_allocated{false};
@@ -58,7 +60,7 @@ private:
     uint64_t nrec_ = 0, n_handed_over_ = 0, n_anchored_ = 0;
     std::atomic<bqc_ctx*> anchor_ctx_{nullptr};
     bool anchors_ok_ = true; // (decode thread)
-    double t_read_ = 0;
+    double t_read_ = 0, t_wait_run_ = 0, t_wait_chunk_ = 0;
     bool ranged_ = false;
     uint64_t range_b0_ = 0, range_b1_ = UINT64_MAX, range_first_ = 0, range_over_ = 0;
 };

@@ -486,7 +486,11 @@ struct GbRun {
 struct GpuBamReader::Impl {
     int device = 0;
     hipStream_t s = nullptr;    // the consumer's: walk, decode, copies
-    hipStream_t ps = nullptr;   // the producer's: copies and inflate kernels of every run
+    hipStream_t ps = nullptr;   // the producer's: inflate kernels of every run (and the first run's copy)
+    hipStream_t cs = nullptr;   // the producer's copies from the second run on (made when that run starts: off the start-up's path).  On ONE stream the
+                                // chunks of run k + 1 queued behind the inflate kernels of run k (17 ms of copies behind 25-37 ms of kernels per 832 MB run),
+                                // their slots came back late and the reader threads stood still: on the 53.6 GB file the producer waited 2.4 s of a 3.1 s
+                                // loop for chunks (profiles/r4_config3_file.json, BQC_GB_COPY_STREAM=0)
     hipEvent_t ev = nullptr;    // blocking
     int fd = -1;                // the file (pread from several threads)
     uint64_t skip_u = 0;        // uncompressed bytes in front of the first record, still to be dropped
@@ -529,6 +533,7 @@ struct GpuBamReader::Impl {
     int32_t n_ref = 0;
     bool timing = false;
     double t_read = 0, t_wait_run = 0;
+    std::atomic<double> t_wait_chunk{0}; // (producer thread writes, consumer reads)
     uint64_t n_rewalk = 0;
     raw_vector<uint8_t> handover_raw;      // a batch the host decoder takes: its bytes
     std::vector<BamRec> handover_recs;
@@ -544,6 +549,7 @@ struct GpuBamReader::Impl {
         if (producer.joinable()) producer.join();
         for (std::thread& t : readers) if (t.joinable()) t.join();
         (void)hipSetDevice(device);
+        if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
         if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
         if (ring_alloc.joinable()) ring_alloc.join();
         for (Slot& C : slots) { if (C.done) (void)hipEventDestroy(C.done); if (C.p) { if (C.registered) (void)hipHostUnregister(C.p); free(C.p); } }
@@ -584,9 +590,10 @@ struct GpuBamReader::Impl {
     // chunk's bytes, so that a block is always contiguous.
     struct Slot { uint8_t* p = nullptr; size_t len = 0; uint64_t index = UINT64_MAX; bool filled = false, used = false, registered = false; hipEvent_t done = nullptr; };
     std::thread ring_alloc; // allocates and touches the ring's chunks while the runtime starts (they are page-locked afterwards: hipHostRegister)
-    static const int kSlots = 6, kReaders = 3;
+    static const int kMaxSlots = 16;
+    int kSlots = 6, kReaders = 3; // (BQC_GB_READERS=N: N reader threads and 2 N chunks, N <= 8)
     static constexpr size_t kHeadroom = 1u << 17;
-    Slot slots[kSlots];
+    Slot slots[kMaxSlots];
     size_t chunk_bytes = 16u << 20; // (six of them are page-locked in open(): 16 ms; with 8 MB chunks the loop of a 54 GB file was 0.2 s longer)
     std::vector<std::thread> readers;
     std::mutex rm;
@@ -633,6 +640,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     I.device = device;
     I.timing = getenv("BQC_GB_TIMING") != nullptr;
     if (const char* e = getenv("BQC_GB_RUN_MB")) I.run_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char* e = getenv("BQC_GB_READERS")) { I.kReaders = std::min(8, std::max(1, atoi(e))); I.kSlots = 2 * I.kReaders; }
     if (const char* e = getenv("BQC_GB_MAX_RUN_OUT_MB")) I.kMaxRunOut = (size_t)std::max(1, atoi(e)) << 20;
     I.fd = ::open(path, O_RDONLY);
     if (I.fd < 0) { err = std::string("could not open ") + path; return false; }
@@ -657,7 +665,8 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     // tools/micro/startup_probe.cpp: hipHostMalloc of 6 x 16 MB 17-26 ms; touching them 18 ms — hidden behind the runtime's start — and
     // hipHostRegister 3-4 ms)
     I.ring_alloc = std::thread([&I] {
-        for (Impl::Slot& C : I.slots) {
+        for (int k_ = 0; k_ < I.kSlots; ++k_) {
+            Impl::Slot& C = I.slots[k_];
             const size_t bytes = (Impl::kHeadroom + I.chunk_bytes + 64 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
             C.p = (uint8_t*)aligned_alloc((size_t)2 << 20, bytes);
             if (C.p) memset(C.p, 0, bytes);
@@ -709,12 +718,13 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     }
     const double t_s2 = now_s();
     I.ring_alloc.join();
-    for (Impl::Slot& C : I.slots) {
+    for (int k_ = 0; k_ < I.kSlots; ++k_) {
+        Impl::Slot& C = I.slots[k_];
         if (he == hipSuccess && !C.p) he = hipErrorOutOfMemory;
         if (he == hipSuccess) { he = hipHostRegister(C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostRegisterDefault); C.registered = he == hipSuccess; }
         if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
     }
-    for (int t = 0; t < Impl::kReaders; ++t) I.readers.emplace_back([&I] { I.reader_loop(); }); // (they wait for the first run to be parsed)
+    for (int t = 0; t < I.kReaders; ++t) I.readers.emplace_back([&I] { I.reader_loop(); }); // (they wait for the first run to be parsed)
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
     if (!I.upload_lanes(hdr)) { err = "GPU reader: out of device memory"; return false; }
     { std::lock_guard<std::mutex> lk(I.m); I.dev_ready = true; }
@@ -840,8 +850,10 @@ void GpuBamReader::Impl::reader_loop()
 GpuBamReader::Impl::Slot* GpuBamReader::Impl::wait_chunk(uint64_t i)
 {
     Slot& S = slots[i % kSlots];
+    const double t0 = now_s();
     std::unique_lock<std::mutex> lk(rm);
     rcv.wait(lk, [&] { return rstop || (S.filled && S.index == i); });
+    t_wait_chunk = t_wait_chunk.load() + (now_s() - t0);
     return rstop ? nullptr : &S;
 }
 
@@ -936,6 +948,9 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
         if (!R.d_comp.need(run_bytes + chunk_bytes + (1u << 17) + 64, true) || !R.d_out.need(out_cap, true) || !R.d_blocks.need(run_bytes / 2048) || !R.d_crc.need(run_bytes / 2048) ||
             !R.d_tok.need(bqc_gpu_inflate_token_words(out_cap, run_bytes / 2048), true) || !R.d_ntok.need(run_bytes / 2048)) { R.rc = -2; return; }
         he = hipMemsetAsync(R.d_status, 0, 4, R.s);
+        static const bool own_copy_stream = !(getenv("BQC_GB_COPY_STREAM") && getenv("BQC_GB_COPY_STREAM")[0] == '0');
+        if (own_copy_stream && !cs && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); cs = nullptr; }
+        hipStream_t const copy_s = own_copy_stream && cs ? cs : R.s;
         if (stop_at != UINT64_MAX) { // the readers may go as far as this run can want
             { std::lock_guard<std::mutex> lk(rm); read_limit = std::max(read_limit, stop_at + (1u << 17)); }
             rcv.notify_all();
@@ -947,7 +962,7 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
             const size_t p = parse_blocks(R, S->p + ring_at, have, d_off, nb, utotal, stop_at, out_limit, stopped);
             if (p == SIZE_MAX) { R.rc = -1; return; }
             if (!R.d_comp.need(d_off + p + 64) || !R.d_out.need(head + utotal + 64)) { R.rc = -2; return; } // (sized at open: grows only for unusual files)
-            if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, S->p + ring_at, p, hipMemcpyHostToDevice, R.s);
+            if (p) he = hipMemcpyAsync(R.d_comp.p + d_off, S->p + ring_at, p, hipMemcpyHostToDevice, copy_s);
             if (he != hipSuccess) break;
             d_off += p; parsed_off += p; ring_at += p;
             if (stopped || utotal + 65536 > out_limit) break; // (the rest of this chunk is the next run's)
@@ -961,10 +976,14 @@ void GpuBamReader::Impl::fill_run(GbRun& R)
             Slot* N = wait_chunk(ring_i + 1);
             if (!N) { R.rc = -2; return; }
             if (rem) memcpy(N->p + kHeadroom - rem, S->p + ring_at, rem);
-            if (!release_chunk(ring_i, R.s)) { R.rc = -2; return; }
+            if (!release_chunk(ring_i, copy_s)) { R.rc = -2; return; }
             ++ring_i;
             ring_at = kHeadroom - rem;
         }
+    }
+    if (he == hipSuccess && cs && produced != 0) { // (the run's chunks went through the copy stream: its kernels wait for the last of them)
+        he = hipEventRecord(R.copied, cs);
+        if (he == hipSuccess) he = hipStreamWaitEvent(R.s, R.copied, 0);
     }
     R.final = file_eof;
     R.utotal = utotal;
@@ -1280,7 +1299,7 @@ int GpuBamReader::next_batch(HostBatch& o, size_t max_reads, size_t max_bases, s
         nrec_ += n;
         I.avg_rec_bytes = (double)pos / (double)n;
         I.avg_rec_bases = (double)bases / (double)n;
-        t_read_ = I.t_read;
+        t_read_ = I.t_read; t_wait_run_ = I.t_wait_run; t_wait_chunk_ = I.t_wait_chunk;
         t_dec = now_s() - td;
         if (I.timing)
             fprintf(stderr, "[gpu reader] batch of %zu records (%.1f MB): %.1f ms = next run %.1f + walk %.1f + decode %.1f (reading so far %.3f s, waiting for runs %.3f s, rewalked %llu) at %.3f\n", N,

@@ -1121,7 +1121,11 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
           // record with a first / last flag whose quality string is empty while its sequence is not
             size_t n_noqual = hb->anchored ? hb->n_noqual : 0; // (a batch whose columns stayed on the card: counted there)
             for (uint16_t f : hb->flag) n_noqual += (f & BQC_FLAG_NO_QUAL) && !(f & 0x900) && (f & 0xC0);
-            if (use_gpu_reader) { n_noqual_deferred += n_noqual; n_noqual = 0; } // (printed once the pass is known to be the one that counts)
+            // (the reader on the card: printed once the pass is known to be the one that counts — it may still hand the file over to the host
+            // reader, which then prints them itself — i.e. behind the loop and in front of a record error: the lines of the batches BEFORE
+            // a failing record all come first, where the reference interleaves them with nothing either; the failing batch's own lines
+            // are the host decoder's to print)
+            if (use_gpu_reader) { n_noqual_deferred += n_noqual; n_noqual = 0; }
             if (n_noqual) {
                 static const char msg[] = "ERROR: length of sequence and quality is not the same\n";
                 std::string out;
@@ -1168,6 +1172,9 @@ static int run_program(int argc, const char** argv, const ShardArgs* shard, bool
     if (timing && refs_beside_loop) fprintf(stderr, "[timing] references uploaded beside the record loop; the submitting thread waited %.3f s for them\n", t_wait_refs);
     if (timing && lazy_refs) fprintf(stderr, "[timing] %u of %u contigs loaded, when their first reads arrived: %.3f s\n", n_lazy_refs, n_refs, t_lazy_refs);
     if (timing && use_gpu_reader) fprintf(stderr, "[timing] %llu batches anchored on the card (fixed columns never on the host)\n", (unsigned long long)gpu_rd.batches_anchored());
+    if (timing && use_gpu_reader)
+        fprintf(stderr, "[timing] reader on the card: pread %.2f s summed over its reader threads, the producer waited %.2f s for them, the decode thread waited %.2f s for inflated runs\n",
+                gpu_rd.seconds_reading(), gpu_rd.seconds_producer_waiting_for_chunks(), gpu_rd.seconds_waiting_for_runs());
     if (timing && use_gpu_reader && gpu_rd.batches_handed_over()) fprintf(stderr, "[timing] %llu batches held records the card does not decode and went through the host decoder\n", (unsigned long long)gpu_rd.batches_handed_over());
     if (timing)
         fprintf(stderr, "[timing] %llu records: decode thread busy %.2f s, submit thread (host pass + enqueue; page-locking %.2f s) %.2f s, waiting for the decoder %.2f s, loop %.2f s\n",

@@ -167,9 +167,10 @@ def main():
         ach = abytes / (kavg[dom] * 1e-3) / 1e9
         # HBM traffic per launch and the issue-slot counters come from rocprofv3 PMC passes (profiles/collect_r2.sh): counters
         # cannot be read in-process
-        traffic, limiter = None, None
+        traffic, limiter, tname = None, None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r3_traffic.json")) else "r2_traffic.json")))
+            tname = next(f for f in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
             if tj.get("kernel") == dom and args.reads == 10_000_000 and args.read_len == 150 and not args.sketch:
                 traffic = tj["traffic_bytes_per_launch"]
                 limiter = tj.get("limiter")
@@ -188,7 +189,7 @@ def main():
                        "reads_per_gpu_per_step": args.reads, "parallelism": "shard by read batch; RCCL reduce of state vector at end"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
                          "frac_vs_measured_copy_6290": ach / 6290.0, "traffic": traffic,
-                         "traffic_source": "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated; limiter against the MEASURED issue ceiling of profiles/r3_valu_issue.json)" if traffic else None,
+                         "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 calibrated; limiter against the MEASURED issue ceiling of profiles/r3_valu_issue.json)" % tname) if traffic else None,
                          "limiter": limiter or {"what": "valu+lds issue (integer SWAR and LDS atomics per base), not HBM: see DESIGN.md 4.2"},
                          "algorithmic_bytes_per_launch": abytes, "bytes_per_read": abytes / args.reads,
                          "kernel_ms": kavg},

@@ -201,8 +201,11 @@ int bqc_set_reference(bqc_ctx* ctx, int32_t rid, const uint8_t* dna5, uint64_t l
 /* Optional, before the first bqc_set_reference: one device allocation for contigs of total_bases bases in all, which
  * bqc_set_reference then carves from (an allocation made while kernels run waits for them). */
 int bqc_reserve_references(bqc_ctx* ctx, uint64_t total_bases, uint32_t n_contigs);
-/* (May be called from a second thread while another one submits batches, for a contig that no batch submitted so far has a read
- * on: the program uploads a genome's contigs behind the start of its record loop that way.) */
+/* (ONE uploader thread may call bqc_set_reference while another thread submits batches — the program's non-default BQC_BG_REFS=1 mode —
+ * under these rules: the contig is one no submitted batch has a read on; the uploader is the only caller of bqc_set_reference /
+ * bqc_reserve_references at that time; and its error is read with bqc_last_error only after the submitting thread has stopped.  The call
+ * waits for the context's compute stream: it returns when the batches queued before it are through.  No other concurrent use of a
+ * context is supported, bqc_anchor_* beside bqc_submit_anchored excepted.) */
 
 /* One batch of decoded records into the pipeline: host pass (coverage anchors), copy into a page-locked staging slot,
  * host-to-device copy, device pre-pass and kernels — three batches in flight, the call returns when the batch is queued.

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gpus-shared", type=int, default=0)
+    ap.add_argument("--proxy", action="store_true", help="config 3: also one worker's eighth of it as a file of its own (77.25 M reads over chr4-chr6) through the program, on the same box: "
+                                                         "shard_proxy and projected_speedup_8 in the result")
+    ap.add_argument("--variant", action="append", default=[], help="ENV=VALUE[,ENV=VALUE]: the timed runs once more with these variables set (reported under `variants`)")
     a = ap.parse_args()
     if a.config == 3:
         names, lens, seed, cli, synth_kw, read_len = NAMES24, GRCH38, 1003, [], {}, 150
@@ -88,6 +91,17 @@ def main():
         res.update({"program_wall_s": med["wall_s"], "reads_per_s": med["reads_per_s"], "compressed_GB_per_s": med["compressed_GB_per_s"], "which": "median of %d runs" % a.runs,
                     "reader": med["reader"], "runs": runs, "primary_reads": info["primary"], "triplets": info["triplets"], "eightmers": info["eightmers"],
                     "coverage_positions": int(cov.sum()), "mean_depth_main": float((cov * range(101)).sum() / max(1, cov.sum())), "invariants": "ok"})
+        res["variants"] = []
+        for spec in a.variant:
+            env = dict(kv.split("=") for kv in spec.split(","))
+            vr = []
+            for k in range(a.runs):
+                time.sleep(2.0)
+                dt, err = timed_run(["-r", fa, "-o", os.path.join(tmp, "v.bamqc")] + cli + [bam], env)
+                vr.append({"wall_s": dt, "timing": [ln for ln in err.splitlines() if ln.startswith("[timing]")]})
+                assert filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "v.bamqc"), shallow=False)
+                print("%s run %d: %.2f s" % (spec, k, dt), flush=True)
+            res["variants"].append({"env": env, "runs": vr, "median_wall_s": sorted(x["wall_s"] for x in vr)[len(vr) // 2]})
         # the host reader on the same file, once (what the GPU reader replaced)
         dt, err = timed_run(["-r", fa, "-o", os.path.join(tmp, "h.bamqc")] + cli + [bam], {"BQC_GPU_DECODE": "0"})
         res["host_reader"] = {"wall_s": dt, "reads_per_s": a.reads / dt, "identical_output": filecmp.cmp(os.path.join(tmp, "o0.bamqc"), os.path.join(tmp, "h.bamqc"), shallow=False)}
@@ -103,6 +117,27 @@ def main():
                                "what": "%d workers SHARING one card (BQC_GPUS_SHARE_DEVICE=1): each reads, inflates and decodes its byte range; sums through pipes" % n})
                 print("--gpus %d on one card: %.2f s, record loops %s" % (n, dt, loops), flush=True)
             res["workers_sharing_one_card"] = shared
+        if a.proxy and a.config == 3:
+            os.remove(bam)  # (room for the second file)
+            which = [3, 4, 5]
+            pn, pl = [names[k] for k in which], [lens[k] for k in which]
+            preads = 618_000_000 // 8
+            pbam, pfa = os.path.join(tmp, "p.bam"), os.path.join(tmp, "p.fa")
+            hostio.synth_stream(pbam, pfa, 1013, preads, pn, pl, level=a.level)
+            pr = []
+            for k in range(a.runs):
+                time.sleep(2.0)
+                dt, err = timed_run(["-r", pfa, "-o", os.path.join(tmp, "p%d.bamqc" % k), "-c", ",".join(pn), pbam])
+                m = re.search(r"record loop starts: ([0-9.]+) s", err)
+                pr.append({"wall_s": dt, "loop_start_s": float(m.group(1)) if m else None, "timing": [ln for ln in err.splitlines() if ln.startswith("[timing]")]})
+                print("proxy run %d: %.3f s" % (k, dt), flush=True)
+            pmed = sorted(x["wall_s"] for x in pr)[len(pr) // 2]
+            bamqc_text.check_invariants(bamqc_text.parse(os.path.join(tmp, "p0.bamqc"))["L1"], n_records=preads, read_len=150)
+            res["shard_proxy"] = {"what": "one worker's eighth of config 3 as a file of its own (%d reads over %s, %.1f GB) through the single-GPU program on the SAME box, median of %d runs"
+                                          % (preads, "+".join(pn), os.path.getsize(pbam) / 1e9, a.runs), "reads": preads, "wall_s": pmed, "runs": pr}
+            res["projected_speedup_8"] = res["program_wall_s"] / pmed
+            res["projected_speedup_8_what"] = "program_wall_s / shard_proxy.wall_s: what `bamqualcheck --gpus 8` gains over one card when its slowest worker takes as long as the proxy run (not in it: the hook's hand-over, one RCCL reduce of ~3 MB, eight workers sharing the host)"
+            print("projected 1 -> 8: %.2f x" % res["projected_speedup_8"], flush=True)
         # the first million reads of the same plan against the oracle, byte for byte
         prefix_parity(tmp, seed, a.reads, min(a.reads, pre_n), names, lens, pre_cli, pre_okw, **pre_kw)
         res["prefix_matches_oracle"] = {"reads": min(a.reads, pre_n), "identical": True}
