@@ -115,11 +115,11 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     hipDeviceProp_t prop;
     CCHK(hipGetDeviceProperties(&prop, c->device));
     c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
+    // (the kernels' attributes — hipFuncSetAttribute for k_short's and k_long's LDS — are set at their first launch: the first such call
+    // loads the code object, 40-60 ms that sat between the runtime's start and the first copy of a run here)
+    cstamp(0);
     c->stream = bqc_pool_stream(c->device, 0); // (made ahead by bqc_warmup, or now; the copy stream: at the first submit, bqc_copy_stream)
     if (!c->stream) { fail(nullptr, BQC_ERR_DEVICE, "bqc_create: hipStreamCreate failed"); bqc_destroy(c); return BQC_ERR_DEVICE; }
-    cstamp(0);
-    CCHK(bqc_long_init());
-    CCHK(bqc_short_init());
     cstamp(1);
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err0, sizeof(ErrRec)));
@@ -160,7 +160,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
         c->ev.push_back(e);
     }
     cstamp(5);
-    if (ctiming) fprintf(stderr, "[timing] bqc_create: streams at %.1f ms, kernel attributes (code object load) %.1f, allocations %.1f, memsets + tables %.1f, sketch %.1f, events %.1f\n", cts[0], cts[1], cts[2], cts[3], cts[4], cts[5]);
+    if (ctiming) fprintf(stderr, "[timing] bqc_create: kernel attributes (code object load) at %.1f ms, compute stream %.1f, allocations %.1f, memsets + tables %.1f, sketch %.1f, events %.1f\n", cts[0], cts[1], cts[2], cts[3], cts[4], cts[5]);
     *out = c;
     return 0;
 }

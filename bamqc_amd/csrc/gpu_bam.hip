@@ -589,7 +589,8 @@ struct GpuBamReader::Impl {
     // blocks to the card and gives the chunk back.  A block cut by a chunk's end is completed in the HEADROOM in front of the next
     // chunk's bytes, so that a block is always contiguous.
     struct Slot { uint8_t* p = nullptr; size_t len = 0; uint64_t index = UINT64_MAX; bool filled = false, used = false, registered = false; hipEvent_t done = nullptr; };
-    std::thread ring_alloc; // allocates and touches the ring's chunks while the runtime starts (they are page-locked afterwards: hipHostRegister)
+    std::thread ring_alloc; // allocates and touches the ring's chunks while the runtime starts, then page-locks them (hipHostRegister)
+    int ring_state = 0;     // (under rm) 1: the chunks are there and page-locked, -1: that failed
     static const int kMaxSlots = 16;
     int kSlots = 6, kReaders = 3; // (BQC_GB_READERS=N: N reader threads and 2 N chunks, N <= 8)
     static constexpr size_t kHeadroom = 1u << 17;
@@ -664,13 +665,23 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
     // the ring's chunks: allocated and touched here, by a thread of their own, while the runtime starts; page-locked below (measured,
     // tools/micro/startup_probe.cpp: hipHostMalloc of 6 x 16 MB 17-26 ms; touching them 18 ms — hidden behind the runtime's start — and
     // hipHostRegister 3-4 ms)
-    I.ring_alloc = std::thread([&I] {
+    I.ring_alloc = std::thread([&I, device] { // (... and page-locks them itself when the runtime is up: the ring is the SECOND run's business, open() does not wait for it)
+        bool ok = true;
         for (int k_ = 0; k_ < I.kSlots; ++k_) {
             Impl::Slot& C = I.slots[k_];
             const size_t bytes = (Impl::kHeadroom + I.chunk_bytes + 64 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
             C.p = (uint8_t*)aligned_alloc((size_t)2 << 20, bytes);
-            if (C.p) memset(C.p, 0, bytes);
+            if (C.p) memset(C.p, 0, bytes); else ok = false;
         }
+        ok = ok && hipSetDevice(device) == hipSuccess;
+        for (int k_ = 0; ok && k_ < I.kSlots; ++k_) {
+            Impl::Slot& C = I.slots[k_];
+            ok = hipHostRegister(C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostRegisterDefault) == hipSuccess;
+            C.registered = ok;
+            ok = ok && hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+        }
+        { std::lock_guard<std::mutex> lk(I.rm); I.ring_state = ok ? 1 : -1; }
+        I.rcv.notify_all();
     });
     hipError_t he = hipSetDevice(device);
     const double t_open1 = now_s();
@@ -717,13 +728,7 @@ bool GpuBamReader::open(const char* path, int device, const BamHeader& hdr, uint
         if (he == hipSuccess) he = hipMalloc((void**)&R.d_status, 64);
     }
     const double t_s2 = now_s();
-    I.ring_alloc.join();
-    for (int k_ = 0; k_ < I.kSlots; ++k_) {
-        Impl::Slot& C = I.slots[k_];
-        if (he == hipSuccess && !C.p) he = hipErrorOutOfMemory;
-        if (he == hipSuccess) { he = hipHostRegister(C.p, Impl::kHeadroom + I.chunk_bytes + 64, hipHostRegisterDefault); C.registered = he == hipSuccess; }
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&C.done, hipEventBlockingSync | hipEventDisableTiming);
-    }
+
     for (int t = 0; t < I.kReaders; ++t) I.readers.emplace_back([&I] { I.reader_loop(); }); // (they wait for the first run to be parsed)
     if (he != hipSuccess) { err = std::string("GPU reader: ") + hipGetErrorString(he); return false; }
     if (!I.upload_lanes(hdr)) { err = "GPU reader: out of device memory"; return false; }
@@ -820,8 +825,8 @@ void GpuBamReader::Impl::reader_loop()
         uint64_t i;
         {
             std::unique_lock<std::mutex> lk(rm);
-            rcv.wait(lk, [&] { return rstop || (ring_open && next_claim < released + (uint64_t)kSlots && ring_base + next_claim * chunk_bytes < read_limit); });
-            if (rstop) return;
+            rcv.wait(lk, [&] { return rstop || ring_state < 0 || (ring_state > 0 && ring_open && next_claim < released + (uint64_t)kSlots && ring_base + next_claim * chunk_bytes < read_limit); });
+            if (rstop || ring_state < 0) return;
             i = next_claim++;
         }
         Slot& S = slots[i % kSlots];
@@ -852,9 +857,9 @@ GpuBamReader::Impl::Slot* GpuBamReader::Impl::wait_chunk(uint64_t i)
     Slot& S = slots[i % kSlots];
     const double t0 = now_s();
     std::unique_lock<std::mutex> lk(rm);
-    rcv.wait(lk, [&] { return rstop || (S.filled && S.index == i); });
+    rcv.wait(lk, [&] { return rstop || ring_state < 0 || (S.filled && S.index == i); });
     t_wait_chunk = t_wait_chunk.load() + (now_s() - t0);
-    return rstop ? nullptr : &S;
+    return rstop || ring_state < 0 ? nullptr : &S;
 }
 
 // the producer is done with chunk i: its slot may be read into again once the copies queued on `st` so far have run

@@ -516,6 +516,8 @@ extern "C" void bqc_launch_long(const DevBatch& b, const StateLayout& sl, uint64
                                 uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, hipStream_t s)
 {
     if (n_chunks_ub == 0) return;
+    static const hipError_t attr_once = bqc_long_init(); // (at the first launch: see bqc_launch_short)
+    (void)attr_once;
     const uint32_t rows = max_len_ub ? (max_len_ub + KL_ROW - 1) / KL_ROW : 1u;
     uint32_t gx = n_cu / rows ? n_cu / rows : 1u; // one workgroup per CU (119 KB of LDS each): gx * rows <= n_cu where possible
     if (gx > n_chunks_ub) gx = n_chunks_ub;

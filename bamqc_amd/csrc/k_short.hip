@@ -697,6 +697,8 @@ extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint6
                                  uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t s)
 {
     if (grid == 0) return;
+    static const hipError_t attr_once = bqc_short_init(); // (at the first launch, not in bqc_create: the call loads the code object — 40-60 ms that
+    (void)attr_once;                                      //  the compute stream, which has slack at a run's start, can take; bqc_create's caller cannot)
     static uint32_t env_period = 0xFFFFFFFFu;
     if (env_period == 0xFFFFFFFFu) { const char* e = getenv("BQC_T8_PERIOD"); env_period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0u; } // tuning knob
     hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_used, t8_lane,
