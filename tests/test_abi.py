@@ -62,3 +62,23 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"oracle/|liboracle|orc_[a-z]+|import\s+.*oracle|from\s+.*oracle", txt):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_program_args_are_checked_without_running_anything():
+    """bqc_program_args (what `bamqualcheck --gpus N` asks before it forks): the program's own parser, no GPU call — the input path
+    wherever it stands on the line, usage errors as status 1, help as 2."""
+    lib = _lib.load()
+
+    def ask(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"bamqualcheck", *[a.encode() for a in args])
+        buf = ctypes.create_string_buffer(4096)
+        rc = lib.bqc_program_args(len(args) + 1, argv, buf, 4096)
+        return rc, buf.value.decode()
+
+    assert ask("-r", "g.fa", "-o", "x.bamqc", "in.bam") == (0, "in.bam")
+    assert ask("-r", "g.fa", "in.bam", "-o", "looks_like_input.bam") == (0, "in.bam")
+    assert ask("-r", "g.fa", "-o", "x.bamqc", "-") == (0, "-")
+    assert ask("-r", "g.fa", "-o", "x.bamqc", "--no-such-option", "in.bam")[0] == 1
+    assert ask("-r", "g.fa", "-o", "x.bamqc")[0] == 1              # no input
+    assert ask("-r", "g.fa", "-o", "x.bamqc", "in.txt")[0] == 1    # not *.bam / *.sam / -
+    assert ask("--help")[0] == 2
