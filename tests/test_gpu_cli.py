@@ -153,3 +153,46 @@ def test_optional_paths_write_the_same_bytes(tmp_path):
         r = subprocess.run([EXE, "-r", fa, "-o", got, bam], capture_output=True, text=True, env=dict(os.environ, **READER, **env))
         assert r.returncode == 0, (env, r.stderr)
         assert filecmp.cmp(got, want, shallow=False), env
+
+
+def test_one_read_group_anchored_then_handed_over(tmp_path, reader):
+    """One read group, the reader on the card, small batches: the first batches are anchored on the card (their columns never on the host);
+    then a record the card does not decode (a second NM tag) makes ITS batch go through the host decoder — and from there on the host keeps the
+    window state machine (the card's copy is behind by then); later, reads of a read group that is not in the header (lane 0 by the
+    reference's getLane).  Same bytes as the host reader's run and as the oracle's."""
+    import struct
+    import numpy as np
+    from bamqc_amd import synth
+    from tests import pybam
+    lens = [600_000, 300_000]
+    refs = [synth.reference(31, i, ln) for i, ln in enumerate(lens)]
+    cols = synth.batch(31, 24_000, lens, refs)
+    n = len(cols["flag"])
+    text = "@HD\tVN:1.6\n" + "".join("@SQ\tSN:chr%d\tLN:%d\n" % (i + 1, ln) for i, ln in enumerate(lens)) + "@RG\tID:L1\tSM:SYN\n"
+    recs, so, qo, co = [], 0, 0, 0
+    for i in range(n):
+        L, nc = int(cols["l_seq"][i]), int(cols["n_cigar"][i])
+        rg = b"other" if i >= 20_000 and i % 50 == 0 else b"L1"  # (a read group the header does not know: lane 0, bamqualcheck.cpp:86)
+        tags = b"RGZ" + rg + b"\0" + b"ASi" + struct.pack("<i", int(cols["as_"][i]))
+        nm = int(cols["nm"][i])
+        if nm >= 0:
+            tags += b"NMi" + struct.pack("<i", nm)
+            if i == 13_000:
+                tags += b"NMC" + struct.pack("<B", min(nm + 1, 255))  # a second NM tag: QualityCheck.hpp:201-218 looks at every one of them
+        recs.append(dict(rid=int(cols["rid"][i]), pos=int(cols["pos"][i]), mapq=int(cols["mapq"][i]), flag=int(cols["flag"][i]) & 0xFFF,
+                         rnext=0 if int(cols["flag"][i]) & 0x1000 else -1, tlen=int(cols["tlen"][i]), name="r%d" % i, cigar=cols["cigar"][co:co + nc],
+                         seq=cols["seq"][so:so + (L + 1) // 2], qual=cols["qual"][qo:qo + L], l_seq=L, tags=tags))
+        so += (L + 1) // 2; qo += L; co += nc
+    bam, fa = str(tmp_path / "h.bam"), str(tmp_path / "h.fa")
+    pybam.write_bam(bam, text, [("chr1", lens[0]), ("chr2", lens[1])], recs, rng=np.random.default_rng(2))
+    hostio.write_fasta(fa, ["chr1", "chr2"], refs)
+    got, want = str(tmp_path / "gpu.bamqc"), str(tmp_path / "oracle.bamqc")
+    r = subprocess.run([EXE, "-r", fa, "-o", got, "-c", "chr1,chr2", "--batch-reads", "3000", bam], capture_output=True, text=True, env=dict(os.environ, BQC_TIMING="1", **READER))
+    assert r.returncode == 0, r.stderr
+    if reader == "gpu_reader":
+        import re
+        m = re.search(r"\[timing\] (\d+) batches anchored on the card", r.stderr)
+        assert m and 1 <= int(m.group(1)) <= 5, r.stderr   # the batches in front of the second NM tag, none behind it
+        assert "went through the host decoder" in r.stderr
+    assert oracle_bamqualcheck(bam, fa, want, chroms="chr1,chr2", batch_reads=3000) == 0
+    assert filecmp.cmp(got, want, shallow=False)
