@@ -101,3 +101,53 @@ def test_config5_long_reads_stream(tmp_path):
     print("config 5: %d reads x 10 kb in %.1f s = %.2f M reads/s (%.1f G bases/s) end to end\n%s" % (n, wall, n / wall / 1e6, n * 1e4 / wall / 1e9, stderr[-600:]))
     prefix_parity(str(tmp_path), 1005, n, min(n, 20_000), ["chr1"], lens, ["-c", "chr1", "-i", "30000", "--no-sketch", "--max-read-len", "16384"],
                   dict(chroms="chr1", isize=30000, klist=(), qlist=(), max_read_len=16384, hist_cap=65536), read_len=10_000, isize=30_000, long_reads=True)
+
+
+def _file_through_cli(tmp, seed, n, names, lens, cli_args, env=None, **synth_kw):
+    """generator -> BAM FILE (BGZF level 1) -> bamqualcheck with the reader on the card; (output path, stderr)"""
+    bam, fa = os.path.join(tmp, "f.bam"), os.path.join(tmp, "f.fa")
+    if not os.path.exists(bam):
+        hostio.synth_stream(bam, fa, seed, n, names, lens, level=1, **synth_kw)
+    out = os.path.join(tmp, "out_%d.bamqc" % len(os.listdir(tmp)))
+    r = subprocess.run([EXE, "-r", fa, "-o", out] + list(cli_args) + [bam], capture_output=True, text=True, env=dict(os.environ, BQC_TIMING="1", **(env or {})))
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out, r.stderr
+
+
+def test_config3_shaped_file_on_the_card(tmp_path):
+    """Config 3's shape as a FILE (40 M reads over the 24 GRCh38-length contigs, ~4 GB; BQC_TEST_CONFIG3_READS scales it): read, inflated, walked,
+    decoded and anchored on the card — no column on the host —; invariants, the first million reads against the oracle, and the same bytes
+    with the host's pass over the columns (BQC_DEVICE_ANCHORS=0) and with the host reader."""
+    import filecmp
+    n = int(os.environ.get("BQC_TEST_CONFIG3_READS", "40000000"))
+    out, err = _file_through_cli(str(tmp_path), 1003, n, NAMES24, GRCH38, [])
+    assert "records decoded on the GPU" in err
+    m = re.search(r"\[timing\] (\d+) batches anchored on the card", err)
+    assert m and int(m.group(1)) >= n // (1 << 20), err[-1500:]
+    lanes = bamqc_text.parse(out)
+    bamqc_text.check_invariants(lanes["L1"], n_records=n, read_len=150)
+    out2, err2 = _file_through_cli(str(tmp_path), 1003, n, NAMES24, GRCH38, [], env={"BQC_DEVICE_ANCHORS": "0"})
+    assert "[timing] 0 batches anchored on the card" in err2
+    assert filecmp.cmp(out, out2, shallow=False)
+    out3, err3 = _file_through_cli(str(tmp_path), 1003, n, NAMES24, GRCH38, [], env={"BQC_GPU_DECODE": "0"})
+    assert "records decoded on the host" in err3
+    assert filecmp.cmp(out, out3, shallow=False)
+    prefix_parity(str(tmp_path), 1003, n, min(n, 1_000_000), NAMES24, GRCH38, ["-c", "chr1"], dict(chroms="chr1"))
+
+
+def test_config5_shaped_file_on_the_card(tmp_path):
+    """Config 5's shape as a FILE (150 K reads x 10 kb with 20-60 CIGAR operations, ~0.9 GB): the long-read kernels behind the reader on the
+    card and its anchors; invariants, the same bytes with the host reader, a prefix against the oracle."""
+    import filecmp
+    n = int(os.environ.get("BQC_TEST_CONFIG5_FILE_READS", "150000"))
+    lens = [250_000_000]
+    cli = ["-c", "chr1", "-i", "30000", "--no-sketch", "--max-read-len", "16384"]
+    kw = dict(read_len=10_000, isize=30_000, long_reads=True)
+    out, err = _file_through_cli(str(tmp_path), 1005, n, ["chr1"], lens, cli, **kw)
+    assert "records decoded on the GPU" in err and "[timing] 0 batches anchored" not in err
+    lanes = bamqc_text.parse(out)
+    bamqc_text.check_invariants(lanes["L1"], n_records=n, read_len=10_000)
+    out2, err2 = _file_through_cli(str(tmp_path), 1005, n, ["chr1"], lens, cli, env={"BQC_GPU_DECODE": "0"}, **kw)
+    assert filecmp.cmp(out, out2, shallow=False)
+    prefix_parity(str(tmp_path), 1005, n, min(n, 10_000), ["chr1"], lens, cli,
+                  dict(chroms="chr1", isize=30000, klist=(), qlist=(), max_read_len=16384, hist_cap=65536), **kw)
