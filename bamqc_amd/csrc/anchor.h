@@ -54,7 +54,9 @@ struct AnchorRun {
     uint32_t b_star;  // stuck: beginPos of that first read further right (if the run has one)
 };
 
-#define AN_MAX_BREAKS 65536u
+// breaks a batch may hold for the card's chain (ONE thread walks them, ~0.2 us each: 3 ms at this limit, what the host's pass over a
+// million reads takes); a batch with more — sparse data: every other read is a break — is left to the host
+#define AN_MAX_BREAKS 16384u
 
 struct AnchorPart { // what a workgroup of k_an_count (1024 reads) knows; summed by k_an_scan
     uint32_t n_slow, max_slow, n_noqual, first_certain;
