@@ -811,32 +811,53 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
     }
     if (stats) { tc[3] = clock64(); if (tid == 0u) atomicAdd(&stats[2], (unsigned long long)rounds); }
     } else __syncthreads(); // (a block without matches: only its CRC is looked at; the tables are complete behind this barrier)
-    // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte).  (All loads in front of all
-    // stores — the compiler has to take a store for a possible source of the next load — measured no faster.)
+    // every match byte from its literal: four bytes per thread and step (the block's tail byte by byte).
+    // Round 4: the literals are gathered from LDS, not from memory.  A thread first takes the roots of its (up to 16) steps into
+    // registers; then the index array — done with — is overwritten with the block's BYTES as phase 1 left them (coalesced 16-byte
+    // loads: the literals are in place, what lies under the matches is never looked at); then four ds_read_u8 per word instead of four
+    // byte loads from memory, which were 64 scattered addresses per instruction (~40 clocks of the CU's address path each, 1024 such
+    // instructions per block: 31 K of the kernel's 150 K clocks per block in round 3).  The words that are all literals come from the same
+    // copy (the CRC wants them too).
     uint32_t acc = 0;
 #define GI_CRC_COL(x) do { if (expect) { const uint32_t w_ = (x); \
         acc = mtab[acc & 255u] ^ mtab[256u + ((acc >> 8) & 255u)] ^ mtab[512u + ((acc >> 16) & 255u)] ^ mtab[768u + (acc >> 24)] ^ \
               ctab[768u + (w_ & 255u)] ^ ctab[512u + ((w_ >> 8) & 255u)] ^ ctab[256u + ((w_ >> 16) & 255u)] ^ ctab[w_ >> 24]; } } while (0)
-    for (uint32_t p = 4u * tid; p < usize; p += 4096u) {
-        uint32_t i0 = p, i1 = p + 1u, i2 = p + 2u, i3 = p + 3u;
-        if (n != 0u) {
-            const uint32_t v0 = pair[p / 2u], v1 = pair[p / 2u + 1u];
-            i0 = v0 & 0xFFFFu; i1 = v0 >> 16; i2 = v1 & 0xFFFFu; i3 = v1 >> 16;
+    if (n != 0u) {
+        uint32_t r0[16], r1[16]; // the roots of this thread's words: step j at p = 4 tid + 4096 j
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t p = 4u * tid + 4096u * (uint32_t)j;
+            if (p < usize) { r0[j] = pair[p / 2u]; r1[j] = pair[p / 2u + 1u]; } else { r0[j] = 0; r1[j] = 0; }
         }
-        if (p + 4u <= usize) {
-            if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) { // four literals: in place already
-                if (expect) GI_CRC_COL(*(const gi_u32_u*)(o0 + p));
-                continue;
+        __syncthreads();
+        uint8_t* const val = (uint8_t*)ridx; // [65536] the block's bytes
+        for (uint32_t off = 16u * tid; off < usize; off += 16384u) *(gi_u32x4*)(val + off) = *(const gi_u32x4_u*)(o0 + off); // (runs up to 15 bytes over the block's end: inside the output buffer and its slack)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t p = 4u * tid + 4096u * (uint32_t)j;
+            if (p >= usize) break;
+            const uint32_t i0 = r0[j] & 0xFFFFu, i1 = r0[j] >> 16, i2 = r1[j] & 0xFFFFu, i3 = r1[j] >> 16;
+            if (p + 4u <= usize) {
+                if (i0 == p && i1 == p + 1u && i2 == p + 2u && i3 == p + 3u) { GI_CRC_COL(*(const uint32_t*)(val + p)); continue; } // four literals: in place already
+                const uint32_t w = (uint32_t)val[i0] | ((uint32_t)val[i1] << 8) | ((uint32_t)val[i2] << 16) | ((uint32_t)val[i3] << 24);
+                *(gi_u32_u*)(o0 + p) = w;
+                GI_CRC_COL(w);
+            } else {
+                const uint32_t ii[4] = {i0, i1, i2, i3};
+                uint32_t w = 0;
+                for (uint32_t k = 0; p + k < usize; ++k) {
+                    const uint32_t by = val[ii[k]];
+                    if (ii[k] != p + k) o0[p + k] = (uint8_t)by;
+                    w |= by << (8u * k);
+                }
+                GI_CRC_COL(w); // (zeros behind the block's end)
             }
-            const uint32_t w = (uint32_t)o0[i0] | ((uint32_t)o0[i1] << 8) | ((uint32_t)o0[i2] << 16) | ((uint32_t)o0[i3] << 24);
-            *(gi_u32_u*)(o0 + p) = w;
-            GI_CRC_COL(w);
-        } else {
-            const uint32_t ii[4] = {i0, i1, i2, i3};
-            uint8_t vv[4] = {0, 0, 0, 0};
-            for (uint32_t j = 0; p + j < usize; ++j) vv[j] = o0[ii[j]];
-            for (uint32_t j = 0; p + j < usize; ++j) if (ii[j] != p + j) o0[p + j] = vv[j];
-            GI_CRC_COL((uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24)); // (zeros behind the block's end)
+        }
+    } else {
+        for (uint32_t p = 4u * tid; p < usize; p += 4096u) { // no match in the block: only its CRC
+            if (p + 4u <= usize) GI_CRC_COL(*(const gi_u32_u*)(o0 + p));
+            else { uint32_t w = 0; for (uint32_t k = 0; p + k < usize; ++k) w |= (uint32_t)o0[p + k] << (8u * k); GI_CRC_COL(w); }
         }
     }
 #undef GI_CRC_COL
