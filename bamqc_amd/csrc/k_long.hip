@@ -27,6 +27,9 @@
 #ifndef KL_WAVES
 #define KL_WAVES  12
 #endif
+#ifndef KL_EXPER
+#define KL_EXPER  0                                // timing experiments only (results are wrong): 1 no triplets, 2 no 8-mers, 4 no per-cycle counters / per-read sums
+#endif
 
 __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0)
 {
@@ -176,11 +179,16 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
         // instructions run while the next rows' loads are in flight: the columns of read k + 16 and the bases / qualities of its
         // row are requested before read k is computed (a wave alone would wait for four dependent round trips per row).
         struct Meta { uint32_t r, flag, L, so, qo, co, ncig; int32_t rid, pos; };
+        struct RefOf { const uint32_t* rn; uint64_t len; }; // the read's contig (nibble table, length): asked for with the row's bases — looked up
+                                                            // where it is needed it cost every row two dependent round trips behind a vmcnt(0)
         auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }; // the same in every lane: keep it in a scalar register
-        auto load_meta = [&](uint32_t kk) {
+        // (the read's index is asked for an iteration before its columns are: read where it is needed it was a round trip of its own
+        // per row, behind a vmcnt(0) that also waited for the row loads issued just before)
+        auto load_perm = [&](uint32_t kk) { return kk < ch.count ? b.perm[ch.first + kk] : 0u; };
+        auto load_meta = [&](uint32_t kk, uint32_t r_raw) {
             Meta m{0, 0x900u, 0, 0, 0, 0, 0, -1, 0};
             if (kk < ch.count) {
-                m.r = uni(b.perm[ch.first + kk]);
+                m.r = uni(r_raw);
                 m.flag = b.flag[m.r]; m.L = b.l_seq[m.r]; m.so = b.seq_off[m.r]; m.qo = b.qual_off[m.r];
                 m.co = b.cigar_off[m.r]; m.ncig = b.n_cigar[m.r]; m.rid = b.rid[m.r]; m.pos = b.pos[m.r];
             }
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             m.rid = (int32_t)uni((uint32_t)m.rid); m.pos = (int32_t)uni((uint32_t)m.pos);
         };
         // bases / qualities of the row, and the read's first 64 CIGAR operations (operation ln in lane ln)
-        auto load_row = [&](const Meta& m, uint32_t (&s)[3], uint32_t (&q)[4], uint32_t& cw) { // (rows that are skipped load harmlessly from the buffers' start)
+        auto load_row = [&](const Meta& m, uint32_t (&s)[3], uint32_t (&q)[4], uint32_t& cw, RefOf& ro) { // (rows that are skipped load harmlessly from the buffers' start)
             const bool rc_ = m.flag & 0x10u;
             const bool use = !(m.flag & 0x900u) && (m.flag & 0xC0u) && m.L > cyc0;
             const int32_t o0_ = rc_ ? (int32_t)m.L - (int32_t)cyc0 : (int32_t)cyc0 - 16;
@@ -203,15 +211,26 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             GVec<3>::ldu(s, g_seq + so);
             GVec<4>::ldu(q, g_qual + qo);
             cw = use && ln < m.ncig ? b.cigar[(uint64_t)m.co + ln] : 0u;
+            const bool hasref = use && m.rid >= 0 && (uint32_t)m.rid < refs.n_refs;
+            ro.rn = hasref ? refs.refn[m.rid] : nullptr;
+            ro.len = hasref ? refs.len[m.rid] : 0;
         };
-        Meta cur_m = load_meta(wave), nxt_m = load_meta(wave + KL_WAVES);
+        const uint32_t r_0 = load_perm(wave), r_1 = load_perm(wave + KL_WAVES);
+        uint32_t r_nn = load_perm(wave + 2 * KL_WAVES);
+        Meta cur_m = load_meta(wave, r_0), nxt_m = load_meta(wave + KL_WAVES, r_1);
         uint32_t s[3], q[4], cw, s_n[3], q_n[4], cw_n;
+        RefOf ro, ro_n;
         settle(cur_m);
-        load_row(cur_m, s, q, cw);
+        load_row(cur_m, s, q, cw, ro);
+        // Every load of the prologue has arrived before the loop is entered: the compiler's wait-count pass otherwise carries "pending
+        // since the prologue, three loads behind it" into the loop and waits — in every iteration, in the middle of the row, for all but
+        // the last three of the loads the iteration has just issued (s_waitcnt vmcnt(3) in front of the first use of the contig's length).
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         for (uint32_t k = wave; k < ch.count; k += KL_WAVES) {
             settle(nxt_m);                                  // (its columns were requested one iteration ago)
-            load_row(nxt_m, s_n, q_n, cw_n);
-            const Meta nn_m = load_meta(k + 2 * KL_WAVES);
+            load_row(nxt_m, s_n, q_n, cw_n, ro_n);
+            const Meta nn_m = load_meta(k + 2 * KL_WAVES, r_nn);
+            r_nn = load_perm(k + 3 * KL_WAVES);
             {
             const uint32_t r = cur_m.r, flag = cur_m.flag;
             if ((flag & 0x900u) || !(flag & 0xC0u)) goto next_read;  // skipped records; a missing mate flag is raised by the pre-pass / k_reads
@@ -222,12 +241,110 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             // BAM index of the first base of lane 0's window, and of this lane's: forward reads run with the cycles, reverse reads
             // against them (lane w then takes the mirrored window and turns it in registers)
             const int32_t o0 = rc ? (int32_t)L - (int32_t)cyc0 : (int32_t)cyc0 - 16;
-            const int32_t sw = rc ? -(int32_t)w : (int32_t)w;
             const uint32_t nv = c_lo < 0 ? 0u : (uint32_t)min(max((int32_t)L - c_lo, 0), 16); // valid cycles of this lane
             const uint32_t nvq = noq ? 0u : nv;
             uint32_t xm[2], qm[4];
             kl_lut_nib(xm, LUT + 8u * nv);
             kl_lut_byte(qm, LUT + 8u * nvq + 4u);
+            // ---- triplets in cycle space (TripletCounting.hpp:195-236), first half: the CIGAR's segments and the reference windows they
+            // need are worked out BEFORE the row's own arithmetic, which then runs while the windows are on their way
+            const uint32_t ncig = cur_m.ncig;
+            const int32_t rid = cur_m.rid;
+            const uint32_t* rn = (const uint32_t*)(((uint64_t)uni((uint32_t)((uint64_t)ro.rn >> 32)) << 32) | uni((uint32_t)(uint64_t)ro.rn)); // (nullptr: no such contig, or not loaded)
+            const int64_t reflen = (int64_t)(((uint64_t)uni((uint32_t)(ro.len >> 32)) << 32) | uni((uint32_t)ro.len));
+            const bool trip = !(KL_EXPER & 1) && (flag & BQC_FLAG_TRIPLET) && L >= 3 && ncig > 0 && !noq && rid >= 0 && rn != nullptr;
+            const uint32_t* __restrict__ cg = b.cigar + cur_m.co;
+            const uint32_t nd8p1 = (uint32_t)((reflen + 7) >> 3) + 1u; // (the table: 2 pad dwords, nd8, 2 pad dwords)
+            const int64_t pos0 = cur_m.pos;
+            // the row's bases in BAM orientation (flank lanes included: their cycles are never evaluated, only looked at)
+            const int64_t I0 = rc ? (int64_t)L - cyc0 - KL_ROW : (int64_t)cyc0, I1 = I0 + KL_ROW;
+            const uint32_t w16 = 16u * w;
+            // Round 4: one triplet pass per LANE, not per segment.  A match-like CIGAR segment aligns read positions [ia, ib) at
+            // chromPos = posv + i; the lanes holding the operations clip it to the contig and the row and turn it into CYCLES of this
+            // row (+ 16: lane w holds 16 w .. 16 w + 15) and the reference nibble index of lane 0's window; every cycle lane then
+            // picks the (at most two, nearly always) segments that touch its 16 cycles and evaluates each with its own alignment —
+            // two passes per row whatever the number of segments (round 3: a pass of the whole wave per segment, three per row on
+            // config 5's reads), both reference windows in flight together, 32-bit arithmetic throughout the pass.  The window
+            // has 18 nibbles now (the reference bases in front of the lane's first cycle and behind its last one under THIS
+            // lane's alignment; the neighbour may sit in another segment).
+            auto seg_pack = [&](bool valid, int64_t ia, int64_t ib, int64_t posv, uint32_t& kab_s, uint32_t& U_s) {
+                if (1 - posv > ia) ia = 1 - posv;                       // context posv+i-1 .. posv+i+1 inside the contig
+                if (reflen - 1 - posv < ib) ib = reflen - 1 - posv;
+                valid = valid && ia < ib && ia < I1 && ib > I0;
+                int64_t ka = (rc ? (int64_t)L - ib : ia) - (int64_t)cyc0 + 16, kb = (rc ? (int64_t)L - ia : ib) - (int64_t)cyc0 + 16;
+                ka = ka < 0 ? 0 : ka > 1024 ? 1024 : ka;
+                kb = kb < 0 ? 0 : kb > 1024 ? 1024 : kb;
+                kab_s = (uint32_t)ka | ((uint32_t)kb << 16);
+                U_s = (uint32_t)(uint64_t)(posv + o0 + 15);             // (the table has 16 pad nibbles in front; the window starts one nibble early)
+                return valid;
+            };
+            // The walk of :207-222, by the whole wave: operation kb + ln in lane ln.  Read / chromosome advance of every operation
+            // (the first one is taken as match-like whatever it is), exclusive prefix sums by DPP scans (the chromosome advance as two
+            // 16-bit halves: 64 operations of up to 2^28 positions); the match-like ones that reach into the row are the result.
+            int64_t rp_c = 0, cp_c = 0; // positions in front of the current block of 64 operations
+            auto scan_block = [&](uint32_t kb, uint32_t& kab_s, uint32_t& U_s) {
+                const uint32_t kk = kb + ln;
+                const uint32_t wv = kb == 0u ? cw : (kk < ncig ? cg[kk] : 0u), op = wv & 15u, nn = wv >> 4;
+                const bool live = kk < ncig;
+                const bool ref_only = live && kk != 0u && (op == 2u || op == 3u || op == 5u || op == 6u); // D N H P
+                const bool read_only = live && kk != 0u && (op == 4u || op == 1u);                         // S I
+                const bool match = live && !ref_only && !read_only;
+                const uint32_t ra = (live && !ref_only) ? min(nn, L + 1u) : 0u, ca = (live && !read_only) ? nn : 0u;
+                const uint32_t ra_i = wave_scan_incl(ra), cl_i = wave_scan_incl(ca & 0xFFFFu), ch_i = wave_scan_incl(ca >> 16);
+                const int64_t rp = rp_c + (ra_i - ra), cp = cp_c + (int64_t)(cl_i - (ca & 0xFFFFu)) + ((int64_t)(ch_i - (ca >> 16)) << 16);
+                // segment of a match-like operation: read positions [ia, ib) at chromPos = posv + i
+                const int64_t ia = rp > 1 ? rp : 1, ib = rp + nn < (int64_t)L - 1 ? rp + nn : (int64_t)L - 1;
+                const int64_t posv = pos0 + cp - rp;
+                const bool seg = seg_pack(match && rp < (int64_t)L && ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2, ia, ib, posv, kab_s, U_s);
+                rp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ra_i, 63);
+                cp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cl_i, 63) + ((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ch_i, 63) << 16);
+                return (uint64_t)__ballot(seg);
+            };
+            // the segments `t` (operation lanes) that touch this lane's cycles, at most two per call, in operation order from
+            // `wm` on; returns the ones some lane had no room for
+            auto collect = [&](uint64_t t, uint32_t kab_s, uint32_t U_s, uint32_t& wm, uint32_t (&kab)[2], uint32_t (&U)[2], uint32_t& have) {
+                kab[0] = kab[1] = 0; U[0] = U[1] = 0; have = 0;
+                uint64_t rest = 0;
+                while (t) {
+                    const uint32_t src = (uint32_t)__ffsll((unsigned long long)t) - 1u;
+                    t &= t - 1;
+                    const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)kab_s, (int)src), UU = (uint32_t)__builtin_amdgcn_readlane((int)U_s, (int)src);
+                    const bool ov = (K & 0xFFFFu) < w16 + 16u && (K >> 16) > w16 && src >= wm;
+                    const bool take = ov && have < 2u;
+                    if (take) {
+                        if (have == 0u) { kab[0] = K; U[0] = UU; } else { kab[1] = K; U[1] = UU; }
+                        ++have; wm = src + 1u;
+                    }
+                    if (__ballot(ov && !take)) rest |= 1ull << src;
+                }
+                return rest;
+            };
+            auto issue = [&](uint32_t U, uint32_t& pp, uint32_t (&e)[4]) {
+                pp = rc ? U - w16 : U + w16;                            // nibble index of the lane's window, minus one (a lane that takes the segment: 0 <= pp < reflen + 16)
+                const uint32_t di = min(pp >> 3, nd8p1);
+                GVec<3>::lda(e, (const uint8_t*)(rn + di));
+                e[3] = rn[min(di + 3u, nd8p1 + 2u)];                    // (the nibble behind the window when it starts at a dword's last nibble)
+            };
+            // the first 64 operations' segments, the first two per lane: requested here, evaluated at the end
+            uint32_t t_kab_s = 0, t_U_s = 0, t_wm = 0, t_kab[2] = {0, 0}, t_pp[2] = {0, 0}, t_e0[4] = {0, 0, 0, 0}, t_e1[4] = {0, 0, 0, 0};
+            uint64_t t_todo = 0;
+            bool t_two = false, t_any = false;
+            if (trip) {
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw) >> 4; // operation 0 sits in lane 0
+                if (n0 == 0u) {
+                    // cigarCount starts at (size_t)-1: every position counts as inside the first operation (:203)
+                    t_todo = seg_pack(pos0 > -(1 << 30) && pos0 < (1 << 30), 1, (int64_t)L - 1, pos0, t_kab_s, t_U_s) ? 1ull : 0ull; // (the same in every lane)
+                    rp_c = (int64_t)L; // (no further operations)
+                } else t_todo = scan_block(0, t_kab_s, t_U_s);
+                if (t_todo) {
+                    uint32_t U[2], have;
+                    t_todo = collect(t_todo, t_kab_s, t_U_s, t_wm, t_kab, U, have);
+                    t_two = __ballot(have >= 2u) != 0;
+                    t_any = true;
+                    issue(U[0], t_pp[0], t_e0);
+                    if (t_two) issue(U[1], t_pp[1], t_e1);
+                }
+            }
             // ---------------- the lane's cycles: one-hot base nibbles X[h] = cycles 8h..8h+7 (first cycle in the top nibble) ...
             uint32_t X[2];
             {
@@ -259,8 +376,45 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             Planes P[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) P[h] = planes_of(X[h]);
-            // ---- per-cycle counters and the per-read sums (QualityCheck.hpp:122-166)
+            // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
+            uint32_t cn[2], nb[3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cn[h] = (P[h].c | P[h].t) | ((P[h].g | P[h].t) << 1);
+                nb[h] = P[h].n | (~xm[h] & M); // literal N or outside the read: blocks 8-mer windows and triplet flanks
+            }
+            // ---- 8-mers: windows starting at the lane's cycles (OverallNumbers.hpp:137-168)
+            uint32_t old[16], f[2], c32 = 0, cx = 0;
+            const bool t8_go = !(KL_EXPER & 2) && own && nv > 0u;
             {
+                uint32_t S[2];
+                S[0] = vperm(squeeze2(cn[0]), squeeze2(cn[1]), 0x05040100u);
+                S[1] = lane_next(S[0]);
+                nb[2] = lane_next(nb[0]);
+                if (w == 63u) nb[2] = M;
+                {
+                    uint32_t sa[3], sb[3];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) sa[h] = nb[h] | alignbit(nb[h], nb[h + 1], 28);
+                    sa[2] = nb[2] | (nb[2] << 4);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) sb[h] = sa[h] | alignbit(sa[h], sa[h + 1], 24);
+                    sb[2] = sa[2] | (sa[2] << 8);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) f[h] = ~(sb[h] | alignbit(sb[h], sb[h + 1], 16)); // nibble LSB set <=> the window starting there is counted
+                }
+                if (t8_go) { // all 16 atomics are issued, the returned values looked at further down; a blocked window adds 0
+                    c32 = S[0]; cx = S[1];
+#pragma unroll
+                    for (int kw = 0; kw < 16; ++kw) {
+                        const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw);
+                        const uint32_t one = bfe(f[kw >> 3], 28 - 4 * (kw & 7), 1);
+                        old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            // ---- per-cycle counters and the per-read sums (QualityCheck.hpp:122-166) — while the 8-mer counters' old values come back
+            if (!(KL_EXPER & 4)) {
                 if (own) { if (mate) kl_add(A1, P, Q); else kl_add(A0, P, Q); }
                 if (++n1[mate] == 15u) { if (own) { if (mate) kl_spill(A1, lds, 1, w); else kl_spill(A0, lds, 0, w); } n1[mate] = 0; }
                 if (++n2[mate] == 255u) { if (own) { if (mate) kl_qflush(A1, lds, 1, w); else kl_qflush(A0, lds, 0, w); } n2[mate] = 0; }
@@ -282,67 +436,23 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
 #pragma unroll
                     for (int h = 0; h < 2; ++h) { vn += (uint32_t)__popc(P[h].n); vgc += (uint32_t)__popc(P[h].c | P[h].g); }
                 }
-                const uint32_t s1 = wave_sum(v | (vn << 20)), s2 = wave_sum(vgc); // (<= 62 * 4080 < 2^20; <= 992)
-                if (ln == 0) {
+                // (sums over the wave by DPP adds, the total in lane 63: no LDS round trips; <= 62 * 4080 < 2^20, <= 992)
+                const uint32_t s1 = wave_scan_incl(v | (vn << 20)), s2 = wave_scan_incl(vgc);
+                if (ln == 63u) {
                     if (s1 & 0xFFFFFu) atomicAdd(&rsum[3 * (uint64_t)r], s1 & 0xFFFFFu);
                     if (s1 >> 20) atomicAdd(&rsum[3 * (uint64_t)r + 1], s1 >> 20);
                     if (s2) atomicAdd(&rsum[3 * (uint64_t)r + 2], s2);
                 }
             }
-            // ---- 2-bit codes per nibble; non-ACGT -> A (char -> Dna after the reverse complement)
-            uint32_t cn[2], nb[3];
+            if (t8_go) { // a counter that wrapped (exact accounting: swar.h)
+                uint32_t hot0 = 0, hot1 = 0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                cn[h] = (P[h].c | P[h].t) | ((P[h].g | P[h].t) << 1);
-                nb[h] = P[h].n | (~xm[h] & M); // literal N or outside the read: blocks 8-mer windows and triplet flanks
+                for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
+                if (hot0 & 0x80808080u) t8_check<0>(em, c32, cx, f[0], old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
+                if (hot1 & 0x80808080u) t8_check<8>(em, c32, cx, f[1], old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
             }
-            // ---- 8-mers: windows starting at the lane's cycles (OverallNumbers.hpp:137-168)
-            {
-                uint32_t S[2];
-                S[0] = vperm(squeeze2(cn[0]), squeeze2(cn[1]), 0x05040100u);
-                S[1] = lane_next(S[0]);
-                nb[2] = lane_next(nb[0]);
-                if (w == 63u) nb[2] = M;
-                uint32_t f[2];
-                {
-                    uint32_t sa[3], sb[3];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) sa[h] = nb[h] | alignbit(nb[h], nb[h + 1], 28);
-                    sa[2] = nb[2] | (nb[2] << 4);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) sb[h] = sa[h] | alignbit(sa[h], sa[h + 1], 24);
-                    sb[2] = sa[2] | (sa[2] << 8);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) f[h] = ~(sb[h] | alignbit(sb[h], sb[h + 1], 16)); // nibble LSB set <=> the window starting there is counted
-                }
-                if (own && nv > 0u) { // all 16 atomics are issued before the first returned value is looked at; a blocked window adds 0
-                    const uint32_t c32 = S[0], cx = S[1];
-                    uint32_t old[16];
-#pragma unroll
-                    for (int kw = 0; kw < 16; ++kw) {
-                        const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw);
-                        const uint32_t one = bfe(f[kw >> 3], 28 - 4 * (kw & 7), 1);
-                        old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    uint32_t hot0 = 0, hot1 = 0;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) { hot0 |= old[kk]; hot1 |= old[8 + kk]; }
-                    if (hot0 & 0x80808080u) t8_check<0>(em, c32, cx, f[0], old[0], old[1], old[2], old[3], old[4], old[5], old[6], old[7]);
-                    if (hot1 & 0x80808080u) t8_check<8>(em, c32, cx, f[1], old[8], old[9], old[10], old[11], old[12], old[13], old[14], old[15]);
-                }
-            }
-            // ---- triplets in cycle space (TripletCounting.hpp:195-236): one pass per match-like CIGAR segment that touches the row
-            const uint32_t ncig = cur_m.ncig;
-            const int32_t rid = cur_m.rid;
-            const bool trip = (flag & BQC_FLAG_TRIPLET) && L >= 3 && ncig > 0 && !noq && rid >= 0 && (uint32_t)rid < refs.n_refs && refs.refn[rid] != nullptr;
+            // ---- triplets, second half: the passes
             if (trip) {
-                const uint32_t* __restrict__ cg = b.cigar + cur_m.co;
-                const uint32_t* rn = refs.refn[rid];
-                const int64_t reflen = (int64_t)refs.len[rid];
-                const int64_t nd8 = (reflen + 7) >> 3;
-                const int64_t pos0 = cur_m.pos;
-                // the row's bases in BAM orientation (flank lanes included: their cycles are never evaluated, only looked at)
-                const int64_t I0 = rc ? (int64_t)L - cyc0 - KL_ROW : (int64_t)cyc0, I1 = I0 + KL_ROW;
                 const uint32_t rcm = rc ? 0x33333333u : 0u;
                 // quality 20..94 <=> (signed char)(q + 33) >= '5'; flags at the byte MSBs, then moved next to each other in pairs
                 uint32_t qf[4];
@@ -356,41 +466,31 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 uint32_t ct[2]; // read codes as the triplet test sees them (BAM-orientation char -> Dna: non-ACGT -> A, i.e. 3 in the cycle space of a reverse read)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { const uint32_t x = ~P[h].oh & M; ct[h] = cn[h] | ((x | (x << 1)) & rcm); }
+                // what a lane needs from its neighbours does not depend on the alignment: the read's code and the "N or outside the
+                // read" flag of the cycle in front of its first and behind its last one — once per row (round 3: four lane moves per pass)
+                const uint32_t ctp = lane_prev(ct[1]) & 3u, nbp = lane_prev(nb[1]) & 1u;
+                const uint32_t ctn = lane_next(ct[0]) & 0x30000000u, nbn = lane_next(nb[0]) & 0x10000000u;
                 uint32_t* tbin = lds + KL_TRIP + ((rc ? 2u : 0u) + mate) * 256u; // fwd1st fwd2nd rev1st rev2nd
-                // One triplet pass, in two steps so that the reference windows of several segments are in flight together.
-                // Read positions [ia, ib) are aligned at chromPos = posv + i.  issue: clip to the contig and the row, request the lane's
-                // reference window (nibbles r1 r0 ~r0 ~r1, one nibble early: k_short's "nibble index minus one"); false: nothing to do.
-                auto issue = [&](int64_t& ia, int64_t& ib, int64_t posv, uint32_t (&e)[3]) {
-                    if (1 - posv > ia) ia = 1 - posv;                       // context posv+i-1 .. posv+i+1 inside the contig
-                    if (reflen - 1 - posv < ib) ib = reflen - 1 - posv;
-                    if (ib <= ia || ib <= I0 || ia >= I1) return false;     // (wave-uniform)
-                    const int64_t pp = posv + o0 + 15 + 16 * (int64_t)sw;  // (the table has 16 pad nibbles in front)
-                    const int64_t di = min(max(pp >> 3, (int64_t)0), nd8 + 1);
-                    GVec<3>::lda(e, (const uint8_t*)(rn + di));
-                    return true;
-                };
-                auto eval = [&](int64_t ia, int64_t ib, int64_t posv, const uint32_t (&e)[3]) {
-                    const int32_t ja32 = (int32_t)(rc ? (int64_t)L - ib : ia), jb32 = (int32_t)(rc ? (int64_t)L - ia : ib); // the same range in cycles
-                    const uint32_t ja = (uint32_t)min(max(ja32 - c_lo, 0), 16), jb = (uint32_t)min(max(jb32 - c_lo, 0), 16);
-                    const uint32_t pp = (uint32_t)((int32_t)posv + o0 + 15 + 16 * sw);
-                    uint32_t E[2];
-                    {
-                        const uint32_t sh = 28u - 4u * (pp & 7u);
-                        uint32_t F[2];
+                auto eval = [&](uint32_t kab, uint32_t pp, const uint32_t (&e)[4]) {
+                    const uint32_t ja = (uint32_t)min(max((int32_t)(kab & 0xFFFFu) - (int32_t)w16, 0), 16), jb = (uint32_t)min(max((int32_t)(kab >> 16) - (int32_t)w16, 0), 16);
+                    const uint32_t sh = 28u - 4u * (pp & 7u);
+                    uint32_t G[3], E[2], Ep, En; // Ep: the reference nibble of the cycle in front of the lane's first (bits 3:0), En: behind its last (bits 31:28)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) F[h] = alignbit(e[h], e[h + 1], sh);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) E[h] = rc ? __brev(F[1 - h]) : F[h];
-                    }
-                    uint32_t I[4], bad[4]; // [1 .. 2] = this lane, [0] / [3] = the last / first dword of its neighbours
+                    for (int h = 0; h < 3; ++h) G[h] = alignbit(e[h], e[h + 1], sh);
+                    const uint32_t pv = e[0] >> sh;
+                    if (rc) { E[0] = __brev(G[1]); E[1] = __brev(G[0]); Ep = __brev(G[2]); En = __brev(pv); }
+                    else { E[0] = G[0]; E[1] = G[1]; Ep = pv; En = G[2]; }
+                    uint32_t I[4], bad[4]; // [1 .. 2] = this lane, [0] / [3] = the cycle in front / behind (low / top nibble)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         I[h + 1] = (E[h] & 0xCCCCCCCCu) | ct[h]; // nibble = [r c]
                         const uint32_t t = I[h + 1] ^ (I[h + 1] >> 2);
                         bad[h + 1] = ((t | (t >> 1)) & M) | nb[h]; // as a flank: mismatch or N
                     }
-                    bad[0] = lane_prev(bad[2]); bad[3] = lane_next(bad[1]);
-                    I[0] = lane_prev(I[2]); I[3] = lane_next(I[1]);
+                    I[0] = (Ep & 0xCu) | ctp;
+                    { const uint32_t t = I[0] ^ (I[0] >> 2); bad[0] = ((t | (t >> 1)) & 1u) | nbp; }
+                    I[3] = (En & 0xC0000000u) | ctn;
+                    { const uint32_t t = I[3] ^ (I[3] >> 2); bad[3] = ((t | (t >> 1)) & 0x10000000u) | nbn; }
                     uint32_t pa[2], pb[2];
                     kl_lut_nib(pa, LUT + 8u * ja);
                     kl_lut_nib(pb, LUT + 8u * jb);
@@ -409,63 +509,34 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
 #pragma unroll
                             for (int t = 0; t < 8; ++t) { // bin = c(j-1) r(j) c(j) r(j+1): 8 contiguous bits of the [r c] stream
                                 const uint32_t ix = t < 6 ? bfe(SA, 20 - 4 * t, 8) : bfe(SB, 12 - 4 * (t - 6), 8);
-                                if (ok[h] & (1u << (28 - 4 * t))) atomicAdd(tbin + ix, 1u);
+                                // (a cycle that does not count adds 0: a branch per cycle was two scalar and two vector instructions more
+                                // than the atomic itself, sixteen times a pass)
+                                __hip_atomic_fetch_add(tbin + ix, bfe(ok[h], 28 - 4 * t, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                         }
                     }
                 };
-                const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw) >> 4; // operation 0 sits in lane 0
-                if (n0 == 0u) {
-                    // cigarCount starts at (size_t)-1: every position counts as inside the first operation (:203)
-                    if (pos0 > -(1 << 30) && pos0 < (1 << 30)) {
-                        int64_t ia = 1, ib = (int64_t)L - 1;
-                        uint32_t e[3];
-                        if (issue(ia, ib, pos0, e)) eval(ia, ib, pos0, e);
+                if (t_any) {
+                    eval(t_kab[0], t_pp[0], t_e0);
+                    if (t_two) eval(t_kab[1], t_pp[1], t_e1);
+                }
+                // what is left: lanes touched by three or more segments (rare), operations 64 and up (long CIGARs)
+                auto passes = [&](uint64_t todo, uint32_t kab_s, uint32_t U_s, uint32_t wm) {
+                    while (todo) {
+                        uint32_t kab[2], U[2], have, pp0, pp1 = 0, e0[4], e1[4] = {0, 0, 0, 0};
+                        todo = collect(todo, kab_s, U_s, wm, kab, U, have);
+                        const bool two = __ballot(have >= 2u) != 0;
+                        issue(U[0], pp0, e0);
+                        if (two) issue(U[1], pp1, e1);
+                        eval(kab[0], pp0, e0);
+                        if (two) eval(kab[1], pp1, e1);
                     }
-                } else {
-                    // The walk of :207-222, by the whole wave: operation kb + ln in lane ln.  Read / chromosome advance of every
-                    // operation (the first one is taken as match-like whatever it is), exclusive prefix sums by DPP scans (the
-                    // chromosome advance as two 16-bit halves: 64 operations of up to 2^28 positions), then the match-like ones that
-                    // reach into the row: one pass each, their reference windows requested three at a time.
-                    int64_t rp_c = 0, cp_c = 0; // positions in front of the current block of 64 operations
-                    for (uint32_t kb = 0; kb < ncig && rp_c < (int64_t)L; kb += 64u) {
-                        const uint32_t kk = kb + ln;
-                        const uint32_t wv = kb == 0u ? cw : (kk < ncig ? cg[kk] : 0u), op = wv & 15u, nn = wv >> 4;
-                        const bool live = kk < ncig;
-                        const bool ref_only = live && kk != 0u && (op == 2u || op == 3u || op == 5u || op == 6u); // D N H P
-                        const bool read_only = live && kk != 0u && (op == 4u || op == 1u);                         // S I
-                        const bool match = live && !ref_only && !read_only;
-                        const uint32_t ra = (live && !ref_only) ? min(nn, L + 1u) : 0u, ca = (live && !read_only) ? nn : 0u;
-                        const uint32_t ra_i = wave_scan_incl(ra), cl_i = wave_scan_incl(ca & 0xFFFFu), ch_i = wave_scan_incl(ca >> 16);
-                        const int64_t rp = rp_c + (ra_i - ra), cp = cp_c + (int64_t)(cl_i - (ca & 0xFFFFu)) + ((int64_t)(ch_i - (ca >> 16)) << 16);
-                        // segment of a match-like operation: read positions [ia, ib) at chromPos = posv + i
-                        const int64_t ia = rp > 1 ? rp : 1, ib = rp + nn < (int64_t)L - 1 ? rp + nn : (int64_t)L - 1;
-                        const int64_t posv = pos0 + cp - rp;
-                        const bool seg = match && rp < (int64_t)L && ia < ib && posv > INT32_MIN / 2 && posv < INT32_MAX / 2 && ia < I1 && ib > I0;
-                        uint64_t todo = __ballot(seg);
-                        while (todo) {
-                            int64_t A[3], B[3], V[3];
-                            uint32_t e[3][3];
-                            bool go[3];
-#pragma unroll
-                            for (int g = 0; g < 3; ++g) {
-                                go[g] = todo != 0;
-                                if (go[g]) {
-                                    const int src = __ffsll((unsigned long long)todo) - 1;
-                                    todo &= todo - 1;
-                                    A[g] = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ia, src);
-                                    B[g] = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ib, src);
-                                    V[g] = (int64_t)__builtin_amdgcn_readlane((int)(int32_t)posv, src);
-                                    go[g] = issue(A[g], B[g], V[g], e[g]);
-                                }
-                            }
-#pragma unroll
-                            for (int g = 0; g < 3; ++g)
-                                if (go[g]) eval(A[g], B[g], V[g], e[g]);
-                        }
-                        rp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ra_i, 63);
-                        cp_c += (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)cl_i, 63) + ((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)ch_i, 63) << 16);
-                    }
+                };
+                passes(t_todo, t_kab_s, t_U_s, t_wm);
+                for (uint32_t kb = 64u; kb < ncig && rp_c < (int64_t)L; kb += 64u) {
+                    uint32_t kab_s, U_s;
+                    const uint64_t todo = scan_block(kb, kab_s, U_s);
+                    passes(todo, kab_s, U_s, 0u);
                 }
             }
             }
@@ -476,6 +547,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
 #pragma unroll
             for (int d = 0; d < 4; ++d) q[d] = q_n[d];
             cw = cw_n;
+            ro = ro_n;
             nxt_m = nn_m;
         }
     }

@@ -159,6 +159,54 @@ def test_triplet_contig_edges_and_segments():
     assert_parity(synth.concat(recs), [ref], n_lanes=3, hist_cap=1024, max_read_len=512)
 
 
+def test_long_reads_many_short_segments_per_lane():
+    """k_long hands the CIGAR's match-like segments to the lanes that hold the cycles (two per lane and pass): reads of several rows
+    whose segments are shorter than a lane's 16 cycles (three and more per lane: the extra rounds), segments straddling lanes and rows,
+    more than 64 operations (several blocks), both strands, reads that hang over the contig's ends."""
+    rng = np.random.default_rng(44)
+    reflen = 9000
+    ref = rng.integers(0, 4, size=reflen).astype(np.uint8)
+    ok = P | PR
+    recs = []
+    for trial in range(120):
+        L = int(rng.choice([300, 993, 1500, 2100, 3000]))
+        kind = trial % 4
+        ops, left = [], L
+        while left > 0:
+            if kind == 0: m = int(rng.integers(1, 6))          # very short segments
+            elif kind == 1: m = int(rng.integers(1, 40))
+            elif kind == 2: m = int(rng.choice([15, 16, 17, 31, 32, 33]))
+            else: m = int(rng.integers(100, 600))
+            m = min(m, left)
+            ops.append((m, "M=X"[int(rng.integers(0, 3))]))
+            left -= m
+            if left <= 0: break
+            r = rng.random()
+            if r < 0.4: ops.append((int(rng.integers(1, 4)), "D"))
+            elif r < 0.8:
+                k = min(int(rng.integers(1, 4)), left)
+                ops.append((k, "I")); left -= k
+            else: ops.append((int(rng.integers(1, 30)), "N"))
+            if len(ops) > 600: ops.append((left, "M")); left = 0
+        span = sum(n for n, c in ops if c in "M=XDN")
+        pos = int(rng.choice([0, 1, max(reflen - span - 1, 0), max(reflen - span // 2, 0), int(rng.integers(0, max(reflen - span, 1)))]))
+        # the read follows the reference along its CIGAR (so that triplets do get counted), with a few errors and N
+        codes, rp = [], pos
+        for n, c in ops:
+            if c in "M=X": codes.extend(np.pad(ref, (0, 5000))[rp:rp + n].tolist()); rp += n
+            elif c == "I": codes.extend(rng.integers(0, 4, n).tolist())
+            else: rp += n
+        codes = np.array(codes[:L] + [0] * (L - len(codes)), np.int64)
+        err = rng.random(L) < 0.02
+        codes[err] = rng.integers(0, 5, int(err.sum()))
+        seq = "".join("ACGTN"[int(c)] for c in codes)
+        q = rng.integers(15, 45, size=L).tolist()
+        nm = sum(n for n, c in ops if c in "ID")
+        flag = ok | (REV if trial & 4 else 0) | (FIRST if trial & 8 else LAST)
+        recs.append(synth.single_read(seq, q, ops, flag, pos=pos, mapq=60, as_=90, nm=nm, lane=trial % 2))
+    assert_parity(synth.concat(recs), [ref], n_lanes=2, hist_cap=4096, max_read_len=4096, isize=5000)
+
+
 def test_error_codes_match():
     ref = np.zeros(1000, np.uint8)
     ok = P | PR | FIRST
