@@ -31,9 +31,20 @@
 #define KL_EXPER  0                                // timing experiments only (results are wrong): 1 no triplets, 2 no 8-mers, 4 no per-cycle counters / per-read sums
 #endif
 
-__device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0)
+// The packed 8-mer counters go into the next free row of the workgroup's slot of the scratch table k_short's workgroups use (plain
+// 16-byte stores of the LDS image; k_t8_fold sums the rows of all slots into the state vector later) when the read group is the one
+// the table collects; with global atomics otherwise.  Round 4: with atomics only, every workgroup ended in 65 536 scattered 8-byte
+// atomic adds — 16.6 M per launch on config 5, 0.3 of the kernel's 1.4 ms.  Returns true when a row was written.
+__device__ __forceinline__ bool kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0,
+                                         uint4* __restrict__ slot /* nullptr: atomics */, uint32_t n_rows_used)
 {
     const uint64_t lb = sl.lane_base(lane);
+    const bool to_row = slot && n_rows_used < BQC_T8_SPW;
+    if (to_row) {
+        uint4* row = slot + (size_t)n_rows_used * 4096u;
+        uint4* src = (uint4*)(lds + KL_T8);
+        for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) { row[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
+    } else
     for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) { // packed counters: byte b of dword i is bin 4 i + ((4 - b) & 3)
         const uint32_t v = lds[KL_T8 + i];
         if (!v) continue;
@@ -61,6 +72,7 @@ __device__ __forceinline__ void kl_flush(uint32_t* lds, const StateLayout& sl, u
         const uint32_t j = cyc0 + 16u * (w - 1u) + t;
         if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
     }
+    return to_row;
 }
 
 // Per-cycle accumulators of one lane (its 16 cycles), for the reads of ONE mate: 4-bit vertical counters per base plane
@@ -122,15 +134,22 @@ __device__ __forceinline__ void kl_lut_nib(uint32_t (&d)[2], const uint32_t* e) 
 __device__ __forceinline__ void kl_lut_byte(uint32_t (&d)[4], const uint32_t* e) { const uint4 v = *(const uint4*)e; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
 
 __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
-                                                            uint32_t* __restrict__ err, uint32_t* __restrict__ rsum /* [n_reads][3] */)
+                                                            uint32_t* __restrict__ err, uint32_t* __restrict__ rsum /* [n_reads][3] */,
+                                                            uint4* __restrict__ t8rows, uint32_t* __restrict__ t8_used, uint32_t t8_lane)
 {
     extern __shared__ uint32_t lds[];
+    const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x; // this workgroup's slot of the scratch rows
     if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KL_T8 at LDS address 0)
-        if (threadIdx.x == 0) atomicOr(err, BQC_DEVERR_INTERNAL);
+        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[wg] = 0; }
         return;
     }
     const uint32_t cyc0 = blockIdx.y * KL_ROW;
-    if (cyc0 >= b.desc->long_max_len) return; // no read of the batch reaches this row (the grid is sized from an upper bound)
+    if (cyc0 >= b.desc->long_max_len) { // no read of the batch reaches this row (the grid is sized from an upper bound)
+        if (threadIdx.x == 0) t8_used[wg] = 0;
+        return;
+    }
+    uint4* const t8_slot = t8rows + (size_t)wg * BQC_T8_SPW * 4096u;
+    uint32_t t8_n = 0; // rows written so far
     for (uint32_t i = threadIdx.x; i < KL_WORDS; i += blockDim.x) lds[i] = 0;
     block_sync();
     const uint32_t M = 0x11111111u;
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 if (own) { kl_spill(A0, lds, 0, w); kl_qflush(A0, lds, 0, w); kl_spill(A1, lds, 1, w); kl_qflush(A1, lds, 1, w); }
                 n1[0] = n1[1] = n2[0] = n2[1] = 0;
                 block_sync();
-                kl_flush(lds, sl, state, cur_lane, cyc0);
+                t8_n += kl_flush(lds, sl, state, cur_lane, cyc0, cur_lane == t8_lane ? t8_slot : nullptr, t8_n) ? 1u : 0u;
                 block_sync();
             }
             cur_lane = ch.lane;
@@ -339,7 +358,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 if (t_todo) {
                     uint32_t U[2], have;
                     t_todo = collect(t_todo, t_kab_s, t_U_s, t_wm, t_kab, U, have);
-                    t_two = __ballot(have >= 2u) != 0;
+                    t_two = !(KL_EXPER & 64) && __ballot(have >= 2u) != 0; // (64: no second pass)
                     t_any = true;
                     issue(U[0], t_pp[0], t_e0);
                     if (t_two) issue(U[1], t_pp[1], t_e1);
@@ -409,7 +428,15 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                     for (int kw = 0; kw < 16; ++kw) {
                         const uint32_t h = kw < 8 ? c32 >> (16 - 2 * kw) : kw == 8 ? c32 : alignbit(c32, cx, 48 - 2 * kw);
                         const uint32_t one = bfe(f[kw >> 3], 28 - 4 * (kw & 7), 1);
+#if KL_EXPER & 8   // the atomics without their returned values
+                        old[kw] = 0; __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif KL_EXPER & 16 // the arithmetic without the atomics (and without the checks: the values never look hot)
+                        old[kw] = ((h & 0xFFFCu) + alignbyte(one, one, h)) & 0x7F7F7F7Fu;
+#elif KL_EXPER & 128 // neither: what is in front of the loop only
+                        old[kw] = 0; if (kw == 0) old[0] = (c32 ^ cx ^ f[0] ^ f[1]) & 0x7F7F7F7Fu;
+#else
                         old[kw] = __hip_atomic_fetch_add(lds_at(h & 0xFFFCu), alignbyte(one, one, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                     }
                 }
             }
@@ -511,9 +538,16 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                                 const uint32_t ix = t < 6 ? bfe(SA, 20 - 4 * t, 8) : bfe(SB, 12 - 4 * (t - 6), 8);
                                 // (a cycle that does not count adds 0: a branch per cycle was two scalar and two vector instructions more
                                 // than the atomic itself, sixteen times a pass)
+#if KL_EXPER & 32 // the passes without their atomics
+                                okany += ix + bfe(ok[h], 28 - 4 * t, 1);
+#else
                                 __hip_atomic_fetch_add(tbin + ix, bfe(ok[h], 28 - 4 * t, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                             }
                         }
+#if KL_EXPER & 32
+                        if (okany == 0x12345u) atomicAdd(tbin, 1u); // (keeps the arithmetic alive)
+#endif
                     }
                 };
                 if (t_any) {
@@ -551,6 +585,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             nxt_m = nn_m;
         }
     }
+    if (threadIdx.x == 0) t8_used[wg] = t8_n; // rows of this workgroup's slot that k_t8_fold has to read
 }
 
 // per-read histograms from the sums (QualityCheck.hpp:157-165): thread per read of the generic chunks
@@ -583,17 +618,34 @@ extern "C" hipError_t bqc_long_init()
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_long), hipFuncAttributeMaxDynamicSharedMemorySize, KL_WORDS * 4);
 }
 
-// n_chunks_ub / max_len_ub: host-side upper bounds (the exact values are in the batch descriptor on the device)
+static void kl_grid(uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, uint32_t& gx, uint32_t& rows)
+{
+    rows = max_len_ub ? (max_len_ub + KL_ROW - 1) / KL_ROW : 1u;
+    gx = n_cu / rows ? n_cu / rows : 1u; // one workgroup per CU (119 KB of LDS each): gx * rows <= n_cu where possible
+    if (gx > n_chunks_ub) gx = n_chunks_ub;
+}
+
+// workgroups (= slots of the 8-mer scratch rows) a launch with these bounds has
+extern "C" uint32_t bqc_long_slots(uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu)
+{
+    if (n_chunks_ub == 0) return 0;
+    uint32_t gx, rows;
+    kl_grid(max_len_ub, n_chunks_ub, n_cu, gx, rows);
+    return gx * rows;
+}
+
+// n_chunks_ub / max_len_ub: host-side upper bounds (the exact values are in the batch descriptor on the device); t8rows / t8_used:
+// bqc_long_slots() slots of the scratch table
 extern "C" void bqc_launch_long(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, hipStream_t s)
+                                uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, uint32_t* t8rows, uint32_t* t8_used,
+                                uint32_t t8_lane, hipStream_t s)
 {
     if (n_chunks_ub == 0) return;
     static const hipError_t attr_once = bqc_long_init(); // (at the first launch: see bqc_launch_short)
     (void)attr_once;
-    const uint32_t rows = max_len_ub ? (max_len_ub + KL_ROW - 1) / KL_ROW : 1u;
-    uint32_t gx = n_cu / rows ? n_cu / rows : 1u; // one workgroup per CU (119 KB of LDS each): gx * rows <= n_cu where possible
-    if (gx > n_chunks_ub) gx = n_chunks_ub;
-    hipLaunchKernelGGL(k_long, dim3(gx, rows), dim3(KL_WAVES * 64), KL_WORDS * 4, s, b, sl, state, refs, err, rsum);
+    uint32_t gx, rows;
+    kl_grid(max_len_ub, n_chunks_ub, n_cu, gx, rows);
+    hipLaunchKernelGGL(k_long, dim3(gx, rows), dim3(KL_WAVES * 64), KL_WORDS * 4, s, b, sl, state, refs, err, rsum, (uint4*)t8rows, t8_used, t8_lane);
     const uint32_t g2 = n_chunks_ub < n_cu * 8 ? n_chunks_ub : n_cu * 8;
     hipLaunchKernelGGL(k_long_finish, dim3(g2), dim3(256), 0, s, b, sl, state, rsum);
 }

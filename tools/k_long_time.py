@@ -21,6 +21,15 @@ for it in range(8):
         if it >= 2:
             kt.setdefault(k, []).append(v)
 agg.sync()
+# the same without per-kernel events: everything a batch costs the stream, the deferred fold of the 8-mer scratch rows included
+import time
+agg.set_timing(False)
+t0 = time.perf_counter()
+for it in range(16):
+    agg.process(db)
+agg.sync()
+print("16 batches back to back, synchronised at the end: %.3f ms per batch (all kernels of a batch and the folds)" % ((time.perf_counter() - t0) * 1e3 / 16))
+agg.set_timing(True)
 ab = db.algorithmic_bytes
 print("reads %d x %d bases, CIGAR operations per read %.1f, algorithmic bytes %.1f MB" % (n, L, len(cols["cigar"]) / n, ab / 1e6))
 for k, v in kt.items():
