@@ -131,6 +131,8 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     c->t8_slots_cap = std::max(1024u, 4u * c->n_cu);
     CCHK(hipMalloc(&c->d_t8rows, (size_t)c->t8_slots_cap * BQC_T8_SPW * 65536));
     CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * 4));
+    CCHK(hipMalloc(&c->d_kl_cyc, (size_t)c->n_cu * 2 * 6 * 1024 * 4));
+    CCHK(hipMalloc(&c->d_kl_cyc_used, (size_t)c->n_cu * 4));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
     CCHK(hipMalloc(&c->d_parity, ((size_t)opt->n_lanes + 1) * 4));
     CCHK(hipMalloc(&c->d_started, opt->n_lanes));
@@ -248,7 +250,7 @@ extern "C" void bqc_destroy(bqc_ctx* c)
 
     (void)hipFree(c->d_refn_ptrs);
     if (c->sketch) sketch_destroy(c->sketch);
-    (void)hipFree(c->d_state); (void)hipFree(c->d_err0); (void)hipFree(c->d_cursor); (void)hipFree(c->d_fasta_index); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_t8used); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
+    (void)hipFree(c->d_state); (void)hipFree(c->d_err0); (void)hipFree(c->d_cursor); (void)hipFree(c->d_fasta_index); (void)hipFree(c->d_t8rows); (void)hipFree(c->d_t8used); (void)hipFree(c->d_kl_cyc); (void)hipFree(c->d_kl_cyc_used); (void)hipFree(c->d_carry); (void)hipFree(c->d_parity);
     (void)hipFree(c->d_started); (void)hipFree(c->d_ref_ptrs); (void)hipFree(c->d_ref_len); (void)hipFree(c->d_main);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);

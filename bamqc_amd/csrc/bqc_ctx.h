@@ -150,6 +150,9 @@ struct bqc_ctx {
     // needs it.  (kT8Slots * BQC_T8_SPW * 64 KiB = 512 MiB of the 288 GB.)
     uint32_t* d_t8rows = nullptr;
     uint32_t* d_t8used = nullptr;
+    // per-cycle counter tiles of k_long's workgroups (48 KiB each; d_kl_cyc_used[wg] = written), summed by k_long_cyc_fold in the same launch
+    uint32_t* d_kl_cyc = nullptr;
+    uint32_t* d_kl_cyc_used = nullptr;
     uint32_t t8_slots_used = 0, t8_slots_cap = 0;
     uint32_t t8_rows_lane = 0;
     std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)

@@ -21,7 +21,7 @@
 extern "C" {
 void bqc_launch_reads_chunks(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t fast_table, hipStream_t);
 void bqc_launch_nm_extra(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, hipStream_t);
-void bqc_launch_long(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t);
+void bqc_launch_long(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, uint32_t* cyc_tiles, uint32_t* cyc_used, hipStream_t);
 uint32_t bqc_long_slots(uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu);
 void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* carry, uint32_t* parity, const uint8_t* lane_mask, uint8_t* started,
                     const uint8_t* started_after, uint32_t n_lanes, hipStream_t);
@@ -523,7 +523,7 @@ static int enqueue_kernels(bqc_ctx* c, BatchMem& m)
         const uint32_t slots = bqc_long_slots(m.max_len_slow, m.n_chunks_slow_ub, c->n_cu); // a slot of 8-mer scratch rows per workgroup, as for k_short
         if (c->t8_rows_lane != m.t8_lane || c->t8_slots_used + slots > c->t8_slots_cap) { bqc_state_ready(c); c->t8_rows_lane = m.t8_lane; }
         bqc_launch_long(d, c->sl, c->d_state, refs, err, m.d_rsum, m.max_len_slow, m.n_chunks_slow_ub, c->n_cu,
-                        c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + c->t8_slots_used, m.t8_lane, c->stream);
+                        c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + c->t8_slots_used, m.t8_lane, c->d_kl_cyc, c->d_kl_cyc_used, c->stream);
         c->t8_slots_used += slots;
         tick(c, "k_long");
     }

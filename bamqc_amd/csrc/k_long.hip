@@ -35,8 +35,10 @@
 // 16-byte stores of the LDS image; k_t8_fold sums the rows of all slots into the state vector later) when the read group is the one
 // the table collects; with global atomics otherwise.  Round 4: with atomics only, every workgroup ended in 65 536 scattered 8-byte
 // atomic adds — 16.6 M per launch on config 5, 0.3 of the kernel's 1.4 ms.  Returns true when a row was written.
+// The per-cycle tile likewise: its first flush for that read group goes, as it is, into the workgroup's place of a scratch array that
+// k_long_cyc_fold sums over the workgroups of a row (they all count the same cycles: 23 workgroups' atomics on the same words).
 __device__ __forceinline__ bool kl_flush(uint32_t* lds, const StateLayout& sl, uint64_t* __restrict__ state, uint32_t lane, uint32_t cyc0,
-                                         uint4* __restrict__ slot /* nullptr: atomics */, uint32_t n_rows_used)
+                                         uint4* __restrict__ slot /* nullptr: atomics */, uint32_t n_rows_used, uint4* __restrict__ cyc_tile /* nullptr: atomics */)
 {
     const uint64_t lb = sl.lane_base(lane);
     const bool to_row = slot && n_rows_used < BQC_T8_SPW;
@@ -63,7 +65,11 @@ __device__ __forceinline__ bool kl_flush(uint32_t* lds, const StateLayout& sl, u
         else { ctx = ((3u - f0) << 4) | ((3u - f2) << 2) | (3u - f3); base = 3u - f1; }                // reverse: complement, mirrored
         gadd(state + lb + sl.o_triplet + ctx * 16u + grp * 4u + base, v);
     }
-    for (uint32_t i = threadIdx.x; i < 2 * 6 * 1024; i += blockDim.x) {
+    if (cyc_tile) {
+        uint4* src = (uint4*)(lds + KL_CYC);
+        for (uint32_t i = threadIdx.x; i < 2 * 6 * 1024 / 4; i += blockDim.x) { cyc_tile[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
+    } else
+    for (uint32_t i = threadIdx.x; i < ((KL_EXPER & 256) ? 0 : 2 * 6 * 1024); i += blockDim.x) { // (256: timing without this flush)
         const uint32_t v = lds[KL_CYC + i];
         if (!v) continue;
         lds[KL_CYC + i] = 0;
@@ -87,41 +93,44 @@ __device__ __forceinline__ void kl_zero(KlAcc& A)
 #pragma unroll
     for (int d = 0; d < 4; ++d) { A.qo[d] = 0; A.qe[d] = 0; }
 }
-__device__ __noinline__ void kl_spill_half(uint32_t a, uint32_t c, uint32_t g, uint32_t t, uint32_t* base /* tile + w + 64 * 8 * half */)
+// (the tiles are addressed by their LDS byte address — the dynamic LDS starts at address 0, checked at the kernel's start —: as
+// generic pointers the seven tile addresses a lane keeps were 14 registers, all of them spilled)
+template <uint32_t TILE /* word index of tile + 64 * 8 * half */> __device__ __noinline__ void kl_spill_half(uint32_t a, uint32_t c, uint32_t g, uint32_t t, uint32_t w)
 {
     const uint32_t v[4] = {a, c, g, t};
+    const uint32_t base = 4u * (TILE + w); // (computed here: kept by the caller, the compiler hoisted the eight addresses out of the read loop and spilled them)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) atomicAdd(base + p * 1024 + 64 * (7 - n), (v[p] >> (4 * n)) & 15u);
+        for (int n = 0; n < 8; ++n) __hip_atomic_fetch_add(lds_at(base + 4u * (p * 1024 + 64 * (7 - n))), (v[p] >> (4 * n)) & 15u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __noinline__ void kl_qflush_pair(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t* base /* tile + 5 * 1024 + w + 64 * 8 * half */)
+template <uint32_t TILE /* word index of tile + 5 * 1024 + 64 * 8 * half */> __device__ __noinline__ void kl_qflush_pair(uint32_t o0, uint32_t e0, uint32_t o1, uint32_t e1, uint32_t w)
 {
     const uint32_t vo[2] = {o0, o1}, ve[2] = {e0, e1};
+    const uint32_t base = 4u * (TILE + w);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        atomicAdd(base + 64 * (4 * d + 0), vo[d] >> 16);
-        atomicAdd(base + 64 * (4 * d + 1), ve[d] >> 16);
-        atomicAdd(base + 64 * (4 * d + 2), vo[d] & 0xFFFFu);
-        atomicAdd(base + 64 * (4 * d + 3), ve[d] & 0xFFFFu);
+        __hip_atomic_fetch_add(lds_at(base + 4u * (64 * (4 * d + 0))), vo[d] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(lds_at(base + 4u * (64 * (4 * d + 1))), ve[d] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(lds_at(base + 4u * (64 * (4 * d + 2))), vo[d] & 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(lds_at(base + 4u * (64 * (4 * d + 3))), ve[d] & 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
-__device__ __forceinline__ void kl_spill(KlAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
+template <uint32_t MATE> __device__ __forceinline__ void kl_spill(KlAcc& A, uint32_t w)
 {
+    kl_spill_half<KL_CYC + MATE * 6 * 1024>(A.l1[0][0], A.l1[0][1], A.l1[0][2], A.l1[0][3], w);
+    kl_spill_half<KL_CYC + MATE * 6 * 1024 + 64 * 8>(A.l1[1][0], A.l1[1][1], A.l1[1][2], A.l1[1][3], w);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        kl_spill_half(A.l1[h][0], A.l1[h][1], A.l1[h][2], A.l1[h][3], lds + KL_CYC + mate * 6 * 1024 + w + 64 * 8 * h);
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int p = 0; p < 4; ++p) A.l1[h][p] = 0;
-    }
 }
-__device__ __forceinline__ void kl_qflush(KlAcc& A, uint32_t* lds, uint32_t mate, uint32_t w)
+template <uint32_t MATE> __device__ __forceinline__ void kl_qflush(KlAcc& A, uint32_t w)
 {
+    kl_qflush_pair<KL_CYC + (MATE * 6 + 5) * 1024>(A.qo[0], A.qe[0], A.qo[1], A.qe[1], w);
+    kl_qflush_pair<KL_CYC + (MATE * 6 + 5) * 1024 + 64 * 8>(A.qo[2], A.qe[2], A.qo[3], A.qe[3], w);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        kl_qflush_pair(A.qo[2 * h], A.qe[2 * h], A.qo[2 * h + 1], A.qe[2 * h + 1], lds + KL_CYC + (mate * 6 + 5) * 1024 + w + 64 * 8 * h);
-        A.qo[2 * h] = A.qe[2 * h] = A.qo[2 * h + 1] = A.qe[2 * h + 1] = 0;
-    }
+    for (int d = 0; d < 4; ++d) { A.qo[d] = 0; A.qe[d] = 0; }
 }
 __device__ __forceinline__ void kl_add(KlAcc& A, const Planes (&P)[2], const uint32_t (&Q)[4])
 {
@@ -135,21 +144,24 @@ __device__ __forceinline__ void kl_lut_byte(uint32_t (&d)[4], const uint32_t* e)
 
 __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
                                                             uint32_t* __restrict__ err, uint32_t* __restrict__ rsum /* [n_reads][3] */,
-                                                            uint4* __restrict__ t8rows, uint32_t* __restrict__ t8_used, uint32_t t8_lane)
+                                                            uint4* __restrict__ t8rows, uint32_t* __restrict__ t8_used, uint32_t t8_lane,
+                                                            uint4* __restrict__ cyc_tiles, uint32_t* __restrict__ cyc_used)
 {
     extern __shared__ uint32_t lds[];
     const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x; // this workgroup's slot of the scratch rows
     if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KL_T8 at LDS address 0)
-        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[wg] = 0; }
+        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[wg] = 0; cyc_used[wg] = 0; }
         return;
     }
     const uint32_t cyc0 = blockIdx.y * KL_ROW;
     if (cyc0 >= b.desc->long_max_len) { // no read of the batch reaches this row (the grid is sized from an upper bound)
-        if (threadIdx.x == 0) t8_used[wg] = 0;
+        if (threadIdx.x == 0) { t8_used[wg] = 0; cyc_used[wg] = 0; }
         return;
     }
     uint4* const t8_slot = t8rows + (size_t)wg * BQC_T8_SPW * 4096u;
     uint32_t t8_n = 0; // rows written so far
+    uint4* const cyc_tile = cyc_tiles + (size_t)wg * (2 * 6 * 1024 / 4);
+    bool cyc_written = false;
     for (uint32_t i = threadIdx.x; i < KL_WORDS; i += blockDim.x) lds[i] = 0;
     block_sync();
     const uint32_t M = 0x11111111u;
@@ -184,10 +196,12 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
         if (!done) ch = b.chunks[ci];
         if (ch.lane != cur_lane) { // block-uniform
             if (cur_lane != 0xFFFFFFFFu) {
-                if (own) { kl_spill(A0, lds, 0, w); kl_qflush(A0, lds, 0, w); kl_spill(A1, lds, 1, w); kl_qflush(A1, lds, 1, w); }
+                if (own) { kl_spill<0>(A0, w); kl_qflush<0>(A0, w); kl_spill<1>(A1, w); kl_qflush<1>(A1, w); }
                 n1[0] = n1[1] = n2[0] = n2[1] = 0;
                 block_sync();
-                t8_n += kl_flush(lds, sl, state, cur_lane, cyc0, cur_lane == t8_lane ? t8_slot : nullptr, t8_n) ? 1u : 0u;
+                const bool tile_out = cur_lane == t8_lane && !cyc_written;
+                t8_n += kl_flush(lds, sl, state, cur_lane, cyc0, cur_lane == t8_lane ? t8_slot : nullptr, t8_n, tile_out ? cyc_tile : nullptr) ? 1u : 0u;
+                cyc_written |= tile_out;
                 block_sync();
             }
             cur_lane = ch.lane;
@@ -443,8 +457,8 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             // ---- per-cycle counters and the per-read sums (QualityCheck.hpp:122-166) — while the 8-mer counters' old values come back
             if (!(KL_EXPER & 4)) {
                 if (own) { if (mate) kl_add(A1, P, Q); else kl_add(A0, P, Q); }
-                if (++n1[mate] == 15u) { if (own) { if (mate) kl_spill(A1, lds, 1, w); else kl_spill(A0, lds, 0, w); } n1[mate] = 0; }
-                if (++n2[mate] == 255u) { if (own) { if (mate) kl_qflush(A1, lds, 1, w); else kl_qflush(A0, lds, 0, w); } n2[mate] = 0; }
+                if (++n1[mate] == 15u) { if (own) { if (mate) kl_spill<1>(A1, w); else kl_spill<0>(A0, w); } n1[mate] = 0; }
+                if (++n2[mate] == 255u) { if (own) { if (mate) kl_qflush<1>(A1, w); else kl_qflush<0>(A0, w); } n2[mate] = 0; }
                 uint32_t oany = 0, oth[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { oth[h] = own ? xm[h] & M & ~P[h].oh : 0u; oany |= oth[h]; }
@@ -585,7 +599,24 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             nxt_m = nn_m;
         }
     }
-    if (threadIdx.x == 0) t8_used[wg] = t8_n; // rows of this workgroup's slot that k_t8_fold has to read
+    if (threadIdx.x == 0) { t8_used[wg] = t8_n; cyc_used[wg] = cyc_written ? 1u : 0u; } // rows of this workgroup's slot that k_t8_fold has to read; its tile
+}
+
+// the per-cycle tiles of the workgroups of one row (blockIdx.y), summed and added to the read group's counters: thread per tile word
+__global__ __launch_bounds__(256) void k_long_cyc_fold(const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ used, uint32_t gx, StateLayout sl,
+                                                          uint64_t* __restrict__ state, uint32_t lane)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y; // i < 2 * 6 * 1024
+    uint64_t v = 0;
+    for (uint32_t x = 0; x < gx; ++x) {
+        const uint32_t wg = y * gx + x;
+        if (used[wg]) v += tiles[(size_t)wg * (2 * 6 * 1024) + i];
+    }
+    if (!v) return;
+    const uint32_t m = i / (6 * 1024), c = (i / 1024) % 6, jj = i % 1024, w = jj % 64, t = jj / 64;
+    if (w == 0 || w == 63) return; // (never written)
+    const uint32_t j = y * KL_ROW + 16u * (w - 1u) + t;
+    if (j < sl.lcap) gadd(state + sl.mate_base(lane, m) + (c < 5 ? sl.m_dnacount + c * sl.lcap : sl.m_qualcount) + j, v);
 }
 
 // per-read histograms from the sums (QualityCheck.hpp:157-165): thread per read of the generic chunks
@@ -638,14 +669,15 @@ extern "C" uint32_t bqc_long_slots(uint32_t max_len_ub, uint32_t n_chunks_ub, ui
 // bqc_long_slots() slots of the scratch table
 extern "C" void bqc_launch_long(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
                                 uint32_t* rsum, uint32_t max_len_ub, uint32_t n_chunks_ub, uint32_t n_cu, uint32_t* t8rows, uint32_t* t8_used,
-                                uint32_t t8_lane, hipStream_t s)
+                                uint32_t t8_lane, uint32_t* cyc_tiles /* [slots][2 * 6 * 1024] */, uint32_t* cyc_used, hipStream_t s)
 {
     if (n_chunks_ub == 0) return;
     static const hipError_t attr_once = bqc_long_init(); // (at the first launch: see bqc_launch_short)
     (void)attr_once;
     uint32_t gx, rows;
     kl_grid(max_len_ub, n_chunks_ub, n_cu, gx, rows);
-    hipLaunchKernelGGL(k_long, dim3(gx, rows), dim3(KL_WAVES * 64), KL_WORDS * 4, s, b, sl, state, refs, err, rsum, (uint4*)t8rows, t8_used, t8_lane);
+    hipLaunchKernelGGL(k_long, dim3(gx, rows), dim3(KL_WAVES * 64), KL_WORDS * 4, s, b, sl, state, refs, err, rsum, (uint4*)t8rows, t8_used, t8_lane, (uint4*)cyc_tiles, cyc_used);
+    hipLaunchKernelGGL(k_long_cyc_fold, dim3(2 * 6 * 1024 / 256, rows), dim3(256), 0, s, cyc_tiles, cyc_used, gx, sl, state, t8_lane);
     const uint32_t g2 = n_chunks_ub < n_cu * 8 ? n_chunks_ub : n_cu * 8;
     hipLaunchKernelGGL(k_long_finish, dim3(g2), dim3(256), 0, s, b, sl, state, rsum);
 }
