@@ -130,7 +130,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     }
     c->t8_slots_cap = std::max(1024u, 4u * c->n_cu);
     CCHK(hipMalloc(&c->d_t8rows, (size_t)c->t8_slots_cap * BQC_T8_SPW * 65536));
-    CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * 4));
+    CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * BQC_T8_USED * 4));
     CCHK(hipMalloc(&c->d_kl_cyc, (size_t)c->n_cu * 2 * 6 * 1024 * 4));
     CCHK(hipMalloc(&c->d_kl_cyc_used, (size_t)c->n_cu * 4));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));

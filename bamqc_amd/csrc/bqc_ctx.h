@@ -31,7 +31,7 @@ struct HostPass {
     uint32_t n = 0;
     uint64_t seq_bytes = 0, qual_bytes = 0, cigar_words = 0;
     uint32_t n_slow = 0, max_len_slow = 0;  // reads for the generic kernels, the longest of them
-    uint32_t t8_lane = 0;                   // read group with the most reads: its 8-mer counts go through the scratch rows
+    uint32_t t8_lane = 0;                   // read group with the most reads (k_long: its per-cycle tiles go through the scratch array)
     bool multi_lane = false;
     raw_vector<CovEntry> cov;               // [n] anchors {win, pos} / BQC_COV_NONE
     raw_vector<uint32_t> order;             // [n] reads grouped by read group (only when multi_lane)
@@ -62,6 +62,7 @@ struct BatchMem {
     ErrRec* d_err = nullptr;
     uint64_t algo_bytes = 0;
     uint32_t n_slow = 0, max_len_slow = 0, n_chunks_slow_ub = 0, t8_lane = 0;
+    uint64_t lane_bits[4] = {0, 0, 0, 0}; // read groups the batch holds (their 8-mer counts may be in the scratch rows after its kernels)
     bool processed = false;
     // where the pieces of the host-side image go (offsets into dmem; the staged image has the same layout from h2d_begin on)
     size_t h2d_begin = 0, h2d_end = 0;   // the contiguous part that is copied from the staging image
@@ -154,7 +155,7 @@ struct bqc_ctx {
     uint32_t* d_kl_cyc = nullptr;
     uint32_t* d_kl_cyc_used = nullptr;
     uint32_t t8_slots_used = 0, t8_slots_cap = 0;
-    uint32_t t8_rows_lane = 0;
+    uint64_t t8_lanes[4] = {0, 0, 0, 0}; // read groups (bit per lane) of the batches whose rows are in the table
     std::vector<std::pair<void*, size_t>> pool; // device buffers of freed batches, reused by bqc_upload (hipMalloc / hipFree cost milliseconds)
     uint32_t* d_carry = nullptr;  // [lane][2][2000]
     uint32_t* d_parity = nullptr; // [lane], then the count of finished workgroups of the running k_cov

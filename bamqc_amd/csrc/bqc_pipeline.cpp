@@ -27,7 +27,7 @@ void bqc_launch_cov(const DevBatch&, const StateLayout&, uint64_t*, uint32_t* ca
                     const uint8_t* started_after, uint32_t n_lanes, hipStream_t);
 void bqc_launch_add_words(uint64_t* state, const uint64_t* idx, const uint64_t* val, uint32_t n, hipStream_t);
 void bqc_launch_or_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, hipStream_t);
-void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t);
+void bqc_launch_short(const DevBatch&, const StateLayout&, uint64_t*, const DevRefs&, uint32_t*, uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, hipStream_t);
 uint32_t bqc_short_parts();
 void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout&, uint64_t* state, uint32_t lane, hipStream_t);
 void bqc_launch_err_merge(ErrRec* dst, const ErrRec* src, hipStream_t);
@@ -52,7 +52,9 @@ int bqc_copy_stream(bqc_ctx* c)
 void bqc_state_ready(bqc_ctx* c)
 {
     if (!c->t8_slots_used) return;
-    bqc_launch_t8_fold(c->d_t8rows, c->d_t8used, c->t8_slots_used, c->sl, c->d_state, c->t8_rows_lane, c->stream);
+    for (uint32_t l = 0; l < c->opt.n_lanes; ++l) // one pass over the slots' directory per read group that may have rows
+        if (c->t8_lanes[l >> 6] >> (l & 63u) & 1ull) bqc_launch_t8_fold(c->d_t8rows, c->d_t8used, c->t8_slots_used, c->sl, c->d_state, l, c->stream);
+    c->t8_lanes[0] = c->t8_lanes[1] = c->t8_lanes[2] = c->t8_lanes[3] = 0;
     c->t8_slots_used = 0;
 }
 
@@ -447,6 +449,8 @@ static int layout_batch(bqc_ctx* c, BatchMem& m, const bqc_batch* b, const HostP
     m.d_err = p.err;
     m.algo_bytes = 48ull * n + H.seq_bytes + H.qual_bytes + 4 * H.cigar_words; // A(L,n) of SURVEY.md §8d summed over the batch
     m.n_slow = H.n_slow; m.max_len_slow = H.max_len_slow; m.n_chunks_slow_ub = (uint32_t)cs_cap; m.t8_lane = H.t8_lane;
+    m.lane_bits[0] = m.lane_bits[1] = m.lane_bits[2] = m.lane_bits[3] = 0;
+    for (size_t l = 0; l < H.lane_count.size() && l < 256; ++l) if (H.lane_count[l]) m.lane_bits[l >> 6] |= 1ull << (l & 63);
     if (in_place) { // the columns where the caller has them
         d.mapq = b->mapq; d.lane = b->lane; d.rid = b->rid; d.pos = b->pos; d.tlen = b->tlen; d.nm = b->nm; d.as_ = b->as; d.l_seq = b->l_seq; d.n_cigar = b->n_cigar;
         d.seq = b->seq; d.qual = b->qual; d.cigar = b->cigar;
@@ -510,9 +514,10 @@ static int enqueue_kernels(bqc_ctx* c, BatchMem& m)
             bqc_launch_reads_chunks(d, c->sl, c->d_state, refs, err, c->n_cu * 8, 1, c->stream);
             tick(c, "k_reads");
         }
-        if (c->t8_rows_lane != m.t8_lane || c->t8_slots_used + grid > c->t8_slots_cap) { bqc_state_ready(c); c->t8_rows_lane = m.t8_lane; }
-        bqc_launch_short(d, c->sl, c->d_state, refs, err, grid, c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + c->t8_slots_used,
-                         m.t8_lane, c->stream);
+        if (c->t8_slots_used + grid > c->t8_slots_cap) bqc_state_ready(c);
+        for (int k = 0; k < 4; ++k) c->t8_lanes[k] |= m.lane_bits[k];
+        bqc_launch_short(d, c->sl, c->d_state, refs, err, grid, c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u,
+                         c->d_t8used + (size_t)c->t8_slots_used * BQC_T8_USED, c->stream);
         c->t8_slots_used += grid;
         tick(c, "k_short");
     }
@@ -521,9 +526,11 @@ static int enqueue_kernels(bqc_ctx* c, BatchMem& m)
         tick(c, "k_reads(generic)");
         HIPCHK(c, hipMemsetAsync(m.d_rsum, 0, 12ull * d.n_reads, c->stream));
         const uint32_t slots = bqc_long_slots(m.max_len_slow, m.n_chunks_slow_ub, c->n_cu); // a slot of 8-mer scratch rows per workgroup, as for k_short
-        if (c->t8_rows_lane != m.t8_lane || c->t8_slots_used + slots > c->t8_slots_cap) { bqc_state_ready(c); c->t8_rows_lane = m.t8_lane; }
+        if (c->t8_slots_used + slots > c->t8_slots_cap) bqc_state_ready(c);
+        for (int k = 0; k < 4; ++k) c->t8_lanes[k] |= m.lane_bits[k];
         bqc_launch_long(d, c->sl, c->d_state, refs, err, m.d_rsum, m.max_len_slow, m.n_chunks_slow_ub, c->n_cu,
-                        c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + c->t8_slots_used, m.t8_lane, c->d_kl_cyc, c->d_kl_cyc_used, c->stream);
+                        c->d_t8rows + (size_t)c->t8_slots_used * BQC_T8_SPW * 16384u, c->d_t8used + (size_t)c->t8_slots_used * BQC_T8_USED, m.t8_lane, c->d_kl_cyc,
+                        c->d_kl_cyc_used, c->stream);
         c->t8_slots_used += slots;
         tick(c, "k_long");
     }

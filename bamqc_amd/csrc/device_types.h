@@ -14,6 +14,7 @@
 #define BQC_FAST_WAVES 16        // waves per workgroup of k_short = tiles per fast chunk (host chunk layout and kernel must agree)
 #define BQC_FAST_NH 2            // 8-cycle halves a lane of k_short owns (2: 16 cycles, 4: 32 cycles); also the pad dwords of the nibble tables
 #define BQC_T8_SPW 8             // rows (64 KiB images of the packed 8-mer counters) a workgroup of k_short can write per launch
+#define BQC_T8_USED 4            // words per slot of the rows' directory: rows written, the read group of rows 0-3 (a byte each), of rows 4-7, unused
 #define BQC_FAST_MAXLEN 255      // reads up to this length take the short-read fast path (k_short); 255: per-read N / GC counts fit 8 bits
 #define BQC_COV_TILE_WINDOWS 4   // coverage tile = 4 windows of 1000 positions
 #define BQC_COV_TILE (BQC_COV_TILE_WINDOWS * 1000)

@@ -32,8 +32,8 @@
 #endif
 
 // The packed 8-mer counters go into the next free row of the workgroup's slot of the scratch table k_short's workgroups use (plain
-// 16-byte stores of the LDS image; k_t8_fold sums the rows of all slots into the state vector later) when the read group is the one
-// the table collects; with global atomics otherwise.  Round 4: with atomics only, every workgroup ended in 65 536 scattered 8-byte
+// 16-byte stores of the LDS image; k_t8_fold sums the rows of all slots into the state vector later) while the slot has rows left; with
+// global atomics after that.  Round 4: with atomics only, every workgroup ended in 65 536 scattered 8-byte
 // atomic adds — 16.6 M per launch on config 5, 0.3 of the kernel's 1.4 ms.  Returns true when a row was written.
 // The per-cycle tile likewise: its first flush for that read group goes, as it is, into the workgroup's place of a scratch array that
 // k_long_cyc_fold sums over the workgroups of a row (they all count the same cycles: 23 workgroups' atomics on the same words).
@@ -46,15 +46,7 @@ __device__ __forceinline__ bool kl_flush(uint32_t* lds, const StateLayout& sl, u
         uint4* row = slot + (size_t)n_rows_used * 4096u;
         uint4* src = (uint4*)(lds + KL_T8);
         for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) { row[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
-    } else
-    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) { // packed counters: byte b of dword i is bin 4 i + ((4 - b) & 3)
-        const uint32_t v = lds[KL_T8 + i];
-        if (!v) continue;
-        lds[KL_T8 + i] = 0;
-#pragma unroll
-        for (uint32_t b8 = 0; b8 < 4; ++b8)
-            if ((v >> (8u * b8)) & 0xFFu) gadd(state + lb + sl.o_eightmer + 4u * i + ((4u - b8) & 3u), (v >> (8u * b8)) & 0xFFu);
-    }
+    } else t8_atomics_out(lds + KL_T8, state + lb + sl.o_eightmer);
     for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) { // bin = c(j-1) r(j) c(j) r(j+1) of group i >> 8, in cycle space
         const uint32_t v = lds[KL_TRIP + i];
         if (!v) continue;
@@ -150,16 +142,17 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
     extern __shared__ uint32_t lds[];
     const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x; // this workgroup's slot of the scratch rows
     if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KL_T8 at LDS address 0)
-        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[wg] = 0; cyc_used[wg] = 0; }
+        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[wg * BQC_T8_USED] = 0; cyc_used[wg] = 0; }
         return;
     }
     const uint32_t cyc0 = blockIdx.y * KL_ROW;
     if (cyc0 >= b.desc->long_max_len) { // no read of the batch reaches this row (the grid is sized from an upper bound)
-        if (threadIdx.x == 0) { t8_used[wg] = 0; cyc_used[wg] = 0; }
+        if (threadIdx.x == 0) { t8_used[wg * BQC_T8_USED] = 0; cyc_used[wg] = 0; }
         return;
     }
     uint4* const t8_slot = t8rows + (size_t)wg * BQC_T8_SPW * 4096u;
     uint32_t t8_n = 0; // rows written so far
+    T8Tags t8_tags;    // ... and their read groups
     uint4* const cyc_tile = cyc_tiles + (size_t)wg * (2 * 6 * 1024 / 4);
     bool cyc_written = false;
     for (uint32_t i = threadIdx.x; i < KL_WORDS; i += blockDim.x) lds[i] = 0;
@@ -200,7 +193,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 n1[0] = n1[1] = n2[0] = n2[1] = 0;
                 block_sync();
                 const bool tile_out = cur_lane == t8_lane && !cyc_written;
-                t8_n += kl_flush(lds, sl, state, cur_lane, cyc0, cur_lane == t8_lane ? t8_slot : nullptr, t8_n, tile_out ? cyc_tile : nullptr) ? 1u : 0u;
+                if (kl_flush(lds, sl, state, cur_lane, cyc0, t8_slot, t8_n, tile_out ? cyc_tile : nullptr)) { t8_tag(t8_tags, t8_n, cur_lane); ++t8_n; }
                 cyc_written |= tile_out;
                 block_sync();
             }
@@ -599,7 +592,7 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
             nxt_m = nn_m;
         }
     }
-    if (threadIdx.x == 0) { t8_used[wg] = t8_n; cyc_used[wg] = cyc_written ? 1u : 0u; } // rows of this workgroup's slot that k_t8_fold has to read; its tile
+    if (threadIdx.x == 0) { t8_directory(t8_used + wg * BQC_T8_USED, t8_n, t8_tags); cyc_used[wg] = cyc_written ? 1u : 0u; } // rows of this workgroup's slot that k_t8_fold has to read; its tile
 }
 
 // the per-cycle tiles of the workgroups of one row (blockIdx.y), summed and added to the read group's counters: thread per tile word

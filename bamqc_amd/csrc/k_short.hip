@@ -67,14 +67,7 @@ __device__ __forceinline__ bool t8_flush(uint32_t* lds, uint64_t* __restrict__ e
         for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) { row[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
         return true;
     }
-    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) {
-        const uint32_t v = lds[KS_T8 + i];
-        if (!v) continue;
-        lds[KS_T8 + i] = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 4; ++b)
-            if ((v >> (8u * b)) & 0xFFu) gadd(em + 4u * i + ((4u - b) & 3u), (v >> (8u * b)) & 0xFFu);
-    }
+    t8_atomics_out(lds + KS_T8, em);
     return false;
 }
 
@@ -229,11 +222,11 @@ __device__ __forceinline__ Pre ks_prefetch(const uint32_t* rec, uint32_t w, cons
 
 __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl, uint64_t* __restrict__ state, DevRefs refs,
                                                          uint32_t* __restrict__ err, uint32_t parts, uint4* __restrict__ t8rows,
-                                                         uint32_t* __restrict__ t8_used, uint32_t t8_lane, uint32_t t8_period)
+                                                         uint32_t* __restrict__ t8_used, uint32_t t8_period)
 {
     extern __shared__ uint32_t lds[];
     if ((uint32_t)(uintptr_t)(lds_u32*)lds != 0u) { // the 8-mer atomics address LDS directly (KS_T8 at LDS address 0)
-        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[blockIdx.x] = 0; }
+        if (threadIdx.x == 0) { atomicOr(err, BQC_DEVERR_INTERNAL); t8_used[blockIdx.x * BQC_T8_USED] = 0; }
         return;
     }
     for (uint32_t i = threadIdx.x; i < KS_WORDS; i += blockDim.x) lds[i] = 0;
@@ -274,6 +267,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
     uint32_t cur_lane = 0xFFFFFFFFu, since_t8 = 0;
     uint4* const t8_slot = t8rows + (size_t)blockIdx.x * BQC_T8_SPW * 4096u; // this workgroup's rows of the scratch table
     uint32_t t8_n = 0;                                                          // rows written so far
+    T8Tags t8_tags;                                                             // ... and their read groups
 
     const uint8_t* g_seq = b.seq - KS_BIAS;
     const uint8_t* g_qual = b.qual - KS_BIAS;
@@ -300,7 +294,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                 if (lane_used) { cyc_spill(A, lds, mate, w); cyc_qflush(A, lds, mate, w); }
                 n1 = n2 = 0;
                 block_sync();
-                t8_n += ks_flush(lds, sl, state, cur_lane, cur_lane == t8_lane ? t8_slot : nullptr, t8_n) ? 1u : 0u;
+                if (ks_flush(lds, sl, state, cur_lane, t8_slot, t8_n)) { t8_tag(t8_tags, t8_n, cur_lane); ++t8_n; }
                 rs_flush(lds + KS_RS, sl, state, cur_lane);
             }
             cur_lane = ch.lane;
@@ -312,7 +306,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
             // the other waves are still making for earlier chunks simply land in a later row.  All waves walk the same chunk
             // sequence, so they agree on the row index.
             since_t8 = 1;
-            const bool to_row = cur_lane == t8_lane && t8_n < BQC_T8_SPW;
+            const bool to_row = t8_n < BQC_T8_SPW;
             uint32_t* row = (uint32_t*)(t8_slot + (size_t)t8_n * 4096u);
             uint64_t* emf = state + sl.lane_base(cur_lane) + sl.o_eightmer;
 #pragma unroll 4
@@ -326,7 +320,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
                         if ((v >> (8u * b8)) & 0xFFu) gadd(emf + 4u * i + ((4u - b8) & 3u), (v >> (8u * b8)) & 0xFFu);
                 }
             }
-            t8_n += to_row ? 1u : 0u;
+            if (to_row) { t8_tag(t8_tags, t8_n, cur_lane); ++t8_n; }
         }
         const uint64_t lb = sl.lane_base(cur_lane);
         uint64_t* em = state + lb + sl.o_eightmer;
@@ -621,7 +615,7 @@ __global__ __launch_bounds__(KS_THREADS) void k_short(DevBatch b, StateLayout sl
         __builtin_amdgcn_wave_barrier();
         } // tiles
     }
-    if (threadIdx.x == 0) t8_used[blockIdx.x] = t8_n; // rows of this workgroup's slot that k_t8_fold has to read
+    if (threadIdx.x == 0) t8_directory(t8_used + blockIdx.x * BQC_T8_USED, t8_n, t8_tags); // rows of this workgroup's slot that k_t8_fold has to read
 }
 
 
@@ -673,17 +667,18 @@ extern "C" hipError_t bqc_short_init()
 // the 8-mer counters of the state vector: thread per LDS dword (4 bins) and slice of 64 slots.  Rows are read once and not
 // written: the next launches overwrite them.
 __global__ __launch_bounds__(256) void k_t8_fold(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ used, uint32_t n_slots,
-                                                    uint64_t* __restrict__ em)
+                                                    uint64_t* __restrict__ em, uint32_t lane)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // < 16384
     uint32_t A = 0, B = 0, C = 0, D = 0; // bytes 0..3 of the dword = bins 4i + (0, 3, 2, 1); at most 64 * BQC_T8_SPW * 255 each
     const uint32_t s0 = blockIdx.y * 64u, s1 = min(n_slots, s0 + 64u); // (few slices: every slice ends in 65 536 x 4 global atomics)
     for (uint32_t sidx = s0; sidx < s1; ++sidx) {
-        const uint32_t n = min(used[sidx], (uint32_t)BQC_T8_SPW);
+        const uint32_t n = min(used[sidx * BQC_T8_USED], (uint32_t)BQC_T8_SPW);
+        const uint64_t tags = (uint64_t)used[sidx * BQC_T8_USED + 1] | ((uint64_t)used[sidx * BQC_T8_USED + 2] << 32);
         const uint32_t* slot = rows + (size_t)sidx * BQC_T8_SPW * 16384u + i;
         uint32_t v[BQC_T8_SPW];
 #pragma unroll
-        for (uint32_t f = 0; f < BQC_T8_SPW; ++f) v[f] = f < n ? slot[(size_t)f * 16384u] : 0u; // independent loads, issued together
+        for (uint32_t f = 0; f < BQC_T8_SPW; ++f) v[f] = f < n && ((uint32_t)(tags >> (8u * f)) & 0xFFu) == lane ? slot[(size_t)f * 16384u] : 0u; // independent loads, issued together
 #pragma unroll
         for (uint32_t f = 0; f < BQC_T8_SPW; ++f) { A += v[f] & 0xFFu; B += (v[f] >> 8) & 0xFFu; C += (v[f] >> 16) & 0xFFu; D += v[f] >> 24; }
     }
@@ -694,21 +689,21 @@ __global__ __launch_bounds__(256) void k_t8_fold(const uint32_t* __restrict__ ro
 }
 
 extern "C" void bqc_launch_short(const DevBatch& b, const StateLayout& sl, uint64_t* state, const DevRefs& refs, uint32_t* err,
-                                 uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, uint32_t t8_lane, hipStream_t s)
+                                 uint32_t grid, uint32_t* t8rows, uint32_t* t8_used, hipStream_t s)
 {
     if (grid == 0) return;
     static const hipError_t attr_once = bqc_short_init(); // (at the first launch, not in bqc_create: the call loads the code object — 40-60 ms that
     (void)attr_once;                                      //  the compute stream, which has slack at a run's start, can take; bqc_create's caller cannot)
     static uint32_t env_period = 0xFFFFFFFFu;
     if (env_period == 0xFFFFFFFFu) { const char* e = getenv("BQC_T8_PERIOD"); env_period = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 0u; } // tuning knob
-    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_used, t8_lane,
+    hipLaunchKernelGGL(k_short, dim3(grid), dim3(KS_THREADS), KS_WORDS * 4, s, b, sl, state, refs, err, bqc_short_parts(), (uint4*)t8rows, t8_used,
                        env_period ? env_period : KS_T8_PERIOD);
 }
 
-// sum the rows of `n_slots` workgroup slots into the 8-mer counters of `lane`
+// sum the rows of `n_slots` workgroup slots that belong to read group `lane` into its 8-mer counters
 extern "C" void bqc_launch_t8_fold(const uint32_t* t8rows, const uint32_t* t8_used, uint32_t n_slots, const StateLayout& sl, uint64_t* state, uint32_t lane,
                                    hipStream_t s)
 {
     if (!n_slots) return;
-    hipLaunchKernelGGL(k_t8_fold, dim3(64, (n_slots + 63) / 64), dim3(256), 0, s, t8rows, t8_used, n_slots, state + sl.lane_base(lane) + sl.o_eightmer);
+    hipLaunchKernelGGL(k_t8_fold, dim3(64, (n_slots + 63) / 64), dim3(256), 0, s, t8rows, t8_used, n_slots, state + sl.lane_base(lane) + sl.o_eightmer, lane);
 }

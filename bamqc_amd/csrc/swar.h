@@ -84,6 +84,32 @@ __device__ __noinline__ void t8_check(uint64_t* __restrict__ em, uint32_t c32, u
 }
 
 
+// read groups of the rows a workgroup has written into its slot of the scratch table (round 4: every read group's counters may leave
+// through the rows, not only the one with the most reads; k_t8_fold runs once per read group present)
+struct T8Tags { uint32_t lo = 0, hi = 0; };
+__device__ __forceinline__ void t8_tag(T8Tags& t, uint32_t row, uint32_t lane)
+{
+    if (row < 4u) t.lo |= lane << (8u * row); else t.hi |= lane << (8u * (row - 4u));
+}
+__device__ __forceinline__ void t8_directory(uint32_t* __restrict__ used /* this slot's BQC_T8_USED words */, uint32_t n_rows, const T8Tags& t)
+{
+    used[0] = n_rows; used[1] = t.lo; used[2] = t.hi;
+}
+
+// The packed counters of a workgroup added to the 64-bit counters in memory by atomics — for read groups that do not own the scratch
+// rows.  One BIN per lane: 64 consecutive counters = 512 contiguous bytes per wave instruction (round 4; a dword of four bins per lane
+// before: four instructions whose lanes lay 32 bytes apart, the shape the float-atomics section of the MI355X guide calls an order of
+// magnitude slower).  Called by every thread of the workgroup, between barriers; leaves the table zeroed.
+__device__ __forceinline__ void t8_atomics_out(uint32_t* t8 /* LDS [16384] */, uint64_t* __restrict__ em)
+{
+    for (uint32_t b = threadIdx.x; b < 65536u; b += blockDim.x) {
+        const uint32_t v = (t8[b >> 2] >> (8u * t8_byte(b))) & 0xFFu;
+        if (v) gadd(em + b, v);
+    }
+    block_sync();
+    for (uint32_t i = threadIdx.x; i < 16384u; i += blockDim.x) t8[i] = 0;
+}
+
 // explicit global-address-space loads (generic/flat loads would count on lgkmcnt and make every LDS wait also wait for
 // the prefetch); the 12- and 16-byte loads are unaligned
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
