@@ -349,7 +349,8 @@ __global__ __launch_bounds__(KL_WAVES * 64) void k_long(DevBatch b, StateLayout 
                 pp = rc ? U - w16 : U + w16;                            // nibble index of the lane's window, minus one (a lane that takes the segment: 0 <= pp < reflen + 16)
                 const uint32_t di = min(pp >> 3, nd8p1);
                 GVec<3>::lda(e, (const uint8_t*)(rn + di));
-                e[3] = rn[min(di + 3u, nd8p1 + 2u)];                    // (the nibble behind the window when it starts at a dword's last nibble)
+                e[3] = KS_GLOBAL(uint32_t, rn + min(di + 3u, nd8p1 + 2u)); // (the nibble behind the window when it starts at a dword's last nibble; said to be
+                                                                            //  global: a plain load through this pointer — itself loaded — is a FLAT load)
             };
             // the first 64 operations' segments, the first two per lane: requested here, evaluated at the end
             uint32_t t_kab_s = 0, t_U_s = 0, t_wm = 0, t_kab[2] = {0, 0}, t_pp[2] = {0, 0}, t_e0[4] = {0, 0, 0, 0}, t_e1[4] = {0, 0, 0, 0};

@@ -23,9 +23,18 @@ __device__ __forceinline__ void block_sync()
     __syncthreads();
 }
 
+// Atomic adds to counters in DEVICE memory, said so to the compiler (round 4): a pointer it cannot trace to a kernel argument — one
+// loaded from a table of pointers, as the sketch's are — otherwise gives a FLAT atomic, which counts on vmcnt AND lgkmcnt and completes
+// out of order, so that every later wait for an LDS read also waits for the atomic's trip to memory.
+typedef __attribute__((address_space(1))) unsigned long long gmem_u64;
+typedef __attribute__((address_space(1))) uint32_t gmem_u32;
 __device__ __forceinline__ void gadd(uint64_t* p, uint64_t v)
 {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+    __hip_atomic_fetch_add((gmem_u64*)(uintptr_t)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gadd32(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_fetch_add((gmem_u32*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Add 1 to *addr for every lane with pred, aggregating lanes that hit the same address

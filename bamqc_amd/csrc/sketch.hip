@@ -244,57 +244,105 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch(DevBatch b, const DevSket
                 }
                 const uint32_t nb = min(16u, L - cb);
                 // Which of the chunk's 16 positions restart the k-mer ('N', or (signed char)(phred + 33) below the threshold:
-                // ReadQualityHasher.hpp:61-66) — for all 16 at once (round 4; a field extract, an add, a sign extension and two compares per
-                // base before): the nibbles that are 15 by two AND-shifts, the qualities byte-wise in four dwords — v = phred + 33 mod 256
-                // without a carry between the bytes, valid iff bit 7 of v is clear and its low seven bits reach the threshold (1..127; other
-                // thresholds: the compares, below).  A step then tests one bit of each.
-                uint64_t nmask; // position jj: bit 60 - 4 jj
-                { const uint64_t y = ns & (ns >> 1); nmask = y & (y >> 2) & 0x1111111111111111ull; }
-                const bool q_swar = P.q_thr >= 1 && P.q_thr <= 127;
-                uint64_t qbad_lo = 0, qbad_hi = 0; // position jj: bit 8 (jj & 7) + 7 of the half it lies in
-                if (q_swar) {
-                    const uint64_t add = 0x0101010101010101ull * (uint64_t)(0x80u - (uint32_t)P.q_thr);
-                    auto bad8 = [&](uint64_t w) {
-                        const uint64_t v = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x2121212121212121ull) ^ (w & 0x8080808080808080ull);
-                        const uint64_t tt = (v & 0x7F7F7F7F7F7F7F7Full) + add; // bit 7 of a byte: its low seven bits reach the threshold
-                        return ~(tt & ~v) & 0x8080808080808080ull;
+                // ReadQualityHasher.hpp:61-66) — for all 16 at once: the nibbles that are 15 by two AND-shifts, the qualities byte-wise in
+                // four dwords — v = phred + 33 mod 256 without a carry between the bytes, valid iff bit 7 of v is clear and its low seven bits
+                // reach the threshold (1..127; other thresholds: sixteen compares) — gathered into one 16-bit mask V (bit jj: position jj
+                // takes part in a k-mer).
+                uint32_t V;
+                {
+                    uint64_t y = ns & (ns >> 1);
+                    y = y & (y >> 2) & 0x1111111111111111ull;              // position jj: bit 60 - 4 jj
+                    auto gather4 = [](uint32_t w) {                          // flags at bits 0, 4, .., 28 -> bits 0..7
+                        w = (w | (w >> 3)) & 0x03030303u;
+                        w = (w | (w >> 6)) & 0x000F000Fu;
+                        return (w | (w >> 12)) & 0xFFu;
                     };
-                    qbad_lo = bad8(qlo); qbad_hi = bad8(qhi);
-                }
-                auto step = [&](const uint32_t jj) __attribute__((always_inline)) {
-                    const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
-                    bool restart = (nmask >> (60 - 4 * jj)) & 1ull;
-                    if (q_swar) restart |= (((jj < 8 ? qbad_lo : qbad_hi) >> (8 * (jj & 7) + 7)) & 1ull) != 0;
-                    else restart |= (int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u) < P.q_thr;
-                    if (restart) { t = 0; return; } // 'N' or low quality: restart (ReadQualityHasher.hpp:61-66)
-                    if (t == 0) { hh = hl = th = tl = 0; }
-                    // RepHash::init built incrementally (:85-97) and RepHash::update(out, in) (:99-113) as one step: nothing
-                    // leaves the k-mer while it is still filling
-                    const uint32_t outn = t < P.k ? 16u : (uint32_t)(outs >> (60 - 4 * jj)) & 15u;
-                    const uint32_t pi = (rc ? 272u : 0u) + (outn << 4) + nib;
-                    const uint4 a = pf[pi], bt = pt[pi];
-                    rotl1_128(hh, hl);
-                    hl ^= (uint64_t)a.x | ((uint64_t)a.y << 32); hh ^= (uint64_t)a.z | ((uint64_t)a.w << 32);   // h = rotl1(h) ^ rotl_k(hvals[out]) ^ hvals[in]
-                    tl ^= (uint64_t)bt.x | ((uint64_t)bt.y << 32); th ^= (uint64_t)bt.z | ((uint64_t)bt.w << 32); // ht = rotr1(ht ^ hvals[twin[out]] ^ rotl_k(hvals[twin[in]]))
-                    rotr1_128(th, tl);
-                    if (t < P.k && ++t < P.k) return;
-                    // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
-                    const uint64_t hash = hl ^ tl;
-                    ++n_hash;
-                    if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
-                    else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
-                    // bitScanForward (lsb.cpp:26-29), clamped to the last of the 32 levels: the lowest set bit of the hash's low word, 31
-                    // when that word is zero (__ffs(0) - 1 wraps to 0xFFFFFFFF)
-                    const uint32_t w = min((uint32_t)__ffs((int)(uint32_t)hash) - 1u, 31u);
-                    if (mine && ((sat_mask >> w) & 1u)) return; // M[w] == size*countsPerLong*maxVal: every counter is 15
-                    const uint32_t index = (uint32_t)(hash >> (w + 1u)) & P.ctr_mask;
-                    // fire and forget: the counter's value is min(15, raw); k_sketch_levels clamps the raw counts after every
-                    // batch and finds the levels in which every counter has reached 15
-                    atomicAdd(D.counters + ((w << P.ctr_shift) + index), 1u); // (32 levels x ctr_per_level counters: far below 2^32)
-                };
+                    const uint32_t n16 = gather4((uint32_t)y) | (gather4((uint32_t)(y >> 32)) << 8); // bit i: position 15 - i
+                    uint32_t bad = __brev(n16) >> 16;
+                    if (P.q_thr >= 1 && P.q_thr <= 127) {
+                        const uint64_t add = 0x0101010101010101ull * (uint64_t)(0x80u - (uint32_t)P.q_thr);
+                        auto bad8 = [&](uint64_t w) { // bit 8 j + 7: position j of the half is below the threshold
+                            const uint64_t v = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x2121212121212121ull) ^ (w & 0x8080808080808080ull);
+                            const uint64_t tt = (v & 0x7F7F7F7F7F7F7F7Full) + add; // bit 7 of a byte: its low seven bits reach the threshold
+                            return ~(tt & ~v) & 0x8080808080808080ull;
+                        };
+                        auto gather8 = [](uint32_t w) {                      // flags at bits 7, 15, 23, 31 -> bits 0..3
+                            w = (w >> 7) & 0x01010101u;
+                            w = (w | (w >> 7)) & 0x00030003u;
+                            return (w | (w >> 14)) & 0xFu;
+                        };
+                        const uint64_t bl = bad8(qlo), bh = bad8(qhi);
+                        bad |= gather8((uint32_t)bl) | (gather8((uint32_t)(bl >> 32)) << 4) | (gather8((uint32_t)bh) << 8) | (gather8((uint32_t)(bh >> 32)) << 12);
+                    } else {
 #pragma unroll
-                for (uint32_t jj = 0; jj < 16u; ++jj) // unrolled: the nibble / quality / leaving-base extractions get constant shifts
-                    if (jj < nb) step(jj);
+                        for (uint32_t jj = 0; jj < 16u; ++jj)
+                            bad |= ((int32_t)(int8_t)(uint8_t)((uint32_t)((jj < 8 ? qlo : qhi) >> (8 * (jj & 7))) + 33u) < P.q_thr ? 1u : 0u) << jj;
+                    }
+                    V = ~bad & (nb >= 16u ? 0xFFFFu : (1u << nb) - 1u);
+                }
+                // What a position does follows from V and the count t the chunk is entered with, without walking the positions one after
+                // the other (round 4).  T = number of consecutive valid positions ending at jj, t included where the run reaches the
+                // chunk's start: the states are cleared where T == 1 (First), nothing leaves the k-mer while T <= k (Fill), a hash is
+                // emitted where T >= k (Emit) — the serial form's  if (t == 0) clear;  out = t < k ? none : ..;  if (t < k && ++t < k) return.
+                uint32_t First, Fill, Emit;
+                {
+                    auto low = [](uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; };
+                    const uint32_t z = min((uint32_t)__ffs((int)~V) - 1u, 16u);      // first position that is not valid
+                    const uint32_t A = low(z);                                       // the run from the chunk's start
+                    const uint32_t Bm = V & ~A;
+                    Emit = A & ~low(P.k - 1u > t ? P.k - 1u - t : 0u);
+                    Fill = (A & low(P.k > t ? P.k - t : 0u)) | Bm;
+                    if (P.k <= 16u) { // (runs inside the chunk can reach k)
+                        uint32_t ge = V;
+                        for (uint32_t sft = 1; sft < P.k; ++sft) ge &= V << sft;
+                        Emit |= Bm & ge;
+                        Fill &= ~(Bm & ge & (V << P.k));
+                    }
+                    First = V & ~((V << 1) | (t != 0u ? 1u : 0u));
+                    t = z == 16u ? min(P.k, t + 16u) : min(P.k, (uint32_t)__clz((int)~(V << 16)));
+                    Emit &= 0xFFFFu;
+                }
+                n_hash += (uint32_t)__popc(Emit);
+                // The two 16-byte table entries a position needs depend on V, Fill and the bases only: they are requested three positions
+                // ahead of the serial chain  h = rotl1(h) ^ a;  ht = rotr1(ht ^ b)  (round 4: each step waited for its own LDS round trip).
+                const uint32_t rcbase = rc ? 272u : 0u;
+                auto entry = [&](const uint32_t jj) __attribute__((always_inline)) {
+                    const uint32_t nib = (uint32_t)(ns >> (60 - 4 * jj)) & 15u;
+                    const uint32_t outn = (Fill >> jj) & 1u ? 16u : (uint32_t)(outs >> (60 - 4 * jj)) & 15u;
+                    return rcbase + (outn << 4) + nib;
+                };
+                uint4 ea[4], eb[4]; // entries of positions jj .. jj + 3 at [jj & 3]
+#pragma unroll
+                for (uint32_t jj = 0; jj < 3u; ++jj) { const uint32_t pi = entry(jj); ea[jj] = pf[pi]; eb[jj] = pt[pi]; }
+#pragma unroll
+                for (uint32_t jj = 0; jj < 16u; ++jj) { // unrolled: the nibble / leaving-base extractions get constant shifts
+                    if (jj + 3u < 16u) { const uint32_t pi = entry(jj + 3u); ea[(jj + 3u) & 3u] = pf[pi]; eb[(jj + 3u) & 3u] = pt[pi]; }
+                    const uint4 a = ea[jj & 3u], bt = eb[jj & 3u];
+                    if ((V >> jj) & 1u) {
+                        if ((First >> jj) & 1u) { hh = hl = th = tl = 0; }
+                        // RepHash::init built incrementally (:85-97) and RepHash::update(out, in) (:99-113) as one step: nothing
+                        // leaves the k-mer while it is still filling
+                        rotl1_128(hh, hl);
+                        hl ^= (uint64_t)a.x | ((uint64_t)a.y << 32); hh ^= (uint64_t)a.z | ((uint64_t)a.w << 32);   // h = rotl1(h) ^ rotl_k(hvals[out]) ^ hvals[in]
+                        tl ^= (uint64_t)bt.x | ((uint64_t)bt.y << 32); th ^= (uint64_t)bt.z | ((uint64_t)bt.w << 32); // ht = rotr1(ht ^ hvals[twin[out]] ^ rotl_k(hvals[twin[in]]))
+                        rotr1_128(th, tl);
+                        if ((Emit >> jj) & 1u) {
+                            // ---- StreamCounter::operator()(hash), StreamCounter.hpp:68-93
+                            const uint64_t hash = hl ^ tl;
+                            if (mine) atomicAdd(&f2[(uint32_t)hash & P.f2_mask], 1u);
+                            else gadd(D.f2 + ((uint32_t)hash & P.f2_mask), 1);
+                            // bitScanForward (lsb.cpp:26-29), clamped to the last of the 32 levels: the lowest set bit of the hash's low word,
+                            // 31 when that word is zero (__ffs(0) - 1 wraps to 0xFFFFFFFF)
+                            const uint32_t w = min((uint32_t)__ffs((int)(uint32_t)hash) - 1u, 31u);
+                            if (!(mine && ((sat_mask >> w) & 1u))) { // (else M[w] == size*countsPerLong*maxVal: every counter is 15)
+                                const uint32_t index = (uint32_t)(hash >> (w + 1u)) & P.ctr_mask;
+                                // fire and forget: the counter's value is min(15, raw); k_sketch_levels clamps the raw counts after every
+                                // batch and finds the levels in which every counter has reached 15
+                                gadd32(D.counters + ((w << P.ctr_shift) + index), 1u); // (32 levels x ctr_per_level counters: far below 2^32)
+                            }
+                        }
+                    }
+                }
             }
             if (mine) atomicAdd(&lm[32], n_hash); else if (n_hash) gadd(D.misc, n_hash);
         }
