@@ -590,7 +590,7 @@ struct ProgramOptions {
     // extensions (not in the reference)
     uint32_t max_read_len = 65536, hist_cap = 65536;
     int device = 0;
-    uint32_t batch_reads = 1u << 20;
+    uint32_t batch_reads = [] { const char* e = getenv("BQC_BATCH_READS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 1u << 20; }(); // (the variable: experiments; --batch-reads)
     bool no_sketch = false;
 };
 
