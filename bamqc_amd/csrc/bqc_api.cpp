@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "bqc_ctx.h"
@@ -109,7 +110,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     } while (0)
     const bool ctiming = getenv("BQC_TIMING") && getenv("BQC_TIMING")[0] == '1';
     const auto ct0 = std::chrono::steady_clock::now();
-    double cts[6] = {0, 0, 0, 0, 0, 0};
+    double cts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto cstamp = [&](int k) { cts[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - ct0).count() * 1e3; };
     CCHK(hipSetDevice(c->device));
     hipDeviceProp_t prop;
@@ -124,13 +125,16 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMalloc(&c->d_state, c->sl.words * 8));
     CCHK(hipMalloc(&c->d_err0, sizeof(ErrRec)));
     CCHK(hipMalloc(&c->d_cursor, 8));
+    cstamp(6);
     if (!c->fasta_index.empty()) {
         CCHK(hipMalloc(&c->d_fasta_index, 4 * c->fasta_index.size()));
         CCHK(hipMemcpy(c->d_fasta_index, c->fasta_index.data(), 4 * c->fasta_index.size(), hipMemcpyHostToDevice));
     }
+    cstamp(7);
     c->t8_slots_cap = std::max(1024u, 4u * c->n_cu);
     CCHK(hipMalloc(&c->d_t8rows, (size_t)c->t8_slots_cap * BQC_T8_SPW * 65536));
     CCHK(hipMalloc(&c->d_t8used, (size_t)c->t8_slots_cap * BQC_T8_USED * 4));
+    cstamp(8);
     CCHK(hipMalloc(&c->d_kl_cyc, (size_t)c->n_cu * 2 * 6 * 1024 * 4));
     CCHK(hipMalloc(&c->d_kl_cyc_used, (size_t)c->n_cu * 4));
     CCHK(hipMalloc(&c->d_carry, (size_t)opt->n_lanes * 2 * 2000 * 4));
@@ -140,6 +144,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
     CCHK(hipMalloc(&c->d_ref_len, sizeof(uint64_t) * nr));
     CCHK(hipMalloc(&c->d_refn_ptrs, sizeof(uint32_t*) * nr));
     CCHK(hipMalloc(&c->d_main, nr));
+    cstamp(9);
     CCHK(hipMemcpy(c->d_main, c->main_chrom.data(), nr, hipMemcpyHostToDevice));
     cstamp(2);
     CCHK(hipMemsetAsync(c->d_state, 0, c->sl.words * 8, c->stream));
@@ -162,7 +167,7 @@ extern "C" int bqc_create(const bqc_options* opt, bqc_ctx** out)
         c->ev.push_back(e);
     }
     cstamp(5);
-    if (ctiming) fprintf(stderr, "[timing] bqc_create: kernel attributes (code object load) at %.1f ms, compute stream %.1f, allocations %.1f, memsets + tables %.1f, sketch %.1f, events %.1f\n", cts[0], cts[1], cts[2], cts[3], cts[4], cts[5]);
+    if (ctiming) fprintf(stderr, "[timing] bqc_create: kernel attributes (code object load) at %.1f ms, compute stream %.1f, allocations %.1f (first three %.1f, FASTA index copied %.1f, 8-mer rows %.1f, the rest %.1f, then a copy), memsets + tables %.1f, sketch %.1f, events %.1f\n", cts[0], cts[1], cts[2], cts[6], cts[7], cts[8], cts[9], cts[3], cts[4], cts[5]);
     *out = c;
     return 0;
 }
@@ -212,6 +217,9 @@ extern "C" int bqc_warmup(int32_t device)
     }
     auto done = [](int rc) { { std::lock_guard<std::mutex> lk(g_streams.m); g_streams.making = false; } g_streams.cv.notify_all(); return rc; };
     if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) return done(BQC_ERR_DEVICE);
+    // (Tried in round 4: the first copy from pageable memory — ~50 ms of runtime set-up that bqc_create pays behind its compute stream,
+    // `[timing] bqc_create` — made here by a thread of its own beside the streams: the record loop starts at 0.19 s either way,
+    // gpurun_out/r9d; the runtime serialises the two.)
     for (int k = 0; k < StreamPool::kAhead; ++k) {
         hipStream_t s = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return done(BQC_ERR_DEVICE); }
