@@ -38,6 +38,20 @@ def test_sketch_iupac_noqual_varlen_and_batches():
     assert_parity(split(cols, [700, 1500]), refs, klist=[8, 32], qlist=[17])
 
 
+def test_sketch_restarts_inside_chunks_small_k_and_odd_thresholds():
+    """The kernel works out a 16-base chunk's restarts as run masks: k-mers no longer than a chunk (k = 1, 2, 15, 16, 17: runs that start
+    and end inside one chunk count), many restarts (a fifth of the bases below the threshold, IUPAC codes), reads shorter than k, and a
+    threshold outside the byte-wise compare's range (q = 100: (signed char)(133) is negative, every quality passes)."""
+    cols, refs = synth.synth(seed=23, n_reads=4000, n_refs=1, ref_len=80_000, var_len=True, p_iupac=0.03, p_noqual=0.01)
+    rng = np.random.default_rng(5)
+    q = cols["qual"].copy()
+    low = (rng.random(q.size) < 0.2) & (q != 0xFF)
+    q[low] = rng.integers(0, 17, int(low.sum())).astype(np.uint8)
+    cols["qual"] = q
+    assert_parity(split(cols, [1300]), refs, klist=[1, 2, 15, 16], qlist=[17])
+    assert_parity(cols, refs, klist=[17, 33], qlist=[0, 100])
+
+
 def test_sketch_empty_input_prints_the_reference_nan_value():
     cols, refs = synth.synth(seed=1, n_reads=0, n_refs=1, ref_len=10_000)
     co, cg, _, _ = assert_parity(cols, refs, klist=[32], qlist=[17])
