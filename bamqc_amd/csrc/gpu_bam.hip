@@ -194,11 +194,22 @@ __global__ __launch_bounds__(64) void k_gb_walk_wave(const uint8_t* __restrict__
     if (s >= seg0 + nseg) return;
     const uint64_t a = (uint64_t)s * GB_SEG, b = min(avail, a + GB_SEG);
     const uint64_t staged = min(avail - a, (uint64_t)GBW_STAGE) & ~(uint64_t)3; // whole words (a tail of 1-3 bytes at the window's end is read from memory)
-    for (uint32_t off = lane * 16u; off < (uint32_t)staged; off += 1024u) {
-        if (off + 16u <= (uint32_t)staged) {
-            const gb_u32x4 v = *(const gb_u32x4_u*)(base + a + off);
-            buf[off / 4] = v.x; buf[off / 4 + 1] = v.y; buf[off / 4 + 2] = v.z; buf[off / 4 + 3] = v.w;
-        } else for (uint32_t k = off; k < (uint32_t)staged; k += 4u) buf[k / 4] = ld32(base + a + k);
+    { // (round 4: every load of the stage issued before the first is waited for — as a loop of load-then-store the seventeen 16-byte loads
+      // of a lane were seventeen round trips one after the other, ~30 of the wave's ~40 us)
+        constexpr uint32_t kSteps = (GBW_STAGE + 1023u) / 1024u;
+        gb_u32x4 v[kSteps];
+#pragma unroll
+        for (uint32_t k = 0; k < kSteps; ++k) {
+            const uint32_t off = lane * 16u + 1024u * k;
+            v[k] = gb_u32x4{0, 0, 0, 0};
+            if (off + 16u <= (uint32_t)staged) v[k] = *(const gb_u32x4_u*)(base + a + off);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kSteps; ++k) {
+            const uint32_t off = lane * 16u + 1024u * k;
+            if (off + 16u <= (uint32_t)staged) { buf[off / 4] = v[k].x; buf[off / 4 + 1] = v[k].y; buf[off / 4 + 2] = v[k].z; buf[off / 4 + 3] = v[k].w; }
+            else if (off < (uint32_t)staged) for (uint32_t q = off; q < (uint32_t)staged; q += 4u) buf[q / 4] = ld32(base + a + q);
+        }
     }
     if (lane == 0) buf[staged / 4] = 0;
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -222,19 +233,42 @@ __global__ __launch_bounds__(64) void k_gb_walk_wave(const uint8_t* __restrict__
     S.first = (uint32_t)p;
     GbRec* out = recs + (size_t)s * GB_MAXR;
     uint32_t so = 0, qo = 0, co = 0, n = 0;
-    while (p < b && p < limit) { // (every lane the same record: the header's words are broadcast reads)
-        if (p + 36 > avail) { S.flags |= GB_INCOMPLETE; break; }
-        const uint32_t bs = V.u32(p);
+    // (every lane the same record: the header's words are broadcast reads.)  Round 4: the four header words of a record come from six LDS
+    // words requested together (four reads of two words each, each waited for, before), and the records' entries leave 64 at a time —
+    // lane k keeps the entry of record 64 m + k — instead of one 16-byte store per record by lane 0: behind that store the next record's
+    // `s_waitcnt vmcnt(0)` (the compiler's, for the path that reads the header from memory) waited for the store to retire, ~2 000 of the
+    // ~2 200 clocks a record took.
+    GbRec mine{0, 0, 0, 0};
+    // (positions relative to the segment's start inside the loop: 32-bit compares; the data at hand beyond 2^31 bytes behind the segment's
+    // start is as good as endless for a record that starts inside the segment)
+    const uint64_t stop64 = min(b, limit);
+    const uint32_t stop_r = stop64 > a ? (uint32_t)(stop64 - a) : 0u;                         // <= GB_SEG
+    const uint32_t avail_r = (uint32_t)min(avail - a, (uint64_t)0x7FFFFFFFu), staged_r = (uint32_t)staged;
+    uint32_t r = p >= a && p - a < (uint64_t)stop_r ? (uint32_t)(p - a) : 0xFFFFFFFFu;        // (outside: nothing to walk; p stays what it is)
+    while (r < stop_r) {
+        if (r + 36u > avail_r) { S.flags |= GB_INCOMPLETE; break; }
+        uint32_t bs, w12, w16, l_seq;
+        if (r + 24u <= staged_r) {
+            const uint32_t w = r >> 2, sh = r & 3u;
+            const uint32_t x0 = buf[w], x1 = buf[w + 1], x3 = buf[w + 3], x4 = buf[w + 4], x5 = buf[w + 5], x6 = buf[w + 6]; // (buf has a spare word behind the staged bytes)
+            bs = __builtin_amdgcn_alignbyte(x1, x0, sh); w12 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+            w16 = __builtin_amdgcn_alignbyte(x5, x4, sh); l_seq = __builtin_amdgcn_alignbyte(x6, x5, sh);
+        } else { const uint64_t q = a + r; bs = V.u32(q); w12 = V.u32(q + 12); w16 = V.u32(q + 16); l_seq = V.u32(q + 20); } // (the last record of the data at hand)
         if (bs < 32u) { S.flags |= GB_CORRUPT; break; }
-        const uint32_t l_name = V.u32(p + 12) & 255u, n_cig = V.u32(p + 16) & 0xFFFFu, l_seq = V.u32(p + 20);
+        const uint32_t l_name = w12 & 255u, n_cig = w16 & 0xFFFFu;
         const uint64_t var = 32ull + l_name + 4ull * n_cig + ((uint64_t)l_seq + 1u) / 2u + l_seq;
         if (var > bs) { S.flags |= GB_CORRUPT; break; }
-        if (p + 4 + bs > avail) { S.flags |= GB_INCOMPLETE; break; }
-        if (lane == 0) out[n] = GbRec{(uint32_t)p, so, qo, co};
+        const uint64_t next = (uint64_t)r + 4u + bs; // (64 bits: a block_size near 2^32 must not wrap into the segment)
+        if (next > avail - a) { S.flags |= GB_INCOMPLETE; break; }
+        if (lane == (n & 63u)) mine = GbRec{(uint32_t)(a + r), so, qo, co};
         so += (l_seq + 1u) / 2u; qo += l_seq; co += n_cig;
         ++n;
-        p += 4ull + bs;
+        if ((n & 63u) == 0u) out[n - 64u + lane] = mine;
+        if (next >= stop_r) { r = 0xFFFFFFFFu; p = a + next; break; } // the walk leaves the segment (or the data to look at)
+        r = (uint32_t)next;
     }
+    if (r != 0xFFFFFFFFu) p = a + r; // (stopped at a record it could not take)
+    if (lane < (n & 63u)) out[(n & ~63u) + lane] = mine;
     if (lane == 0) {
         S.exit = (uint32_t)min(p, (uint64_t)0xFFFFFFFEu);
         S.count = n; S.seq_bytes = so; S.qual_bytes = qo; S.cigar_words = co;

@@ -799,13 +799,18 @@ __global__ __launch_bounds__(1024) void k_inflate_resolve(const GiBlock* __restr
     if (stats) tc[2] = clock64();
     uint32_t rounds = 0;
     for (; rounds < 16u; ++rounds) { // (skipping the pairs that already point at roots — a mask per thread — changed nothing measurable)
-        uint32_t changed = 0;
+        uint32_t changed = 0, nchg = 0;
 #pragma unroll 4
         for (uint32_t q = tid; q < upad / 2u; q += 1024u) {
             const uint32_t v = pair[q], a = v & 0xFFFFu, b = v >> 16;
             const uint32_t a2 = ridx[a], b2 = ridx[b];
             changed |= (a2 ^ a) | (b2 ^ b);
+            if (stats) nchg += (a2 != a ? 1u : 0u) + (b2 != b ? 1u : 0u);
             pair[q] = a2 | (b2 << 16);
+        }
+        if (stats) { // (BQC_GI_STATS: bytes whose index still moved in this round)
+            for (int o = 32; o > 0; o >>= 1) nchg += __shfl_xor(nchg, o);
+            if ((tid & 63u) == 0u && nchg) atomicAdd(&stats[21 + (rounds < 8u ? rounds : 8u)], (unsigned long long)nchg);
         }
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
@@ -983,6 +988,8 @@ extern "C" void bqc_gpu_inflate_launch(const uint8_t* d_comp, const GiBlock* d_b
                 fprintf(stderr, "[gpu inflate] resolve clocks per block: set-up %.0f, matches listed %.0f, pointer jumping %.0f, gather %.0f\n", (double)h[8] / (h[0] ? h[0] : 1),
                         (double)h[9] / (h[0] ? h[0] : 1), (double)h[10] / (h[0] ? h[0] : 1), (double)h[11] / (h[0] ? h[0] : 1));
                 fprintf(stderr, "[gpu inflate] clock64 ticks per wall_clock64 tick (100 MHz): %.2f\n", (double)(h[8] + h[9] + h[10] + h[11]) / (h[12] ? h[12] : 1));
+                if (h[0]) fprintf(stderr, "[gpu inflate] bytes per block whose index moved in jumping round 1, 2, ..: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f, later %.0f\n", (double)h[21] / h[0], (double)h[22] / h[0],
+                                  (double)h[23] / h[0], (double)h[24] / h[0], (double)h[25] / h[0], (double)h[26] / h[0], (double)h[27] / h[0], (double)h[28] / h[0], (double)h[29] / h[0]);
             }
             if (h[0] || h[4])
                 fprintf(stderr, "[gpu inflate] resolve: %llu blocks, %llu matches, %llu rounds; phase 1 by waves: %llu deflate blocks, %llu scan rounds; clocks per wave: header + tables %.0f, scan %.0f, write %.0f\n", h[0], h[7], h[2], h[4], h[3],
