@@ -130,7 +130,19 @@ __global__ __launch_bounds__(1024) void k_prep_scan(PrepArgs a)
 // per read
 // ---------------------------------------------------------------------------------------------------
 // checkFlagsAndQuality (TripletCounting.hpp:136-168): 1 eligible, 0 not, -1 fatal
-__device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, int32_t as, const uint32_t* cg, uint32_t ncig)
+// A read's CIGAR as the pre-pass sees it: the first four words in registers — requested for all of a thread's reads at once, before any
+// of them is looked at (round 4: read where they were needed, behind the stores and atomics of the read before, they were a chain of
+// dependent round trips per thread: the kernel's whole time) —, the rest from memory.
+struct CigarView {
+    uint32_t w[4];
+    const uint32_t* cg;
+    __device__ __forceinline__ uint32_t at(uint32_t k) const
+    {
+        if (k < 4u) return k == 0u ? w[0] : k == 1u ? w[1] : k == 2u ? w[2] : w[3];
+        return cg[k];
+    }
+};
+__device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, int32_t as, const CigarView& cv, uint32_t ncig)
 {
     if (!(flag & 0x1) || !(flag & 0x2) || (flag & 0x4) || (flag & 0x8) || (flag & 0x100)) return 0;
     if (mapq < 60) return 0;
@@ -138,8 +150,8 @@ __device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, in
     if (as < 50) return 0;
     uint32_t clipped = 0;
     for (uint32_t k = 0; k < ncig; ++k) {
-        const uint32_t op = cg[k] & 15u;
-        if (op == 4u || op == 5u) clipped += cg[k] >> 4;
+        const uint32_t wd = cv.at(k), op = wd & 15u;
+        if (op == 4u || op == 5u) clipped += wd >> 4;
     }
     return clipped > 0 ? 0 : 1;
 }
@@ -147,7 +159,8 @@ __device__ __forceinline__ int triplet_eligible(uint32_t flag, uint32_t mapq, in
 // One read's share of the pre-pass.  Everything but the payload offsets and the cross-read part of the FASTA scan.
 struct ReadIn { uint32_t L, nc, flag, lane, mapq; int32_t rid, pos, as; CovEntry ce; };
 struct ReadOut { uint32_t flag, cls, tgt1; CovEntry ce; };
-__device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& refs, uint32_t i, const ReadIn& in, uint32_t co, bool offsets_ok)
+__device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& refs, uint32_t i, const ReadIn& in, uint32_t co, bool offsets_ok,
+                                            const CigarView& cv, bool ref_loaded /* refs.ref[rid] != nullptr (rid in range) */, int32_t target_in /* the contig's FASTA record, -1: none */)
 {
     ReadOut o;
     uint32_t flag = in.flag & (0x0FFFu | BQC_FLAG_MATE_MAIN | BQC_FLAG_NO_QUAL);
@@ -158,7 +171,6 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
     else if (lane >= a.n_lanes) err_key(a.err, i, 2);
     // (BQC_FLAG_NO_QUAL — quality block starting with 0xFF, SURVEY U1 — is a fact of the record's decoding and arrives with the
     // flag column: probing qual[qo] here cost one 128-byte line per read, more than every other byte this kernel reads)
-    const uint32_t* cg = a.cigar + co;
     if (!offsets_ok) nc = 0; // (the batch fails: k_prep_scan)
     const bool fast = !a.no_fast && L <= BQC_FAST_MAXLEN;
     uint32_t nseg = 0;
@@ -166,13 +178,11 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
     if (!(flag & 0x900u)) { // primary record: bamqualcheck.cpp:318-327
         const bool dup = flag & 0x400u, qcf = flag & 0x200u;
         if (!dup && !qcf) { // tripletCounting, :338-342
-            const int e = triplet_eligible(flag, in.mapq, in.as, cg, nc);
+            const int e = triplet_eligible(flag, in.mapq, in.as, cv, nc);
             if (e < 0) err_key(a.err, i, 4);
             if (e > 0) { // Genome: forward-only FASTA scan (TripletCounting.hpp:254-259)
-                const int32_t rid = in.rid;
-                int32_t target = -1;
-                if (rid >= 0 && (uint32_t)rid < refs.n_refs) target = a.fasta_index ? a.fasta_index[rid] : rid;
-                if (target < 0 || refs.ref[rid] == nullptr) err_key(a.err, i, 5);
+                const int32_t target = target_in;
+                if (target < 0 || !ref_loaded) err_key(a.err, i, 5);
                 else { o.tgt1 = (uint32_t)target + 1u; flag |= BQC_FLAG_TRIPLET; }
             }
         }
@@ -211,11 +221,11 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
             else atomicOr(&a.err->flags, BQC_DEVERR_INTERNAL); // (capacity = CIGAR words / 2 + 1: cannot happen)
         };
         if (nc == 1u) { // (nearly every read: no loop)
-            const uint32_t w = cg[0], op = w & 15u, nn = w >> 4;
+            const uint32_t w = cv.w[0], op = w & 15u, nn = w >> 4;
             if (op == 0u || op == 2u) emit(pos, pos + nn);
         } else {
             for (uint32_t k = 0; k < nc; ++k) {
-                const uint32_t w = cg[rc ? nc - 1 - k : k], op = w & 15u, nn = w >> 4;
+                const uint32_t w = cv.at(rc ? nc - 1 - k : k), op = w & 15u, nn = w >> 4;
                 if (op == 4u) cc += nn;
                 if (op == 0u || op == 2u) {
                     const int64_t lo = pos + (int64_t)cc, hi = lo + nn;
@@ -231,12 +241,12 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
     // k_short evaluates triplets with chromPos = pos + i inside the first CIGAR operation (assumed match-like,
     // TripletCounting.hpp:203); every further match-like operation becomes a segment entry with its own offset
     if (fast && (flag & BQC_FLAG_TRIPLET) && nc > 1 && L >= 3) {
-        const uint32_t n0 = cg[0] >> 4;
+        const uint32_t n0 = cv.w[0] >> 4;
         if (n0 != 0) { // (n0 == 0: every position counts as inside the first operation, no walk)
             uint64_t rp = n0;
             int64_t cpos = (int64_t)in.pos + n0;
             for (uint32_t k2 = 1; k2 < nc && rp < L; ++k2) {
-                const uint32_t op = cg[k2] & 15u, nn = cg[k2] >> 4;
+                const uint32_t wk = cv.at(k2), op = wk & 15u, nn = wk >> 4;
                 if (op == 2u || op == 3u || op == 5u || op == 6u) cpos += nn;   // D N H P
                 else if (op == 4u || op == 1u) rp += nn;                          // S I
                 else {                                                            // M = X (and unknown)
@@ -259,7 +269,10 @@ __device__ __forceinline__ ReadOut prep_one(const PrepArgs& a, const DevRefs& re
 
 // Thread t of a workgroup owns the four consecutive reads b0 + 4t .. + 3: their columns are 8- / 16-byte loads, the payload
 // offsets are a serial prefix inside the thread plus ONE workgroup scan per quantity, and so is the forward-only FASTA scan.
-__global__ __launch_bounds__(PR_THREADS) void k_prep_reads(PrepArgs a, DevRefs refs)
+#ifndef PR_WAVES_PER_EU
+#define PR_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(PR_THREADS) __attribute__((amdgpu_waves_per_eu(PR_WAVES_PER_EU, PR_WAVES_PER_EU))) void k_prep_reads(PrepArgs a, DevRefs refs)
 {
     __shared__ uint32_t sh[2 * (PR_THREADS / 64)];
     __shared__ uint32_t red[8];
@@ -294,15 +307,33 @@ __global__ __launch_bounds__(PR_THREADS) void k_prep_reads(PrepArgs a, DevRefs r
     uint32_t tot;
     const unsigned long long bs = gs + block_scan_excl(ts, sh, &tot), bq = gq + block_scan_excl(tq, sh, &tot), bc = gc + block_scan_excl(tc, sh, &tot);
     ReadOut out[4];
+    // what the four reads need from memory besides their columns, all of it requested before the first read is looked at
+    CigarView cv[4];
+    bool ref_loaded[4];
+    int32_t target[4];
+    unsigned long long cos[4];
+    bool oks[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long so = bs + ls[j], qo = bq + lq[j], co = bc + lc[j];
+        cos[j] = co;
+        oks[j] = so + (in[j].L + 1) / 2 <= 0xFFFFFFFFull && qo + in[j].L <= 0xFFFFFFFFull && co + in[j].nc <= 0xFFFFFFFFull;
+        const bool live = (uint32_t)j < nlive && oks[j];
+        cv[j].cg = a.cigar + (uint32_t)co;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) cv[j].w[k] = live && k < in[j].nc ? cv[j].cg[k] : 0u;
+        const int32_t rid = in[j].rid;
+        const bool rid_ok = (uint32_t)j < nlive && rid >= 0 && (uint32_t)rid < refs.n_refs;
+        ref_loaded[j] = rid_ok && refs.ref[rid] != nullptr;
+        target[j] = rid_ok ? (a.fasta_index ? a.fasta_index[rid] : rid) : -1;
+    }
     uint32_t tmax = 0, tmin = 0xFFFFFFFFu, maxfast = 0, maxlong = 0, cnt[4] = {0, 0, 0, 0};
     bool local_bad[4] = {false, false, false, false};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         out[j] = ReadOut{0x900u, 2u << 8, 0, CovEntry{BQC_COV_NONE, 0}};
         if ((uint32_t)j >= nlive) continue;
-        const unsigned long long so = bs + ls[j], qo = bq + lq[j], co = bc + lc[j];
-        const bool ok = so + (in[j].L + 1) / 2 <= 0xFFFFFFFFull && qo + in[j].L <= 0xFFFFFFFFull && co + in[j].nc <= 0xFFFFFFFFull;
-        out[j] = prep_one(a, refs, i0 + j, in[j], (uint32_t)co, ok);
+        out[j] = prep_one(a, refs, i0 + j, in[j], (uint32_t)cos[j], oks[j], cv[j], ref_loaded[j], target[j]);
         if (out[j].tgt1) { local_bad[j] = out[j].tgt1 < tmax; tmax = max(tmax, out[j].tgt1); tmin = min(tmin, out[j].tgt1); }
         const uint32_t cl = out[j].cls >> 8;
         if (cl == 2u) maxlong = max(maxlong, in[j].L); else maxfast = max(maxfast, in[j].L);
