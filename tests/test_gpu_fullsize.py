@@ -90,3 +90,28 @@ def test_config5_long_reads_parity_and_properties():
     assert o.process(cols) == 0
     d = _abi.diff_counts(o.finalize(), got)
     assert not d, d[:5]
+
+
+def test_twelve_read_groups_every_workgroup_meets_more_than_its_rows():
+    """The packed 8-mer counters of a workgroup leave through at most BQC_T8_SPW = 8 scratch rows per launch, one per read group it meets
+    (round 4: every read group's, with the read group noted in the slot's directory); a workgroup that meets more read groups than it has
+    rows adds the rest by atomics (one bin per lane).  2.4 M reads of twelve read groups in ONE batch: every workgroup of k_short walks
+    chunks of all twelve.  Bit-exact against the oracle, per read group."""
+    lens = [6_000_000, 4_000_000]
+    refs = [csynth.reference(77, i, n) for i, n in enumerate(lens)]
+    n, n_lanes = 2_400_000, 12
+    cols = csynth.batch(77, n, lens, refs, n_lanes=n_lanes)
+    assert len(np.unique(cols["lane"])) == n_lanes
+    agg = Aggregator(n_refs=2, n_lanes=n_lanes, klist=(), qlist=())
+    for i, r in enumerate(refs):
+        agg.set_reference(i, r)
+    agg.submit(cols)
+    got = agg.finalize()
+    o = Oracle(n_refs=2, n_lanes=n_lanes, klist=(), qlist=())
+    for i, r in enumerate(refs):
+        o.reference(i, r)
+    assert o.process(cols) == 0
+    want = o.finalize()
+    d = _abi.diff_counts(want, got)
+    assert not d, "\n".join(d[:20])
+    assert sum(int(c["eightmer"].sum()) for c in got) > 100 * n
