@@ -277,10 +277,12 @@ __global__ __launch_bounds__(64) void k_gb_walk_wave(const uint8_t* __restrict__
 }
 
 // workgroup per taken segment, thread per record: the fixed columns and the tag scan of host/bam_io.cpp
+#define GBD_STAGE 64u // bytes of a record's optional fields staged in LDS (k_gb_decode)
 __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ base, const GbSeg* __restrict__ segs, const GbRec* __restrict__ recs,
                                                    const GbBase* __restrict__ bases, GbCols C, GbLanes LN, const uint8_t* __restrict__ main_chrom, uint32_t n_main,
                                                    uint32_t* __restrict__ status)
 {
+    __shared__ uint32_t tagbuf[64][GBD_STAGE / 4 + 1]; // a record's first optional fields, per thread (an odd stride: the lanes' words in different banks)
     const uint32_t s = blockIdx.x;
     const GbBase B = bases[s];
     if (!B.take) return;
@@ -295,36 +297,55 @@ __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ ba
         const uint32_t l_name = r[8], mapq = r[9], n_cig = ld16(r + 12), flag = ld16(r + 14), l_seq = ld32(r + 16);
         const int32_t rnext = (int32_t)ld32(r + 20), tlen = (int32_t)ld32(r + 28);
         const uint8_t* ql = r + 32 + l_name + 4ull * n_cig + (l_seq + 1u) / 2u;
-        const uint8_t* tg = ql + l_seq;
+        const uint8_t* const tg0 = ql + l_seq;
         const uint8_t* te = r + bs;
         int lane = -1;
         bool rg_seen = false, as_seen = false, nm_seen = false;
         int32_t nm = BQC_NM_ABSENT, as = BQC_AS_ABSENT;
-        while (tg + 3 <= te) {
-            const char k0 = (char)tg[0], k1 = (char)tg[1], ty = (char)tg[2];
-            const uint8_t* v = tg + 3;
+        // The optional fields are walked byte by byte, every byte the address of the next: from memory that was a chain of dependent
+        // loads (the kernel's whole time).  Round 4: a record's first GBD_STAGE bytes of fields come into LDS with four 16-byte loads
+        // issued together (what lies behind them, if anything, is read from memory as before; the buffer's slack covers the over-read).
+        const uint64_t tlen_all = te > tg0 ? (uint64_t)(te - tg0) : 0;
+        uint32_t* const tb = tagbuf[threadIdx.x];
+        {
+            gb_u32x4 v[GBD_STAGE / 16];
+#pragma unroll
+            for (uint32_t k = 0; k < GBD_STAGE / 16; ++k) v[k] = 16u * k < tlen_all ? *(const gb_u32x4_u*)(tg0 + 16u * k) : gb_u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t k = 0; k < GBD_STAGE / 16; ++k) { tb[4 * k] = v[k].x; tb[4 * k + 1] = v[k].y; tb[4 * k + 2] = v[k].z; tb[4 * k + 3] = v[k].w; }
+        }
+        auto t8 = [&](uint64_t o) -> uint32_t { return o < GBD_STAGE ? (tb[(uint32_t)o >> 2] >> (8u * ((uint32_t)o & 3u))) & 255u : (uint32_t)tg0[o]; };
+        auto t16 = [&](uint64_t o) -> uint32_t { return t8(o) | (t8(o + 1) << 8); };
+        auto t32 = [&](uint64_t o) -> uint32_t {
+            if (o + 4 <= GBD_STAGE) { const uint32_t w = (uint32_t)o >> 2, sh = (uint32_t)o & 3u; return __builtin_amdgcn_alignbyte(tb[w + 1], tb[w], sh); } // (a spare word behind the stage)
+            return t8(o) | (t8(o + 1) << 8) | (t8(o + 2) << 16) | (t8(o + 3) << 24);
+        };
+        uint64_t tg = 0; // offset of the next field from tg0
+        while (tg + 3 <= tlen_all) {
+            const char k0 = (char)t8(tg), k1 = (char)t8(tg + 1), ty = (char)t8(tg + 2);
+            const uint64_t v = tg + 3;
             uint64_t len = 0;
             switch (ty) {
             case 'A': case 'c': case 'C': len = 1; break;
             case 's': case 'S': len = 2; break;
             case 'i': case 'I': case 'f': len = 4; break;
             case 'Z': case 'H': {
-                const uint8_t* z = v;
-                while (z < te && *z) ++z;
-                len = z < te ? (uint64_t)(z - v) + 1 : (uint64_t)(te - v);
+                uint64_t z = v;
+                while (z < tlen_all && t8(z)) ++z;
+                len = z < tlen_all ? (z - v) + 1 : tlen_all - v;
                 break;
             }
             case 'B': {
-                if (v + 5 > te) { len = (uint64_t)(te - v); break; }
-                const char st = (char)v[0];
-                const uint64_t cnt = ld32(v + 1);
+                if (v + 5 > tlen_all) { len = tlen_all - v; break; }
+                const char st = (char)t8(v);
+                const uint64_t cnt = t32(v + 1);
                 const uint64_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
                 len = 5 + cnt * es;
                 break;
             }
-            default: len = (uint64_t)(te - v); break;
+            default: len = tlen_all - v; break;
             }
-            if (len > (uint64_t)(te - v)) { exc |= GBX_TAGS; break; }
+            if (len > tlen_all - v) { exc |= GBX_TAGS; break; }
             if (k0 == 'R' && k1 == 'G' && !rg_seen) {
                 rg_seen = true;
                 if (ty == 'Z') {
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ ba
                         if (LN.len[l] != idl) continue;
                         const uint8_t* id = LN.blob + LN.off[l];
                         uint32_t k = 0;
-                        while (k < idl && id[k] == v[k]) ++k;
+                        while (k < idl && id[k] == t8(v + k)) ++k;
                         if (k == idl) lane = (int)LN.index[l];
                     }
                     if (lane < 0) { exc |= GBX_RG_UNKNOWN; lane = 0; }
@@ -341,24 +362,24 @@ __global__ __launch_bounds__(64) void k_gb_decode(const uint8_t* __restrict__ ba
             } else if (k0 == 'N' && k1 == 'M' && (ty == 'c' || ty == 'C' || ty == 's' || ty == 'S' || ty == 'i' || ty == 'I')) {
                 uint32_t x;
                 switch (ty) {
-                case 'c': x = (uint32_t)(int32_t)(int8_t)v[0]; break;
-                case 'C': x = v[0]; break;
-                case 's': x = (uint32_t)(int32_t)(int16_t)ld16(v); break;
-                case 'S': x = ld16(v); break;
-                default: x = ld32(v); break;
+                case 'c': x = (uint32_t)(int32_t)(int8_t)t8(v); break;
+                case 'C': x = t8(v); break;
+                case 's': x = (uint32_t)(int32_t)(int16_t)t16(v); break;
+                case 'S': x = t16(v); break;
+                default: x = t32(v); break;
                 }
                 if (!nm_seen) { nm = (int32_t)x; nm_seen = true; }
                 else exc |= GBX_NM_EXTRA;
             } else if (k0 == 'A' && k1 == 'S' && !as_seen) {
                 as_seen = true;
                 switch (ty) {
-                case 'A': as = (int32_t)(char)v[0]; break;
-                case 'c': as = (int8_t)v[0]; break;
-                case 'C': as = v[0]; break;
-                case 's': as = (int16_t)ld16(v); break;
-                case 'S': as = (int32_t)ld16(v); break;
-                case 'i': case 'I': as = (int32_t)ld32(v); break;
-                case 'f': as = (int32_t)__uint_as_float(ld32(v)); break;
+                case 'A': as = (int32_t)(char)t8(v); break;
+                case 'c': as = (int8_t)t8(v); break;
+                case 'C': as = (int32_t)t8(v); break;
+                case 's': as = (int16_t)t16(v); break;
+                case 'S': as = (int32_t)t16(v); break;
+                case 'i': case 'I': as = (int32_t)t32(v); break;
+                case 'f': as = (int32_t)__uint_as_float(t32(v)); break;
                 default: as = BQC_AS_ABSENT; break;
                 }
             }
