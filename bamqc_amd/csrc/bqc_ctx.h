@@ -111,20 +111,20 @@ struct Slot { // one batch in flight through bqc_submit / bqc_submit_async
 // bqc_anchor_complete run in the thread that decodes the batches, bqc_submit_anchored in the one that submits them.
 struct bqc_anchored {
     AnchorSummary* h_sum = nullptr;   // page-locked: the batch's summary ...
-    AnchorBound* h_bound = nullptr;   // ... and the first kInline entries of its boundary list
-    std::vector<AnchorBound> rest;    // the entries behind them (sparse data), fetched by bqc_anchor_complete
+    uint32_t* h_bound = nullptr;      // ... and the first kInline entries of first_of[] (anchor.h)
+    std::vector<uint32_t> rest;       // the entries behind them (sparse data), fetched by bqc_anchor_complete
     std::vector<int32_t> pend_rid;    // a shard_tail context: the reads set aside (the batch's first n_pending candidates) ...
     std::vector<uint32_t> pend_bp;    // ... chromosome and beginPos, for the pending log (bqc_shard_resolve)
     const CovEntry* d_cov = nullptr;  // the caller's device buffer with the anchors of the batch's reads
     uint32_t n = 0;
     bool completed = false;
-    static const uint32_t kInline = 1u << 16;
+    static const uint32_t kInline = 1u << 17;
 };
 struct AnchorEngine {
     std::atomic<int> mode{0};         // 0: not used yet, 1: the card keeps the state, 2: off for the rest of the stream (the host keeps it)
     AnchorState* d_state = nullptr;
     AnchorSummary* d_sum = nullptr;
-    AnchorBound* d_bound = nullptr;
+    uint32_t* d_bound = nullptr;
     void* d_scratch = nullptr;
     size_t cap_n = 0;                 // reads the scratch buffers are sized for
     std::mutex m;                     // the free list (handles come back from the submitting thread)

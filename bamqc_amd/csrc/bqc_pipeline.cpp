@@ -330,14 +330,20 @@ static int host_pass_anchored(bqc_ctx* c, uint32_t n, const bqc_anchored* a, Hos
     lc.first = S.before.first != 0; lc.id = S.before.id; lc.shift = S.before.shift; lc.win = S.before.win;
     CovPlanner plan(c, H, n);
     if (S.n_cand > S.n_pending) {
-        // first[k] = the first read whose window is >= k: from the boundary list (any order on the card: sorted here)
-        std::vector<AnchorBound> bl(a->h_bound, a->h_bound + std::min<uint32_t>(S.n_bound, bqc_anchored::kInline));
-        bl.insert(bl.end(), a->rest.begin(), a->rest.end());
-        std::sort(bl.begin(), bl.end(), [](const AnchorBound& x, const AnchorBound& y) { return x.rel < y.rel; });
+        // first[k] = the first read whose window is >= k: the card's first_of[] (the first read whose window IS k, AN_NO_READ where a
+        // reset skipped k), filled from the back
+        const size_t total = (size_t)S.last_rel + 1, inl = std::min<size_t>(total, bqc_anchored::kInline);
+        if (total > inl + a->rest.size()) return bqc_fail(c, BQC_ERR_DEVICE, "internal error: the anchors' window table is shorter than the last window");
         std::vector<uint32_t>& first = H.lane_first[0];
-        for (const AnchorBound& e : bl) if (first.size() <= e.rel) first.resize((size_t)e.rel + 1, e.idx);
+        first.assign(total, AN_NO_READ);
+        uint32_t cur = AN_NO_READ;
+        for (size_t k = total; k-- > 0;) {
+            const uint32_t v = k < inl ? a->h_bound[k] : a->rest[k - inl];
+            if (v != AN_NO_READ) cur = v;
+            first[k] = cur;
+        }
         plan.last_rel[0] = S.last_rel;
-        if (first.size() != (size_t)S.last_rel + 1) return bqc_fail(c, BQC_ERR_DEVICE, "internal error: the anchors' boundary list does not end at the last window");
+        if (first[total - 1] == AN_NO_READ) return bqc_fail(c, BQC_ERR_DEVICE, "internal error: the anchors' window table does not end at the last window");
     }
     lc.first = S.after.first != 0; lc.id = S.after.id; lc.shift = S.after.shift; lc.win = S.after.win; // (batch_base: set by the planner, advanced by finish())
     plan.finish();
@@ -818,7 +824,7 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
         if (E.d_scratch) (void)hipFree(E.d_scratch);
         E.d_scratch = nullptr; E.cap_n = 0;
         const size_t cap = std::max<size_t>(n + n / 8, 1u << 20);
-        const size_t bytes = cap * 24 + AN_MAX_BREAKS * (4 + sizeof(AnchorRun)) + (cap / 1024 + 4) * (2 * 4 + sizeof(AnchorPart)) + 4096;
+        const size_t bytes = cap * 24 + 64 + AN_MAX_BREAKS * (4 + sizeof(AnchorRun)) + (cap / 1024 + 4) * (2 * 4 + sizeof(AnchorPart)) + 4096;
         if (hipMalloc(&E.d_scratch, bytes) != hipSuccess) return anchor_fail(c, "out of device memory");
         E.cap_n = cap;
     }
@@ -830,7 +836,7 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
     if (!a) {
         a = new bqc_anchored();
         if (hipHostMalloc((void**)&a->h_sum, sizeof(AnchorSummary), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void**)&a->h_bound, sizeof(AnchorBound) * bqc_anchored::kInline, hipHostMallocDefault) != hipSuccess) {
+            hipHostMalloc((void**)&a->h_bound, sizeof(uint32_t) * bqc_anchored::kInline, hipHostMallocDefault) != hipSuccess) {
             if (a->h_sum) (void)hipHostFree(a->h_sum);
             delete a;
             return anchor_fail(c, "out of page-locked memory");
@@ -847,16 +853,18 @@ extern "C" int bqc_anchor_enqueue(bqc_ctx* c, const bqc_batch* b, void* d_cov, v
     char* q = (char*)E.d_scratch;
     const size_t cap = E.cap_n;
     A.cpos = (uint32_t*)q; q += 4 * cap; A.crid = (int32_t*)q; q += 4 * cap; A.cidx = (uint32_t*)q; q += 4 * cap; A.crun = (uint32_t*)q; q += 4 * cap;
-    A.bound = (AnchorBound*)q; q += 8 * cap; A.bound_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    A.first_of = (uint32_t*)q; q += 8 * cap + 64; A.first_cap = (uint32_t)std::min<size_t>(2 * cap + 16, 0xFFFFFFFFu);
     A.bj = (uint32_t*)q; q += 4 * AN_MAX_BREAKS; A.runs = (AnchorRun*)q; q += sizeof(AnchorRun) * AN_MAX_BREAKS;
     q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
     A.blk_a = (uint32_t*)q; q += 4 * (cap / 1024 + 4); A.blk_b = (uint32_t*)q; q += 4 * (cap / 1024 + 4);
     q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
     A.parts = (AnchorPart*)q;
-    E.d_bound = A.bound;
+    E.d_bound = A.first_of;
+    const size_t n_first = std::min<size_t>(2 * n + 16, A.first_cap); // (windows a batch of n reads can reach)
+    if (hipMemsetAsync(A.first_of, 0xFF, 4 * n_first, st) != hipSuccess) { std::lock_guard<std::mutex> lk(E.m); E.free_list.push_back(a); return anchor_fail(c, "memset failed"); }
     bqc_launch_anchor(A, st);
     if (hipMemcpyAsync(a->h_sum, E.d_sum, sizeof(AnchorSummary), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(a->h_bound, A.bound, sizeof(AnchorBound) * std::min<size_t>(bqc_anchored::kInline, std::max<size_t>(n, 1)), hipMemcpyDeviceToHost, st) != hipSuccess) {
+        hipMemcpyAsync(a->h_bound, A.first_of, sizeof(uint32_t) * std::min<size_t>(bqc_anchored::kInline, n_first), hipMemcpyDeviceToHost, st) != hipSuccess) {
         std::lock_guard<std::mutex> lk(E.m);
         E.free_list.push_back(a);
         return anchor_fail(c, "copy failed");
@@ -879,10 +887,10 @@ extern "C" int bqc_anchor_complete(bqc_ctx* c, bqc_anchored* a, bqc_anchor_info*
         E.free_list.push_back(a);
         return 1;
     }
-    if (S.n_bound > bqc_anchored::kInline) { // (sparse data: the rest of the list, before the next batch's kernels reuse the buffer)
-        a->rest.resize(S.n_bound - bqc_anchored::kInline);
+    if (S.n_cand > S.n_pending && (size_t)S.last_rel + 1 > bqc_anchored::kInline) { // (sparse data: the rest of the table, before the next batch's kernels reuse the buffer)
+        a->rest.resize((size_t)S.last_rel + 1 - bqc_anchored::kInline);
         if (hipSetDevice(c->device) != hipSuccess ||
-            hipMemcpy(a->rest.data(), E.d_bound + bqc_anchored::kInline, sizeof(AnchorBound) * a->rest.size(), hipMemcpyDeviceToHost) != hipSuccess) return anchor_fail(c, "copy failed");
+            hipMemcpy(a->rest.data(), E.d_bound + bqc_anchored::kInline, sizeof(uint32_t) * a->rest.size(), hipMemcpyDeviceToHost) != hipSuccess) return anchor_fail(c, "copy failed");
     }
     if (S.n_pending) { // the reads set aside: chromosome and position of the batch's first n_pending candidates (the scratch's crid / cpos)
         a->pend_rid.resize(S.n_pending); a->pend_bp.resize(S.n_pending);

@@ -343,8 +343,7 @@ __global__ __launch_bounds__(256) void k_an_apply(AnchorArgs a)
         boundary = relp != rel;
     }
     if (boundary) {
-        const uint32_t at = atomicAdd(&a.sum->n_bound, 1u);
-        if (at < a.bound_cap) a.bound[at] = AnchorBound{rel, i};
+        if (rel < a.first_cap) a.first_of[rel] = i;
         else atomicOr(&a.sum->flags, AN_FLAG_BOUND_OVERFLOW);
     }
 }
